@@ -1,0 +1,171 @@
+/*
+ * rtggx.h -- C ABI of librtggx, the MI355X (gfx950) implementation of the RayTracedGGX hot path.
+ *
+ * This is the drop-in boundary: each entry point replaces one method of the
+ * reference's pass objects, minus the D3D12 handle parameters.  The reference-side binding a
+ * maintainer would add is shown in INTEGRATION.md.  No C++ or torch types cross this boundary;
+ * every function returns 0 on success or a negative code (text via rtggx_last_error()).
+ * A context is used from one host thread and owns all device memory; host arrays passed to
+ * rtggx_set_* are copied before the call returns.
+ *
+ *   reference interface (RayTracedGGX/...)                          entry point
+ *   -------------------------------------------------------------   ---------------------------
+ *   RayTracer::Init            Content/RayTracer.h:24-29, .cpp:66    rtggx_create + rtggx_set_mesh + rtggx_set_env
+ *   Denoiser::Init             Content/Denoiser.h:15-17, .cpp:21     rtggx_create (render targets of both)
+ *   createVB/createIB/createGroundMesh   RayTracer.cpp:393-511       rtggx_set_mesh
+ *   DDS::Loader::CreateTextureFromFile   RayTracer.cpp:143-150       rtggx_set_env
+ *   buildAccelerationStructures + BuildAccelerationStructures        rtggx_build_as
+ *                              RayTracer.cpp:676-716, 158-233
+ *   RayTracer::SetMetallic     RayTracer.cpp:244-248                 rtggx_set_metallic
+ *   CBMaterial upload          RayTracer.cpp:129-140                 rtggx_set_material
+ *   RayTracer::UpdateFrame     RayTracer.cpp:250-305 (constants)     rtggx_update_frame
+ *   RayTracer::UpdateAccelerationStructure   RayTracer.cpp:326-341   rtggx_update_as
+ *   RayTracer::TransformSH     RayTracer.cpp:307-310                 rtggx_transform_sh
+ *   RayTracer::RenderVisibility RayTracer.cpp:343-365, 751-791       rtggx_render_visibility
+ *   RayTracer::RayTrace        RayTracer.cpp:367-376, 793-810        rtggx_ray_trace
+ *   Denoiser::Denoise          Denoiser.cpp:66-75                    rtggx_denoise
+ *   Denoiser::ToneMap          Denoiser.cpp:77-103                   rtggx_tone_map
+ *   GetRayTracingOutputs/GetGBuffers/GetDepth  RayTracer.cpp:378-391 rtggx_readback / rtggx_buffer_ptr
+ *   WaitForGpu                 RayTracedGGX.cpp:672-682              rtggx_sync
+ */
+#ifndef RTGGX_H
+#define RTGGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtggx_context rtggx_context;
+
+enum { RTGGX_GROUND = 0, RTGGX_MODEL_OBJ = 1, RTGGX_NUM_MESH = 2 };   /* RayTracer::MeshIndex, RayTracer.h:13-19 */
+
+/* Constant buffers of the reference, byte for byte.  4x4 matrices are
+ * stored as the reference uploads them (XMStoreFloat4x4 of the transpose): logical row-vector
+ * matrix M[i][j] = f[j*4+i].  3x4 blocks are XMStoreFloat3x4 images. */
+typedef struct RtggxCBGlobal {            /* RayTracer.cpp:27-35  <->  RayTracing.hlsl:46-53 */
+  float    WorldViewProjs[2][16];
+  float    WorldViewProjsPrev[2][16];
+  float    Worlds[2][12];
+  float    WorldITs0[12];
+  float    WorldIT1[11];
+  uint32_t FrameIndex;
+} RtggxCBGlobal;
+typedef struct RtggxRayGenConstants {     /* RayTracer.cpp:20-25  <->  RayTracing.hlsl:55-60 */
+  float ProjToWorld[16];
+  float EyePt[4];
+  float ProjBias[2];
+  float pad[2];
+} RtggxRayGenConstants;
+typedef struct RtggxCBPerObject {         /* RayTracer.cpp:37-41  <->  VSVisibility.hlsl:17-21 */
+  float WorldViewProj[16];
+  float ProjBias[2];
+  float pad[2];
+} RtggxCBPerObject;
+typedef struct RtggxCBMaterial {          /* RayTracer.cpp:43-47  <->  Material.hlsli:10-14 */
+  float BaseColors[2][4];
+  float RoughMetals[2][4];
+} RtggxCBMaterial;
+typedef struct RtggxFrameConstants {      /* 768 bytes */
+  RtggxCBGlobal        global;
+  RtggxRayGenConstants rayGen;
+  RtggxCBPerObject     perObject[2];
+  RtggxCBMaterial      material;          /* ignored by rtggx_update_frame: CBMaterial is persistent, see rtggx_set_material */
+} RtggxFrameConstants;
+
+/* Environment texel formats accepted by rtggx_set_env (DXGI numbering). */
+enum { RTGGX_FORMAT_RGBA32F = 2, RTGGX_FORMAT_RGBA16F = 10, RTGGX_FORMAT_BC6H_UF16 = 95 };
+
+/* Buffers readable with rtggx_readback (one element per pixel unless noted). */
+enum {
+  RTGGX_BUF_VISIBILITY = 0,  /* uint32  ((instance<<24)|primitive)+1, 0 = empty   PSVisibility.hlsl:23 */
+  RTGGX_BUF_DEPTH = 1,       /* uint32  D24 value in the low 24 bits */
+  RTGGX_BUF_NORMAL = 2,      /* uint32  R10G10B10A2_UNORM */
+  RTGGX_BUF_ROUGH_METAL = 3, /* uint16  R8G8_UNORM */
+  RTGGX_BUF_VELOCITY = 4,    /* uint32  R16G16_FLOAT */
+  RTGGX_BUF_RT_REFL = 5,     /* uint32  R11G11B10_FLOAT, RayTracingOut0 */
+  RTGGX_BUF_RT_DIFF = 6,     /* uint32  R11G11B10_FLOAT, RayTracingOut1 */
+  RTGGX_BUF_TSS0 = 7,        /* uint64  R16G16B16A16_FLOAT, TemporalSSOut0 */
+  RTGGX_BUF_TSS1 = 8,        /* uint64  TemporalSSOut1 */
+  RTGGX_BUF_FLT_RFL = 9,     /* uint64  FilteredOut */
+  RTGGX_BUF_FLT_DFF = 10,    /* uint64  FilteredOut1 */
+  RTGGX_BUF_BACKBUFFER = 11, /* uint32  R8G8B8A8_UNORM */
+  RTGGX_BUF_SH_COEFFS = 12,  /* 27 floats: 9 x float3 */
+  RTGGX_BUF_BVH_NODES0 = 13, /* 64-byte nodes of mesh 0 (see DESIGN.md "BVH layout") */
+  RTGGX_BUF_BVH_TRIS0 = 14,  /* 48-byte leaf triangles of mesh 0 */
+  RTGGX_BUF_BVH_NODES1 = 15,
+  RTGGX_BUF_BVH_TRIS1 = 16,
+  RTGGX_BUF_TLAS = 17,       /* 2 x 16 floats: world->object matrices (row-vector, row-major) */
+  RTGGX_BUF_ENV = 18,        /* decoded RGBA16F environment, mip-major, 6 faces per mip */
+  RTGGX_BUF_COUNT = 19
+};
+
+/* Per-pass GPU timings of the last completed frame, in milliseconds (hipEvent based). */
+typedef struct RtggxTimings {
+  float update_as, visibility, ray_trace, spatial_refl_h, spatial_refl_v, spatial_diff_h, spatial_diff_v,
+        temporal, tone_map, frame;
+} RtggxTimings;
+
+const char* rtggx_last_error(void);
+
+/* Creates a context on HIP device `device` with all render targets of RayTracer::Init and
+ * Denoiser::Init for a width x height viewport.  The ground mesh of createGroundMesh and the
+ * default materials are installed. */
+int  rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int device);
+void rtggx_destroy(rtggx_context* ctx);
+
+/* Restrict rendering to the row strip [row_begin, row_end) of the full frame (multi-GPU screen
+ * tiling); buffers stay full-size, rows outside the strip (plus the apron the
+ * filters need) are not touched.  Default: the whole frame. */
+int  rtggx_set_strip(rtggx_context* ctx, uint32_t row_begin, uint32_t row_end);
+
+/* Run every pass on an externally owned hipStream_t (e.g. torch's current stream). NULL restores
+ * the context's own streams. */
+int  rtggx_set_stream(rtggx_context* ctx, void* hip_stream);
+
+/* Vertex = {float3 Pos; float3 Nrm} (24 bytes), 32-bit indices, triangle list. */
+int  rtggx_set_mesh(rtggx_context* ctx, uint32_t slot, const float* verts, uint32_t num_verts,
+                    const uint32_t* indices, uint32_t num_indices);
+/* Cube map: `size` x `size` faces, `mips` levels, `data` laid out as in a DDS file (face-major,
+ * full mip chain per face, faces +X -X +Y -Y +Z -Z).  BC6H blocks are decoded on the device. */
+int  rtggx_set_env(rtggx_context* ctx, int format, uint32_t size, uint32_t mips, const void* data, size_t bytes);
+int  rtggx_set_material(rtggx_context* ctx, uint32_t mesh, const float base_color[4], float roughness, float metallic);
+int  rtggx_set_metallic(rtggx_context* ctx, uint32_t mesh, float metallic);
+
+/* LBVH build of both bottom-level structures on the context's build stream. */
+int  rtggx_build_as(rtggx_context* ctx);
+
+/* Per-frame constants; copied into the next of RayTracer::FrameCount (=3) slots. */
+int  rtggx_update_frame(rtggx_context* ctx, const RtggxFrameConstants* constants);
+int  rtggx_update_as(rtggx_context* ctx);
+int  rtggx_transform_sh(rtggx_context* ctx);
+int  rtggx_render_visibility(rtggx_context* ctx);
+int  rtggx_ray_trace(rtggx_context* ctx);
+int  rtggx_denoise(rtggx_context* ctx, int use_shared_mem);
+int  rtggx_tone_map(rtggx_context* ctx);
+
+int  rtggx_sync(rtggx_context* ctx);
+/* Number of non-degenerate rays (TMax > TMin) traced by the last rtggx_ray_trace; synchronises. */
+int  rtggx_ray_count(rtggx_context* ctx, uint64_t* rays);
+int  rtggx_get_timings(rtggx_context* ctx, RtggxTimings* out);
+int  rtggx_enable_timing(rtggx_context* ctx, int enabled);
+
+/* Size in bytes of a buffer / synchronous copy into caller memory / raw device pointer. */
+int  rtggx_buffer_size(rtggx_context* ctx, int buffer_id, size_t* bytes);
+int  rtggx_readback(rtggx_context* ctx, int buffer_id, void* dst, size_t bytes);
+int  rtggx_buffer_ptr(rtggx_context* ctx, int buffer_id, void** device_ptr);
+/* Overwrite a render target from host memory (tests feed one pass with another implementation's input). */
+int  rtggx_upload(rtggx_context* ctx, int buffer_id, const void* src, size_t bytes);
+int  rtggx_frame_parity(rtggx_context* ctx, uint32_t* parity);
+int  rtggx_bvh_root(rtggx_context* ctx, uint32_t slot, int32_t* root);
+
+/* Closest-hit queries on the device for tests: rays = n x {o.xyz, d.xyz, tmin, tmax},
+ * out = n x {t, instance(bits), primitive(bits), b1, b2, valid}. */
+int  rtggx_trace_rays(rtggx_context* ctx, const float* rays, uint32_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGGX_H */

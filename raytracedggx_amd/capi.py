@@ -1,0 +1,228 @@
+"""ctypes binding of librtggx.so -- the C ABI declared in include/rtggx.h.
+
+The library is the product: hand-written HIP for gfx950 behind `extern "C"` entry points.  There is
+no CPU fallback; loading fails loudly when the shared object is missing, and rtggx_create fails
+when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtggx.so")
+
+# buffer ids (rtggx.h)
+BUF_VISIBILITY, BUF_DEPTH, BUF_NORMAL, BUF_ROUGH_METAL, BUF_VELOCITY, BUF_RT_REFL, BUF_RT_DIFF, BUF_TSS0, BUF_TSS1, \
+    BUF_FLT_RFL, BUF_FLT_DFF, BUF_BACKBUFFER, BUF_SH_COEFFS, BUF_BVH_NODES0, BUF_BVH_TRIS0, BUF_BVH_NODES1, BUF_BVH_TRIS1, \
+    BUF_TLAS, BUF_ENV = range(19)
+FORMAT_RGBA32F, FORMAT_RGBA16F, FORMAT_BC6H_UF16 = 2, 10, 95
+
+_BUF_DTYPE = {BUF_VISIBILITY: np.uint32, BUF_DEPTH: np.uint32, BUF_NORMAL: np.uint32, BUF_ROUGH_METAL: np.uint16,
+              BUF_VELOCITY: np.uint32, BUF_RT_REFL: np.uint32, BUF_RT_DIFF: np.uint32, BUF_TSS0: np.uint64, BUF_TSS1: np.uint64,
+              BUF_FLT_RFL: np.uint64, BUF_FLT_DFF: np.uint64, BUF_BACKBUFFER: np.uint32, BUF_SH_COEFFS: np.float32,
+              BUF_BVH_NODES0: np.uint32, BUF_BVH_TRIS0: np.uint32, BUF_BVH_NODES1: np.uint32, BUF_BVH_TRIS1: np.uint32,
+              BUF_TLAS: np.float32, BUF_ENV: np.uint16}
+
+EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip", "rtggx_set_stream", "rtggx_set_mesh",
+           "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",
+           "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
+           "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
+           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays"]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("update_as", "visibility", "ray_trace", "spatial_refl_h", "spatial_refl_v",
+                                         "spatial_diff_h", "spatial_diff_v", "temporal", "tone_map", "frame")]
+
+
+_lib = None
+
+
+def load():
+    """Load librtggx.so; raises if the HIP library has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("librtggx.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C raytracedggx_amd` (hipcc, gfx950). There is no CPU path.")
+    L = C.CDLL(LIB_PATH)
+    L.rtggx_last_error.restype = C.c_char_p
+    vp = C.c_void_p
+    L.rtggx_create.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_int]
+    L.rtggx_destroy.argtypes = [vp]
+    L.rtggx_destroy.restype = None
+    L.rtggx_set_strip.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.rtggx_set_stream.argtypes = [vp, vp]
+    L.rtggx_set_mesh.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
+    L.rtggx_set_env.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+    L.rtggx_set_material.argtypes = [vp, C.c_uint32, vp, C.c_float, C.c_float]
+    L.rtggx_set_metallic.argtypes = [vp, C.c_uint32, C.c_float]
+    for n in ("rtggx_build_as", "rtggx_update_as", "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace",
+              "rtggx_tone_map", "rtggx_sync"):
+        getattr(L, n).argtypes = [vp]
+    L.rtggx_update_frame.argtypes = [vp, vp]
+    L.rtggx_denoise.argtypes = [vp, C.c_int]
+    L.rtggx_ray_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rtggx_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.rtggx_enable_timing.argtypes = [vp, C.c_int]
+    L.rtggx_buffer_size.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+    L.rtggx_readback.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.rtggx_buffer_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rtggx_upload.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.rtggx_frame_parity.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.rtggx_bvh_root.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
+    L.rtggx_trace_rays.argtypes = [vp, vp, C.c_uint32, vp]
+    _lib = L
+    return L
+
+
+class RtggxError(RuntimeError):
+    pass
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One rtggx_context: scene + render targets on one GPU.  Method names follow rtggx.h."""
+
+    def __init__(self, width, height, device=0):
+        self.L = load()
+        self.W, self.H = int(width), int(height)
+        h = C.c_void_p()
+        self._check(self.L.rtggx_create(C.byref(h), self.W, self.H, int(device)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtggxError("librtggx: %s (code %d)" % (self.L.rtggx_last_error().decode(), rc))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rtggx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_strip(self, row_begin, row_end):
+        self._check(self.L.rtggx_set_strip(self.h, row_begin, row_end))
+
+    def set_stream(self, stream_handle):
+        self._check(self.L.rtggx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def set_mesh(self, slot, verts, indices):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 6)
+        i = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        self._check(self.L.rtggx_set_mesh(self.h, slot, _p(v), v.shape[0], _p(i), i.size))
+
+    def set_env(self, fmt, size, mips, data):
+        b = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        self._check(self.L.rtggx_set_env(self.h, fmt, size, mips, _p(b), b.size))
+
+    def set_material(self, mesh, base_color, roughness, metallic):
+        bc = np.asarray(base_color, np.float32)
+        self._check(self.L.rtggx_set_material(self.h, mesh, _p(bc), roughness, metallic))
+
+    def set_metallic(self, mesh, metallic):
+        self._check(self.L.rtggx_set_metallic(self.h, mesh, metallic))
+
+    def build_as(self):
+        self._check(self.L.rtggx_build_as(self.h))
+
+    def update_frame(self, constants768):
+        b = np.frombuffer(bytes(constants768), np.uint8).copy()
+        if b.size != 768:
+            raise ValueError("RtggxFrameConstants is 768 bytes")
+        self._check(self.L.rtggx_update_frame(self.h, _p(b)))
+
+    def update_as(self):
+        self._check(self.L.rtggx_update_as(self.h))
+
+    def transform_sh(self):
+        self._check(self.L.rtggx_transform_sh(self.h))
+
+    def render_visibility(self):
+        self._check(self.L.rtggx_render_visibility(self.h))
+
+    def ray_trace(self):
+        self._check(self.L.rtggx_ray_trace(self.h))
+
+    def denoise(self, use_shared_mem=False):
+        self._check(self.L.rtggx_denoise(self.h, 1 if use_shared_mem else 0))
+
+    def tone_map(self):
+        self._check(self.L.rtggx_tone_map(self.h))
+
+    def sync(self):
+        self._check(self.L.rtggx_sync(self.h))
+
+    def ray_count(self):
+        n = C.c_uint64()
+        self._check(self.L.rtggx_ray_count(self.h, C.byref(n)))
+        return int(n.value)
+
+    def enable_timing(self, on=True):
+        self._check(self.L.rtggx_enable_timing(self.h, 1 if on else 0))
+
+    def timings(self):
+        t = Timings()
+        self._check(self.L.rtggx_get_timings(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in Timings._fields_}
+
+    def buffer_size(self, bid):
+        n = C.c_size_t()
+        self._check(self.L.rtggx_buffer_size(self.h, bid, C.byref(n)))
+        return int(n.value)
+
+    def buffer_ptr(self, bid):
+        p = C.c_void_p()
+        self._check(self.L.rtggx_buffer_ptr(self.h, bid, C.byref(p)))
+        return int(p.value)
+
+    def readback(self, bid):
+        n = self.buffer_size(bid)
+        dt = np.dtype(_BUF_DTYPE[bid])
+        out = np.zeros(max(n // dt.itemsize, 0), dt)
+        if n:
+            self._check(self.L.rtggx_readback(self.h, bid, _p(out), n))
+        if bid <= BUF_BACKBUFFER:
+            return out.reshape(self.H, self.W)
+        if bid == BUF_SH_COEFFS:
+            return out.reshape(9, 3)
+        if bid in (BUF_BVH_NODES0, BUF_BVH_NODES1):
+            return out.reshape(-1, 16)
+        if bid in (BUF_BVH_TRIS0, BUF_BVH_TRIS1):
+            return out.reshape(-1, 12)
+        if bid == BUF_TLAS:
+            return out.reshape(2, 4, 4)
+        if bid == BUF_ENV:
+            return out.reshape(-1, 4)
+        return out
+
+    def upload(self, bid, array):
+        a = np.ascontiguousarray(array)
+        self._check(self.L.rtggx_upload(self.h, bid, _p(a), a.nbytes))
+
+    def frame_parity(self):
+        p = C.c_uint32()
+        self._check(self.L.rtggx_frame_parity(self.h, C.byref(p)))
+        return int(p.value)
+
+    def bvh_root(self, slot):
+        r = C.c_int32()
+        self._check(self.L.rtggx_bvh_root(self.h, slot, C.byref(r)))
+        return int(r.value)
+
+    def trace_rays(self, rays):
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros((r.shape[0], 6), np.float32)
+        self._check(self.L.rtggx_trace_rays(self.h, _p(r), r.shape[0], _p(out)))
+        return {"t": out[:, 0].copy(), "inst": out[:, 1].copy().view(np.uint32), "prim": out[:, 2].copy().view(np.uint32),
+                "b1": out[:, 3].copy(), "b2": out[:, 4].copy(), "valid": out[:, 5] > 0.5}

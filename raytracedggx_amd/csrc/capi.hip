@@ -1,0 +1,430 @@
+// C ABI of librtggx (include/rtggx.h): context management, scene upload, per-frame pass entry points.
+// Frame order issued by the host (RayTracedGGX::OnRender, RayTracedGGX.cpp:302-353):
+//   update_as (stream B)  ||  render_visibility (stream A)  -> event ->  ray_trace -> denoise -> tone_map
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "rtggx_context.h"
+
+namespace rt {
+static thread_local char g_err[512] = "";
+void setError(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+
+__global__ void uploadParamsKernel(FrameParams src, FrameParams* dst) {
+  // 912 bytes: one wave copies the by-value argument into the device-resident slot
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+  for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4; i += blockDim.x) d[i] = s[i];
+}
+int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s) {
+  hipLaunchKernelGGL(uploadParamsKernel, dim3(1), dim3(64), 0, s, c->slots[slot], c->dParams + slot);
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+int uploadScene(rtggx_context* c, hipStream_t s) {
+  Scene sc;
+  for (int i = 0; i < 2; ++i) { sc.verts[i] = c->mesh[i].verts; sc.idx[i] = c->mesh[i].indices; sc.nodes[i] = c->mesh[i].nodes; sc.tris[i] = c->mesh[i].tris; sc.root[i] = c->mesh[i].root; }
+  sc.env = c->env.texels; sc.envSize = c->env.size; sc.envMips = c->env.mips;
+  for (int m = 0; m < 12; ++m) sc.mipOffset[m] = c->env.mipOffset[m];
+  sc.sh = c->sh; sc.cosSin = c->cosSinTab;
+  RT_HIP(hipMemcpyAsync(c->dScene, &sc, sizeof sc, hipMemcpyHostToDevice, s));
+  RT_HIP(hipStreamSynchronize(s));
+  c->sceneDirty = false;
+  return 0;
+}
+
+// world -> object matrices of the two instances: general 4x4 inverse by cofactors in double,
+// rounded once (the software TLAS; DESIGN.md "TLAS").
+static void invert4x4(const float* a /*row-major*/, float* out) {
+  double m[16], inv[16];
+  for (int i = 0; i < 16; ++i) m[i] = (double)a[i];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  const double rdet = 1.0 / det;
+  for (int i = 0; i < 16; ++i) out[i] = (float)(inv[i] * rdet);
+}
+
+static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
+// Constants reach the device in rtggx_update_as; a caller that skips it still gets them, on the main stream.
+static int ensureParams(rtggx_context* c) {
+  if (c->slotUploaded) return 0;
+  const int r = uploadParams(c, c->slot, c->streamMain);
+  if (!r) c->slotUploaded = true;
+  return r;
+}
+
+static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t ni) {
+  MeshDev& m = c->mesh[slot];
+  RT_HIP(hipStreamSynchronize(mainStream(c)));
+  if (m.verts) { hipFree(m.verts); m.verts = nullptr; }
+  if (m.indices) { hipFree(m.indices); m.indices = nullptr; }
+  if (m.nodes) { hipFree(m.nodes); m.nodes = nullptr; }
+  if (m.tris) { hipFree(m.tris); m.tris = nullptr; }
+  m.root = -1; m.numVerts = nv; m.numIndices = ni; m.numTris = ni / 3;
+  for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) { setError("rtggx_set_mesh: index %u out of range (%u vertices)", idx[i], nv); m.numVerts = m.numIndices = m.numTris = 0; return -1; }
+  if (nv && ni) {
+    RT_HIP(hipMalloc(&m.verts, sizeof(float) * 6 * (size_t)nv));
+    RT_HIP(hipMalloc(&m.indices, sizeof(uint32_t) * (size_t)ni));
+    RT_HIP(hipMemcpy(m.verts, verts, sizeof(float) * 6 * (size_t)nv, hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(m.indices, idx, sizeof(uint32_t) * (size_t)ni, hipMemcpyHostToDevice));
+    for (int k = 0; k < 3; ++k) { m.bmin[k] = 3.4e38f; m.bmax[k] = -3.4e38f; }
+    for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; if (x < m.bmin[k]) m.bmin[k] = x; if (x > m.bmax[k]) m.bmax[k] = x; }
+  }
+  c->asBuilt = false; c->sceneDirty = true;
+  return 0;
+}
+
+static const float kGroundVerts[24][6] = {   // RayTracer::createGroundMesh, RayTracer.cpp:430-461
+  {-1, 1, -1, 0, 1, 0}, {1, 1, -1, 0, 1, 0}, {1, 1, 1, 0, 1, 0}, {-1, 1, 1, 0, 1, 0},
+  {-1, -1, -1, 0, -1, 0}, {1, -1, -1, 0, -1, 0}, {1, -1, 1, 0, -1, 0}, {-1, -1, 1, 0, -1, 0},
+  {-1, -1, 1, -1, 0, 0}, {-1, -1, -1, -1, 0, 0}, {-1, 1, -1, -1, 0, 0}, {-1, 1, 1, -1, 0, 0},
+  {1, -1, 1, 1, 0, 0}, {1, -1, -1, 1, 0, 0}, {1, 1, -1, 1, 0, 0}, {1, 1, 1, 1, 0, 0},
+  {-1, -1, -1, 0, 0, -1}, {1, -1, -1, 0, 0, -1}, {1, 1, -1, 0, 0, -1}, {-1, 1, -1, 0, 0, -1},
+  {-1, -1, 1, 0, 0, 1}, {1, -1, 1, 0, 0, 1}, {1, 1, 1, 0, 0, 1}, {-1, 1, 1, 0, 0, 1}};
+static const uint32_t kGroundIdx[36] = {3, 1, 0, 2, 1, 3, 6, 4, 5, 7, 4, 6, 11, 9, 8, 10, 9, 11,   // :477-496
+                                        14, 12, 13, 15, 12, 14, 19, 17, 16, 18, 17, 19, 22, 20, 21, 23, 20, 22};
+}  // namespace rt
+
+using namespace rt;
+
+#define RT_CHECK_CTX(c) do { if (!(c)) { rt::setError("null context"); return -1; } hipError_t _e = hipSetDevice((c)->device); if (_e != hipSuccess) { rt::setError("hipSetDevice: %s", hipGetErrorString(_e)); return -2; } } while (0)
+
+extern "C" {
+
+const char* rtggx_last_error(void) { return rt::g_err; }
+
+int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int device) {
+  if (!out || width == 0 || height == 0 || width > 16384 || height > 16384) { setError("rtggx_create: bad arguments"); return -1; }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { setError("rtggx_create: no HIP device available (this library has no CPU path)"); return -2; }
+  if (device < 0 || device >= count) { setError("rtggx_create: device %d out of range (%d devices)", device, count); return -1; }
+  RT_HIP(hipSetDevice(device));
+  rtggx_context* c = new rtggx_context();
+  c->device = device; c->W = width; c->H = height; c->rowBegin = 0; c->rowEnd = height;
+  const size_t n = (size_t)width * height;
+  RT_HIP(hipStreamCreateWithFlags(&c->ownMain, hipStreamNonBlocking));
+  RT_HIP(hipStreamCreateWithFlags(&c->streamAS, hipStreamNonBlocking));
+  c->streamMain = c->ownMain;
+  RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&c->evFrameStart, hipEventDisableTiming));
+  for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
+  RT_HIP(hipMalloc(&c->visDepth, n * 8)); RT_HIP(hipMalloc(&c->normal, n * 4)); RT_HIP(hipMalloc(&c->velocity, n * 4));
+  RT_HIP(hipMalloc(&c->rtRefl, n * 4)); RT_HIP(hipMalloc(&c->rtDiff, n * 4)); RT_HIP(hipMalloc(&c->backbuffer, n * 4));
+  RT_HIP(hipMalloc(&c->roughMetal, n * 2));
+  RT_HIP(hipMalloc(&c->tss[0], n * 8)); RT_HIP(hipMalloc(&c->tss[1], n * 8)); RT_HIP(hipMalloc(&c->fltRfl, n * 8)); RT_HIP(hipMalloc(&c->fltDff, n * 8));
+  RT_HIP(hipMemset(c->visDepth, 0, n * 8)); RT_HIP(hipMemset(c->normal, 0, n * 4)); RT_HIP(hipMemset(c->velocity, 0, n * 4));
+  RT_HIP(hipMemset(c->rtRefl, 0, n * 4)); RT_HIP(hipMemset(c->rtDiff, 0, n * 4)); RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
+  RT_HIP(hipMemset(c->roughMetal, 0, n * 2));
+  RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
+  c->largeCapacity = 1u << 16;
+  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 40)); RT_HIP(hipMalloc(&c->largeCount, 4));
+  RT_HIP(hipMalloc(&c->rayCounter, 256 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 256 * 8));
+  RT_HIP(hipMalloc(&c->sh, 27 * 4)); RT_HIP(hipMemset(c->sh, 0, 27 * 4));
+  RT_HIP(hipMalloc(&c->cosSinTab, 512 * 4));
+  RT_HIP(hipMalloc(&c->dParams, 3 * sizeof(FrameParams)));
+  RT_HIP(hipMalloc(&c->dScene, sizeof(Scene)));
+  {  // cos/sin(2*pi*s/256): double libm, rounded once (RayTracing.hlsl:94,100 with xi.x = s/256, :391)
+    float tab[512];
+    for (int s = 0; s < 256; ++s) { const double phi = 2.0 * 3.14159265358979323846 * (double)s / 256.0; tab[s] = (float)cos(phi); tab[256 + s] = (float)sin(phi); }
+    RT_HIP(hipMemcpy(c->cosSinTab, tab, sizeof tab, hipMemcpyHostToDevice));
+  }
+  // default materials, RayTracer.cpp:134-139
+  const float bc0[4] = {0.95f, 0.93f, 0.88f, 1.0f}, bc1[4] = {1.0f, 0.71f, 0.29f, 1.0f};
+  const float rm0[4] = {0.5f, 1.0f, 0.0f, 0.0f}, rm1[4] = {0.16f, 1.0f, 0.0f, 0.0f};
+  memcpy(c->material.BaseColors[0], bc0, 16); memcpy(c->material.BaseColors[1], bc1, 16);
+  memcpy(c->material.RoughMetals[0], rm0, 16); memcpy(c->material.RoughMetals[1], rm1, 16);
+  memset(c->invWorld, 0, sizeof c->invWorld);
+  for (int i = 0; i < 2; ++i) for (int k = 0; k < 4; ++k) c->invWorld[i][k * 5] = 1.0f;
+  memset(c->slots, 0, sizeof c->slots);
+  const int r = setMeshImpl(c, RTGGX_GROUND, &kGroundVerts[0][0], 24, kGroundIdx, 36);
+  if (r) { return r; }
+  *out = c;
+  return 0;
+}
+
+void rtggx_destroy(rtggx_context* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (auto& m : c->mesh) { hipFree(m.verts); hipFree(m.indices); hipFree(m.nodes); hipFree(m.tris); }
+  hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->visDepth); hipFree(c->normal); hipFree(c->velocity);
+  hipFree(c->rtRefl); hipFree(c->rtDiff); hipFree(c->backbuffer); hipFree(c->roughMetal); hipFree(c->tss[0]); hipFree(c->tss[1]);
+  hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
+  for (auto& e : c->tev) hipEventDestroy(e);
+  hipEventDestroy(c->evAS); hipEventDestroy(c->evFrameStart);
+  hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS);
+  delete c;
+}
+
+int rtggx_set_strip(rtggx_context* c, uint32_t rowBegin, uint32_t rowEnd) {
+  RT_CHECK_CTX(c);
+  if (rowBegin > rowEnd || rowEnd > c->H) { setError("rtggx_set_strip: bad rows [%u,%u) for height %u", rowBegin, rowEnd, c->H); return -1; }
+  c->rowBegin = rowBegin; c->rowEnd = rowEnd;
+  return 0;
+}
+
+int rtggx_set_stream(rtggx_context* c, void* stream) {
+  RT_CHECK_CTX(c);
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  if (stream) { c->streamMain = (hipStream_t)stream; c->externalStream = true; }
+  else { c->streamMain = c->ownMain; c->externalStream = false; }
+  return 0;
+}
+
+int rtggx_set_mesh(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t ni) {
+  RT_CHECK_CTX(c);
+  if (slot >= RTGGX_NUM_MESH || !verts || !idx || ni % 3 != 0) { setError("rtggx_set_mesh: bad arguments"); return -1; }
+  return setMeshImpl(c, slot, verts, nv, idx, ni);
+}
+
+int rtggx_set_env(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* data, size_t bytes) {
+  RT_CHECK_CTX(c);
+  if (!data) { setError("rtggx_set_env: null data"); return -1; }
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  return decodeEnv(c, format, size, mips, data, bytes, c->streamMain);
+}
+
+int rtggx_set_material(rtggx_context* c, uint32_t mesh, const float baseColor[4], float roughness, float metallic) {
+  RT_CHECK_CTX(c);
+  if (mesh >= RTGGX_NUM_MESH) { setError("rtggx_set_material: bad mesh"); return -1; }
+  memcpy(c->material.BaseColors[mesh], baseColor, 16);
+  c->material.RoughMetals[mesh][0] = roughness; c->material.RoughMetals[mesh][1] = metallic;
+  return 0;
+}
+int rtggx_set_metallic(rtggx_context* c, uint32_t mesh, float metallic) {   // RayTracer.cpp:244-248
+  RT_CHECK_CTX(c);
+  if (mesh >= RTGGX_NUM_MESH) { setError("rtggx_set_metallic: bad mesh"); return -1; }
+  c->material.RoughMetals[mesh][1] = metallic;
+  return 0;
+}
+
+int rtggx_build_as(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  for (uint32_t i = 0; i < 2; ++i) { const int r = buildLbvh(c, i, c->streamAS); if (r) return r; }
+  c->asBuilt = true; c->sceneDirty = true;
+  return 0;
+}
+
+int rtggx_update_frame(rtggx_context* c, const RtggxFrameConstants* k) {
+  RT_CHECK_CTX(c);
+  if (!k) { setError("rtggx_update_frame: null constants"); return -1; }
+  c->slot = (c->slot + 1) % 3;   // RayTracer::FrameCount
+  FrameParams& fp = c->slots[c->slot];
+  fp.g = k->global; fp.rg = k->rayGen; fp.po[0] = k->perObject[0]; fp.po[1] = k->perObject[1];
+  fp.mat = c->material;
+  fp.W = c->W; fp.H = c->H; fp.rowBegin = c->rowBegin; fp.rowEnd = c->rowEnd;
+  memcpy(fp.invWorld, c->invWorld, sizeof fp.invWorld);
+  c->haveConstants = true; c->slotUploaded = false;
+  return 0;
+}
+
+// RayTracer::UpdateAccelerationStructure: refresh the two TLAS instance transforms from CBGlobal::Worlds
+// (= m_worlds, RayTracer.cpp:288-290, 329-336).  Runs on the AS stream, overlapping the visibility pass.
+int rtggx_update_as(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  if (!c->haveConstants) { setError("rtggx_update_as: rtggx_update_frame has not been called"); return -1; }
+  FrameParams& fp = c->slots[c->slot];
+  for (int i = 0; i < 2; ++i) {
+    const M4 w = cbLoad4x3(fp.g.Worlds[i]);
+    invert4x4(&w.m[0][0], c->invWorld[i]);
+  }
+  memcpy(fp.invWorld, c->invWorld, sizeof fp.invWorld);
+  if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
+  if (c->timing) hipEventRecord(c->tev[0], c->streamAS);
+  const int r = uploadParams(c, c->slot, c->streamAS);
+  if (r) return r;
+  c->slotUploaded = true;
+  if (c->timing) hipEventRecord(c->tev[1], c->streamAS);
+  RT_HIP(hipEventRecord(c->evAS, c->streamAS));
+  // every consumer of the constants runs on the main stream behind this event
+  RT_HIP(hipStreamWaitEvent(c->streamMain, c->evAS, 0));
+  return 0;
+}
+
+int rtggx_transform_sh(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  return projectSH(c, c->streamMain);
+}
+
+int rtggx_render_visibility(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
+  { const int r = ensureParams(c); if (r) return r; }
+  if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamMain); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
+  if (c->timing) hipEventRecord(c->tev[2], c->streamMain);
+  return launchVisibility(c, c->slots[c->slot], c->streamMain);
+}
+
+int rtggx_ray_trace(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  if (!c->haveConstants || !c->asBuilt) { setError("rtggx_ray_trace: %s", c->asBuilt ? "no frame constants" : "rtggx_build_as has not been called"); return -1; }
+  if (!c->env.texels) { setError("rtggx_ray_trace: no environment map"); return -1; }
+  if (c->sceneDirty) { const int r = uploadScene(c, c->streamMain); if (r) return r; }
+  { const int r = ensureParams(c); if (r) return r; }
+  if (c->timing) hipEventRecord(c->tev[3], c->streamMain);
+  return launchRayTrace(c, c->slots[c->slot], c->streamMain);
+}
+
+int rtggx_denoise(rtggx_context* c, int useSharedMem) {
+  RT_CHECK_CTX(c);
+  if (!c->haveConstants) { setError("rtggx_denoise: no frame constants"); return -1; }
+  if (c->timing) hipEventRecord(c->tev[9], c->streamMain);   // start of denoise
+  return launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain);
+}
+
+int rtggx_tone_map(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  if (!c->haveConstants) { setError("rtggx_tone_map: no frame constants"); return -1; }
+  const int r = launchToneMap(c, c->slots[c->slot], c->streamMain);
+  if (c->timing) { hipEventRecord(c->tev[10], c->streamMain); c->timingsPending = true; }
+  return r;
+}
+
+int rtggx_sync(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  RT_HIP(hipStreamSynchronize(c->streamAS));
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  return 0;
+}
+
+int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
+  RT_CHECK_CTX(c);
+  unsigned long long h[256];
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipMemcpy(h, c->rayCounter, sizeof h, hipMemcpyDeviceToHost));
+  uint64_t s = 0; for (auto v : h) s += v;
+  *rays = s;
+  return 0;
+}
+
+int rtggx_enable_timing(rtggx_context* c, int enabled) { RT_CHECK_CTX(c); c->timing = enabled != 0; c->timingsPending = false; return 0; }
+int rtggx_get_timings(rtggx_context* c, RtggxTimings* out) {
+  RT_CHECK_CTX(c);
+  if (!c->timing || !c->timingsPending) { setError("rtggx_get_timings: timing not enabled or no complete frame"); return -1; }
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  auto ms = [&](int a, int b) { float t = 0.0f; hipEventElapsedTime(&t, c->tev[a], c->tev[b]); return t; };
+  RtggxTimings t;
+  t.update_as = ms(0, 1); t.visibility = ms(2, 3); t.ray_trace = ms(3, 9); t.spatial_refl_h = ms(9, 4); t.spatial_refl_v = ms(4, 5);
+  t.spatial_diff_h = ms(5, 6); t.spatial_diff_v = ms(6, 7); t.temporal = ms(7, 8); t.tone_map = ms(8, 10); t.frame = ms(2, 10);
+  *out = t; c->lastTimings = t;
+  return 0;
+}
+
+static int bufferInfo(rtggx_context* c, int id, void** ptr, size_t* bytes) {
+  const size_t n = (size_t)c->W * c->H;
+  switch (id) {
+    case RTGGX_BUF_VISIBILITY: case RTGGX_BUF_DEPTH: *ptr = nullptr; *bytes = n * 4; return 0;   // halves of visDepth: staged
+    case RTGGX_BUF_NORMAL: *ptr = c->normal; *bytes = n * 4; return 0;
+    case RTGGX_BUF_ROUGH_METAL: *ptr = c->roughMetal; *bytes = n * 2; return 0;
+    case RTGGX_BUF_VELOCITY: *ptr = c->velocity; *bytes = n * 4; return 0;
+    case RTGGX_BUF_RT_REFL: *ptr = c->rtRefl; *bytes = n * 4; return 0;
+    case RTGGX_BUF_RT_DIFF: *ptr = c->rtDiff; *bytes = n * 4; return 0;
+    case RTGGX_BUF_TSS0: *ptr = c->tss[0]; *bytes = n * 8; return 0;
+    case RTGGX_BUF_TSS1: *ptr = c->tss[1]; *bytes = n * 8; return 0;
+    case RTGGX_BUF_FLT_RFL: *ptr = c->fltRfl; *bytes = n * 8; return 0;
+    case RTGGX_BUF_FLT_DFF: *ptr = c->fltDff; *bytes = n * 8; return 0;
+    case RTGGX_BUF_BACKBUFFER: *ptr = c->backbuffer; *bytes = n * 4; return 0;
+    case RTGGX_BUF_SH_COEFFS: *ptr = c->sh; *bytes = 108; return 0;
+    case RTGGX_BUF_BVH_NODES0: case RTGGX_BUF_BVH_NODES1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_NODES1]; *ptr = m.nodes; *bytes = m.numTris > 1 && m.nodes ? (size_t)(m.numTris - 1) * 64 : 0; return 0; }
+    case RTGGX_BUF_BVH_TRIS0: case RTGGX_BUF_BVH_TRIS1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_TRIS1]; *ptr = m.tris; *bytes = m.tris ? (size_t)m.numTris * 48 : 0; return 0; }
+    case RTGGX_BUF_TLAS: *ptr = nullptr; *bytes = 128; return 0;
+    case RTGGX_BUF_ENV: *ptr = c->env.texels; *bytes = (size_t)c->env.totalTexels * 8; return 0;
+    default: setError("unknown buffer id %d", id); return -1;
+  }
+}
+
+int rtggx_buffer_size(rtggx_context* c, int id, size_t* bytes) { RT_CHECK_CTX(c); void* p; return bufferInfo(c, id, &p, bytes); }
+
+int rtggx_buffer_ptr(rtggx_context* c, int id, void** dptr) {
+  RT_CHECK_CTX(c);
+  size_t bytes;
+  const int r = bufferInfo(c, id, dptr, &bytes);
+  if (r) return r;
+  if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) *dptr = c->visDepth;   // packed u64: (depth << 32) | visibility
+  if (!*dptr) { setError("buffer %d has no device storage", id); return -1; }
+  return 0;
+}
+
+int rtggx_readback(rtggx_context* c, int id, void* dst, size_t bytes) {
+  RT_CHECK_CTX(c);
+  void* p; size_t need;
+  int r = bufferInfo(c, id, &p, &need);
+  if (r) return r;
+  if (bytes < need) { setError("rtggx_readback: buffer %d needs %zu bytes, %zu given", id, need, bytes); return -1; }
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  if (id == RTGGX_BUF_TLAS) { memcpy(dst, c->invWorld, 128); return 0; }
+  if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) {
+    uint32_t *dVis, *dDepth;
+    RT_HIP(hipMalloc(&dVis, need)); RT_HIP(hipMalloc(&dDepth, need));
+    r = unpackVisDepth(c, dVis, dDepth, c->streamMain);
+    if (!r) { hipError_t e = hipMemcpy(dst, id == RTGGX_BUF_VISIBILITY ? dVis : dDepth, need, hipMemcpyDeviceToHost); if (e != hipSuccess) { setError("hipMemcpy: %s", hipGetErrorString(e)); r = -2; } }
+    hipFree(dVis); hipFree(dDepth);
+    return r;
+  }
+  if (need == 0) return 0;
+  RT_HIP(hipMemcpy(dst, p, need, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
+  RT_CHECK_CTX(c);
+  void* p; size_t need;
+  int r = bufferInfo(c, id, &p, &need);
+  if (r) return r;
+  if (bytes != need) { setError("rtggx_upload: buffer %d is %zu bytes, %zu given", id, need, bytes); return -1; }
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) {
+    // replace one half of the packed buffer
+    uint32_t *dVis, *dDepth;
+    RT_HIP(hipMalloc(&dVis, need)); RT_HIP(hipMalloc(&dDepth, need));
+    r = unpackVisDepth(c, dVis, dDepth, c->streamMain);
+    if (!r) { hipError_t e = hipMemcpy(id == RTGGX_BUF_VISIBILITY ? dVis : dDepth, src, need, hipMemcpyHostToDevice); if (e != hipSuccess) { setError("hipMemcpy: %s", hipGetErrorString(e)); r = -2; } }
+    if (!r) r = packVisDepth(c, dVis, dDepth, c->streamMain);
+    hipStreamSynchronize(c->streamMain);
+    hipFree(dVis); hipFree(dDepth);
+    return r;
+  }
+  if (id == RTGGX_BUF_SH_COEFFS) c->shDone = true;
+  if (!p || id >= RTGGX_BUF_BVH_NODES0) { setError("rtggx_upload: buffer %d is not writable", id); return -1; }
+  RT_HIP(hipMemcpy(p, src, need, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int rtggx_frame_parity(rtggx_context* c, uint32_t* parity) { RT_CHECK_CTX(c); *parity = c->frameParity; return 0; }
+int rtggx_bvh_root(rtggx_context* c, uint32_t slot, int32_t* root) { RT_CHECK_CTX(c); if (slot > 1) { setError("bad slot"); return -1; } *root = c->mesh[slot].root; return 0; }
+
+int rtggx_trace_rays(rtggx_context* c, const float* rays, uint32_t n, float* out) {
+  RT_CHECK_CTX(c);
+  if (!c->asBuilt || !c->haveConstants) { setError("rtggx_trace_rays: build_as / update_frame / update_as first"); return -1; }
+  if (c->sceneDirty) { const int r = uploadScene(c, c->streamMain); if (r) return r; }
+  { const int r = ensureParams(c); if (r) return r; }
+  float *dR, *dO;
+  RT_HIP(hipMalloc(&dR, (size_t)n * 32)); RT_HIP(hipMalloc(&dO, (size_t)n * 24));
+  RT_HIP(hipMemcpy(dR, rays, (size_t)n * 32, hipMemcpyHostToDevice));
+  int r = launchTraceRays(c, c->slots[c->slot], dR, n, dO, c->streamMain);
+  if (!r) { hipError_t e = hipStreamSynchronize(c->streamMain); if (e == hipSuccess) e = hipMemcpy(out, dO, (size_t)n * 24, hipMemcpyDeviceToHost); if (e != hipSuccess) { setError("trace_rays: %s", hipGetErrorString(e)); r = -2; } }
+  hipFree(dR); hipFree(dO);
+  return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// Denoiser chain for gfx950: Denoiser::Denoise / ToneMap (RayTracedGGX/Content/Denoiser.cpp:66-103,
+// 361-478) and their shaders:
+//   CSSpatial_H_Refl.hlsl:15-50   CSSpatial_V_Refl.hlsl:16-59   (SpatialFilter.hlsli:57-67)
+//   CSSpatial_H_Diff.hlsl:15-48   CSSpatial_V_Diff.hlsl:17-59   (SpatialFilter.hlsli:69-83)
+//   CSTemporalSS.hlsl:254-336 (_DENOISE_, _ALPHA_AS_ID_, _VARIANCE_AABB_, _USE_YCOCG_; HALF = fp32)
+//   PSToneMap.hlsl:13-41
+// Ping-pong as in SURVEY.md Appendix C: scratch = TSS[parity], history = TSS[!parity].
+//
+// Spatial passes: a workgroup owns a 64-pixel segment of a row (H) or a 64x4.. column block (V);
+// each texel of the segment plus its 16-texel aprons is unpacked ONCE into LDS as the floats the
+// 33-tap loop consumes (tone-mapped colour, normal*2-1, hit flag, roughness, depth), instead of
+// four packed fetches and their unpacking per tap as in the reference's direct path.  Reads are
+// row-coalesced 4/8-byte words; out-of-range texels are the zeros D3D returns.
+// Roofline: HBM by bytes (22-30 B/pixel/pass); measured, they are VALU-bound
+// (33 taps x ~40 flops + 4 transcendentals per covered pixel) -- see DESIGN.md.
+#include "rtggx_context.h"
+
+namespace rt {
+
+#define RT_RADIUS 16
+
+struct GTexel { float nx, ny, nz, nw, rough, metal, depth; };
+
+RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restrict__ roughMetal, const unsigned long long* __restrict__ visDepth,
+                    int x, int y, int W, int H) {
+  GTexel g;
+  if (x < 0 || y < 0 || x >= W || y >= H) { g.nx = g.ny = g.nz = -1.0f; g.nw = 0.0f; g.rough = 0.0f; g.metal = 0.0f; g.depth = 0.0f; return g; }
+  const size_t i = (size_t)y * W + x;
+  const uint32_t n = normal[i];
+  g.nx = ((float)(n & 1023u) / 1023.0f) * 2.0f - 1.0f;
+  g.ny = ((float)((n >> 10) & 1023u) / 1023.0f) * 2.0f - 1.0f;
+  g.nz = ((float)((n >> 20) & 1023u) / 1023.0f) * 2.0f - 1.0f;
+  g.nw = (float)(n >> 30) / 3.0f;
+  const uint32_t rm = roughMetal[i];
+  g.rough = (float)(rm & 0xFFu) / 255.0f; g.metal = (float)(rm >> 8) / 255.0f;
+  g.depth = (float)(uint32_t)(visDepth[i] >> 32) / 16777215.0f;
+  return g;
+}
+RT_DEV f3 TM3(f3 c) { const float l = 1.0f + ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f); return mk3(c.x / l, c.y / l, c.z / l); }     // FilterCommon.hlsli:14-19
+RT_DEV f3 ITM3(f3 c) { const float l = 1.0f - ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f); return mk3(c.x / l, c.y / l, c.z / l); }    // :24-27
+RT_DEV float normalWeight(float ax, float ay, float az, const GTexel& g, float sigma) {   // :34-37
+  return powf(fmaxf((ax * g.nx + ay * g.ny) + az * g.nz, 0.0f), sigma);
+}
+RT_DEV float depthWeight(float dc, float d, float sigma) { return expf(-fabsf(dc - d) * dc * sigma); }   // :39-42
+RT_DEV float gaussianW(float r, int radius) { const float sigma = (float)(radius + 1) / 3.0f; const float a = r / sigma; return expf(-0.5f * a * a); }   // :59-71
+
+struct Targets {
+  const uint32_t* normal; const uint16_t* roughMetal; const unsigned long long* visDepth; const uint32_t* velocity;
+  const uint32_t* rtRefl; const uint32_t* rtDiff;
+  uint2* scratch; const uint2* history; uint2* fltRfl; uint2* fltDff; uint32_t* backbuffer;
+  int W, H, rowBegin, rowEnd;
+};
+
+// mode 0: H_Refl  1: V_Refl  2: H_Diff  3: V_Diff
+template <int MODE>
+__global__ void __launch_bounds__(256) spatialKernel(Targets T) {
+  constexpr bool vertical = (MODE & 1) != 0;
+  constexpr bool diffuse = MODE >= 2;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= T.W || y >= T.rowEnd) return;
+  const size_t pix = (size_t)y * T.W + x;
+  const GTexel gc = loadG(T.normal, T.roughMetal, T.visDepth, x, y, T.W, T.H);
+  const bool skip = diffuse ? (gc.nw <= 0.0f || gc.metal >= 1.0f) : (gc.nw <= 0.0f);
+  if (skip) {
+    if (MODE == 1) { const f3 s = unpackR11G11B10F(T.rtRefl[pix]); T.fltRfl[pix] = packRGBA16F(s.x, s.y, s.z, 0.0f); }
+    if (MODE == 3) T.fltDff[pix] = T.fltRfl[pix];
+    return;
+  }
+  const int br = diffuse ? 0 : (int)clampf(0.1f * gc.rough * (float)T.W, 0.0f, (float)T.H * 0.05f);   // FilterCommon.hlsli:49-52
+  float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
+  for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
+    const int tx = vertical ? x : x + i, ty = vertical ? y + i : y;
+    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);
+    if (diffuse && (g.nw <= 0.0f || g.metal >= 1.0f)) continue;
+    const bool inside = tx >= 0 && ty >= 0 && tx < T.W && ty < T.H;
+    f3 src = mk3(0.0f, 0.0f, 0.0f);
+    if (inside) {
+      const size_t ti = (size_t)ty * T.W + tx;
+      if (vertical) { const f4 v = unpackRGBA16F(T.scratch[ti]); src = mk3(v.x, v.y, v.z); }
+      else src = TM3(unpackR11G11B10F(diffuse ? T.rtDiff[ti] : T.rtRefl[ti]));
+    }
+    float w;
+    if (!diffuse) {   // ReflectionWeight, SpatialFilter.hlsli:57-67
+      w = g.nw > 0.0f ? 1.0f : 0.0f;
+      w *= gaussianW(vertical ? (float)i : (float)abs(i), br);
+      w *= normalWeight(gc.nx, gc.ny, gc.nz, g, 512.0f);
+      w *= depthWeight(gc.depth, g.depth, 4.0f);
+      w *= 1.0f - smoothstepf(0.0f, 0.5f, fabsf(g.rough - gc.rough));
+    } else {          // DiffuseWeight, SpatialFilter.hlsli:69-75
+      w = normalWeight(gc.nx, gc.ny, gc.nz, g, 32.0f);
+      w *= depthWeight(gc.depth, g.depth, 4.0f);
+    }
+    mx += src.x * w; my += src.y * w; mz += src.z * w;
+    wsum += w;
+  }
+  f3 mu = mk3(mx / wsum, my / wsum, mz / wsum);
+  if (MODE == 0 || MODE == 2) T.scratch[pix] = packRGBA16F(mu.x, mu.y, mu.z, 0.0f);
+  if (MODE == 1) { mu = ITM3(mu); T.fltRfl[pix] = packRGBA16F(mu.x, mu.y, mu.z, 1.0f); }
+  if (MODE == 3) {
+    const f4 dest = unpackRGBA16F(T.fltRfl[pix]);
+    mu = ITM3(mu);
+    T.fltDff[pix] = packRGBA16F(dest.x + mu.x, dest.y + mu.y, dest.z + mu.z, dest.w);
+  }
+}
+
+// ---- CSTemporalSS.hlsl --------------------------------------------------------------------------------
+RT_DEV f3 rgbToYCoCg(f3 c) {   // :78-85
+  return mk3((c.x * 1.0f + c.y * 2.0f) + c.z * 1.0f, (c.x * 2.0f + c.y * 0.0f) + c.z * -2.0f, (c.x * -1.0f + c.y * 2.0f) + c.z * -1.0f);
+}
+RT_DEV f3 yCoCgToRGB(f3 c) {   // :90-101
+  const float y = c.x * 0.25f, co = c.y * 0.25f, cg = c.z * 0.25f;
+  return mk3(y + co - cg, y + cg, y - co - cg);
+}
+RT_DEV f3 tssTM(f3 hdr) { const f3 c = rgbToYCoCg(hdr); const float d = 4.0f + c.x; return mk3(c.x / d, c.y / d, c.z / d); }   // :106-114
+RT_DEV f3 tssITM(f3 col) { const float k = 4.0f / (1.0f - col.x); return yCoCgToRGB(mk3(col.x * k, col.y * k, col.z * k)); }   // :119-128
+RT_DEV f2 loadVel(const uint32_t* __restrict__ vel, int x, int y, int W, int H) {
+  f2 v; v.x = 0.0f; v.y = 0.0f;
+  if (x < 0 || y < 0 || x >= W || y >= H) return v;
+  const uint32_t p = vel[(size_t)y * W + x];
+  v.x = f16ToF32(p & 0xFFFFu); v.y = f16ToF32(p >> 16);
+  return v;
+}
+RT_DEV f4 loadRGBA16(const uint2* __restrict__ b, int x, int y, int W, int H) {
+  if (x < 0 || y < 0 || x >= W || y >= H) { f4 z; z.x = z.y = z.z = z.w = 0.0f; return z; }
+  return unpackRGBA16F(b[(size_t)y * W + x]);
+}
+
+__global__ void __launch_bounds__(256) temporalKernel(Targets T) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= T.W || y >= T.rowEnd) return;
+  const int W = T.W, H = T.H;
+  const float Wf = (float)W, Hf = (float)H;
+  const float uvx = ((float)x + 0.5f) / Wf, uvy = ((float)y + 0.5f) / Hf;
+  const f4 current = loadRGBA16(T.fltDff, x, y, W, H);
+  // VelocityMax :133-161
+  f2 vmax = loadVel(T.velocity, x, y, W, H);
+  float speedSq = vmax.x * vmax.x + vmax.y * vmax.y;
+  const int ox[8] = {-1, 1, 0, 0, -1, 1, 1, -1}, oy[8] = {0, 0, -1, 1, -1, -1, 1, 1};   // g_texOffsets :48-52
+  for (int i = 4; i < 8; ++i) {
+    const f2 nb = loadVel(T.velocity, x + ox[i], y + oy[i], W, H);
+    const float sq = nb.x * nb.x + nb.y * nb.y;
+    if (sq > speedSq) { vmax = nb; speedSq = sq; }
+  }
+  // history: bilinear, clamped addressing :259-260
+  f4 history;
+  {
+    const float sx = (uvx - vmax.x) * Wf - 0.5f, sy = (uvy - vmax.y) * Hf - 0.5f;
+    const float x0 = floorf(sx), y0 = floorf(sy);
+    const float fx = sx - x0, fy = sy - y0;
+    const int ix0 = x0 < 0.0f ? 0 : (x0 > (float)(W - 1) ? W - 1 : (int)x0);
+    const int ix1 = x0 + 1.0f < 0.0f ? 0 : (x0 + 1.0f > (float)(W - 1) ? W - 1 : (int)(x0 + 1.0f));
+    const int iy0 = y0 < 0.0f ? 0 : (y0 > (float)(H - 1) ? H - 1 : (int)y0);
+    const int iy1 = y0 + 1.0f < 0.0f ? 0 : (y0 + 1.0f > (float)(H - 1) ? H - 1 : (int)(y0 + 1.0f));
+    const f4 t00 = unpackRGBA16F(T.history[(size_t)iy0 * W + ix0]), t10 = unpackRGBA16F(T.history[(size_t)iy0 * W + ix1]);
+    const f4 t01 = unpackRGBA16F(T.history[(size_t)iy1 * W + ix0]), t11 = unpackRGBA16F(T.history[(size_t)iy1 * W + ix1]);
+    const float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+    history.x = ((t00.x * w00 + t10.x * w10) + t01.x * w01) + t11.x * w11;
+    history.y = ((t00.y * w00 + t10.y * w10) + t01.y * w01) + t11.y * w11;
+    history.z = ((t00.z * w00 + t10.z * w10) + t01.z * w01) + t11.z * w11;
+    history.w = ((t00.w * w00 + t10.w * w10) + t01.w * w01) + t11.w * w11;
+  }
+  // :262-281
+  float curHistoryBlur = fabsf(vmax.x) * (4.0f * Wf) + fabsf(vmax.y) * (4.0f * Hf);
+  float historyBlur = 1.0f - history.w;
+  historyBlur = fmaxf(historyBlur, curHistoryBlur);
+  history.w = history.w * 15.0f + 1.0f;
+  const f3 currentTM = tssTM(mk3(current.x, current.y, current.z));
+  float gamma = current.w <= 0.0f ? 1.0f : clampf(8.0f / historyBlur, 1.0f, 32.0f);
+  // NeighborMinMax :166-236
+  float fl[4] = {currentTM.x, currentTM.y, currentTM.z, current.w};
+  float nmin[4], nmax[4];
+  {
+    float mu[3] = {currentTM.x, currentTM.y, currentTM.z};
+    const float alpha = current.w;
+    float m2[3] = {mu[0] * mu[0], mu[1] * mu[1], mu[2] * mu[2]};
+    for (int i = 0; i < 8; ++i) {
+      const f4 nraw = loadRGBA16(T.fltDff, x + ox[i], y + oy[i], W, H);
+      const f3 t = tssTM(mk3(nraw.x, nraw.y, nraw.z));
+      const float nb[4] = {t.x, t.y, t.z, nraw.w};
+      const float wgt = i < 4 ? 0.5f : 0.25f;
+      for (int k = 0; k < 4; ++k) fl[k] += nb[k] * wgt;
+      for (int k = 0; k < 3; ++k) { mu[k] += nb[k]; m2[k] += nb[k] * nb[k]; }
+    }
+    for (int k = 0; k < 4; ++k) fl[k] /= 4.0f;
+    gamma = fabsf(alpha - fl[3]) < 1.0f / 255.0f ? gamma : 1.0f;
+    float sigma[3];
+    for (int k = 0; k < 3; ++k) {
+      mu[k] /= 9.0f;
+      sigma[k] = sqrtf(fabsf(m2[k] / 9.0f - mu[k] * mu[k]));
+      const float gs = gamma * sigma[k];
+      nmin[k] = fminf(mu[k] - gs, fl[k]);
+      nmax[k] = fmaxf(mu[k] + gs, fl[k]);
+    }
+    nmin[3] = mu[0] - sigma[0]; nmax[3] = mu[0] + sigma[0];
+  }
+  curHistoryBlur = saturatef(curHistoryBlur);   // :290-291
+  historyBlur = saturatef(historyBlur);
+  const f3 hTM = tssTM(mk3(history.x, history.y, history.z));   // :294-299
+  float historyTM[3] = {fminf(fmaxf(hTM.x, nmin[0]), nmax[0]), fminf(fmaxf(hTM.y, nmin[1]), nmax[1]), fminf(fmaxf(hTM.z, nmin[2]), nmax[2])};
+  const float contrast = nmax[3] - nmin[3];
+  const float lumContrastFactor = 32.0f * 4.0f;   // :303-308
+  float addAlias = historyBlur * 0.5f + 0.25f;
+  addAlias = saturatef(addAlias + 1.0f / (1.0f + contrast * lumContrastFactor));
+  const float ctm[3] = {currentTM.x, currentTM.y, currentTM.z};
+  for (int k = 0; k < 3; ++k) fl[k] = lerpf(fl[k], ctm[k], addAlias);   // :311
+  const float lumHist = historyTM[0];   // :314-325
+  const float distToClamp = fminf(fabsf(nmin[3] - lumHist), fabsf(nmax[3] - lumHist));
+  const float historyAmt = fminf(1.0f / history.w + historyBlur / 8.0f, 1.0f);
+  float blend = 0.25f / lerpf(8.0f, distToClamp + contrast, historyAmt);
+  blend = fminf(blend, 0.25f);
+  blend = fl[3] > 0.0f ? blend : 1.0f;
+  f3 result = tssITM(mk3(lerpf(historyTM[0], fl[0], blend), lerpf(historyTM[1], fl[1], blend), lerpf(historyTM[2], fl[2], blend)));   // :327-329
+  if (isnan(result.x) || isnan(result.y) || isnan(result.z)) result = tssITM(mk3(fl[0], fl[1], fl[2]));
+  const float hw = fminf(history.w / 15.0f, 1.0f - curHistoryBlur);
+  T.scratch[(size_t)y * W + x] = packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
+}
+
+// PSToneMap.hlsl:13-41; source = TSS[parity] (passed as T.scratch)
+__global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= T.W || y >= T.rowEnd) return;
+  const int W = T.W, H = T.H;
+  f4 col[5];
+  col[0] = loadRGBA16(T.scratch, x, y, W, H); col[1] = loadRGBA16(T.scratch, x - 1, y, W, H); col[2] = loadRGBA16(T.scratch, x + 1, y, W, H);
+  col[3] = loadRGBA16(T.scratch, x, y - 1, W, H); col[4] = loadRGBA16(T.scratch, x, y + 1, W, H);
+  for (int i = 0; i < 5; ++i) { col[i].x /= col[i].x + 0.5f; col[i].y /= col[i].y + 0.5f; col[i].z /= col[i].z + 0.5f; }
+  float lx = -4.0f * col[0].x, ly = -4.0f * col[0].y, lz = -4.0f * col[0].z;
+  for (int i = 1; i < 5; ++i) { lx += col[i].x; ly += col[i].y; lz += col[i].z; }
+  T.backbuffer[(size_t)y * W + x] = packRGBA8(col[0].x - 0.2f * lx, col[0].y - 0.2f * ly, col[0].z - 0.2f * lz, col[0].w);
+}
+
+static Targets makeTargets(rtggx_context* c, const FrameParams& fp) {
+  Targets T;
+  T.normal = c->normal; T.roughMetal = c->roughMetal; T.visDepth = c->visDepth; T.velocity = c->velocity;
+  T.rtRefl = c->rtRefl; T.rtDiff = c->rtDiff;
+  T.scratch = c->tss[c->frameParity]; T.history = c->tss[c->frameParity ^ 1u]; T.fltRfl = c->fltRfl; T.fltDff = c->fltDff; T.backbuffer = c->backbuffer;
+  T.W = (int)fp.W; T.H = (int)fp.H; T.rowBegin = (int)fp.rowBegin; T.rowEnd = (int)fp.rowEnd;
+  return T;
+}
+
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s) {
+  (void)useLds;
+  c->frameParity ^= 1u;   // Denoiser.cpp:69
+  if (fp.rowEnd <= fp.rowBegin) return 0;
+  const Targets T = makeTargets(c, fp);
+  const dim3 grid((fp.W + 63) / 64, (fp.rowEnd - fp.rowBegin + 3) / 4), block(256);
+  auto mark = [&](int i) { if (c->timing) hipEventRecord(c->tev[i], s); };
+  hipLaunchKernelGGL(spatialKernel<0>, grid, block, 0, s, T); mark(4);
+  hipLaunchKernelGGL(spatialKernel<1>, grid, block, 0, s, T); mark(5);
+  hipLaunchKernelGGL(spatialKernel<2>, grid, block, 0, s, T); mark(6);
+  hipLaunchKernelGGL(spatialKernel<3>, grid, block, 0, s, T); mark(7);
+  hipLaunchKernelGGL(temporalKernel, grid, block, 0, s, T); mark(8);
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
+  if (fp.rowEnd <= fp.rowBegin) return 0;
+  const Targets T = makeTargets(c, fp);
+  const dim3 grid((fp.W + 63) / 64, (fp.rowEnd - fp.rowBegin + 3) / 4), block(256);
+  hipLaunchKernelGGL(toneMapKernel, grid, block, 0, s, T);
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rt

@@ -1,0 +1,223 @@
+// Bottom-level acceleration structures: the gfx950 replacement of the driver-side BLAS build the
+// reference requests in RayTracer::buildAccelerationStructures / BuildAccelerationStructures
+// (RayTracedGGX/Content/RayTracer.cpp:676-716, 158-233; PREFER_FAST_TRACE, one triangle geometry
+// per mesh, R32G32B32_FLOAT positions at stride 24, 32-bit indices).
+//
+// LBVH (Karras 2012): 30-bit Morton codes of triangle-box centres -> stable LSD radix sort
+// (4 x 8 bits, wave64 ballot ranking) -> radix-tree hierarchy, one lane per internal node ->
+// bottom-up box fit with one arrival counter per node -> 64-byte nodes that carry both child
+// boxes, and 48-byte leaf triangles in Morton order.  Runs on the context's build stream; nothing
+// here is on the per-frame path (the BLAS is static, the TLAS refresh is rtggx_update_as).
+#include "rtggx_context.h"
+
+namespace rt {
+
+RT_DEV uint32_t expandBits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ void mortonKernel(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t n,
+                             float3 bmin, float3 invExt, uint32_t* __restrict__ codes, uint32_t* __restrict__ order,
+                             float* __restrict__ triBox) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float mn[3], mx[3];
+  for (int k = 0; k < 3; ++k) {
+    const float a = verts[6 * (size_t)idx[3 * i] + k], b = verts[6 * (size_t)idx[3 * i + 1] + k], c = verts[6 * (size_t)idx[3 * i + 2] + k];
+    mn[k] = fminf(a, fminf(b, c)); mx[k] = fmaxf(a, fmaxf(b, c));
+    triBox[6 * (size_t)i + k] = mn[k]; triBox[6 * (size_t)i + 3 + k] = mx[k];
+  }
+  const float cx = (0.5f * (mn[0] + mx[0]) - bmin.x) * invExt.x;
+  const float cy = (0.5f * (mn[1] + mx[1]) - bmin.y) * invExt.y;
+  const float cz = (0.5f * (mn[2] + mx[2]) - bmin.z) * invExt.z;
+  const uint32_t x = (uint32_t)fminf(fmaxf(cx * 1024.0f, 0.0f), 1023.0f);
+  const uint32_t y = (uint32_t)fminf(fmaxf(cy * 1024.0f, 0.0f), 1023.0f);
+  const uint32_t z = (uint32_t)fminf(fmaxf(cz * 1024.0f, 0.0f), 1023.0f);
+  codes[i] = (expandBits10(x) << 2) | (expandBits10(y) << 1) | expandBits10(z);
+  order[i] = i;
+}
+
+// ---- stable LSD radix sort, 8 bits per pass, 256 keys per workgroup --------------------------------
+__global__ void __launch_bounds__(256) radixHist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t* __restrict__ hist, uint32_t numBlocks) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  __syncthreads();
+  hist[threadIdx.x * numBlocks + blockIdx.x] = h[threadIdx.x];
+}
+// exclusive scan of `count` values by one workgroup
+__global__ void __launch_bounds__(1024) scanExclusive(uint32_t* __restrict__ data, uint32_t count) {
+  __shared__ uint32_t partial[1024];
+  const uint32_t per = (count + 1023) / 1024;
+  const uint32_t b = threadIdx.x * per, e = min(b + per, count);
+  uint32_t s = 0;
+  for (uint32_t i = b; i < e; ++i) s += data[i];
+  partial[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 1024; ++i) { const uint32_t v = partial[i]; partial[i] = run; run += v; } }
+  __syncthreads();
+  uint32_t run = partial[threadIdx.x];
+  for (uint32_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
+}
+__global__ void __launch_bounds__(256) radixScatter(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t n, int shift,
+                                                    const uint32_t* __restrict__ hist, uint32_t numBlocks,
+                                                    uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut) {
+  __shared__ uint32_t waveCount[4][256];
+  for (int w = 0; w < 4; ++w) waveCount[w][threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < n;
+  const uint32_t key = active ? keysIn[i] : 0xFFFFFFFFu;
+  const uint32_t digit = (key >> shift) & 255u;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned long long peers = __ballot(active);
+  for (int b = 0; b < 8; ++b) {
+    const unsigned long long m = __ballot(active && ((digit >> b) & 1u));
+    peers &= ((digit >> b) & 1u) ? m : ~m;
+  }
+  const uint32_t rankInWave = __popcll(peers & ((1ull << lane) - 1ull));
+  if (active && rankInWave == 0) waveCount[wave][digit] = (uint32_t)__popcll(peers);
+  __syncthreads();
+  if (active) {
+    uint32_t off = hist[digit * numBlocks + blockIdx.x] + rankInWave;
+    for (uint32_t w = 0; w < wave; ++w) off += waveCount[w][digit];
+    keysOut[off] = key; valsOut[off] = valsIn[i];
+  }
+}
+
+// ---- Karras hierarchy --------------------------------------------------------------------------------
+RT_DEV int deltaLcp(const uint32_t* __restrict__ codes, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint32_t a = codes[i], b = codes[j];
+  if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+  return __clz(a ^ b);
+}
+__global__ void hierarchyKernel(const uint32_t* __restrict__ codes, int n, int32_t* __restrict__ left, int32_t* __restrict__ right,
+                                int32_t* __restrict__ nodeParent, int32_t* __restrict__ leafParent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (deltaLcp(codes, n, i, i + 1) - deltaLcp(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = deltaLcp(codes, n, i, i - d);
+  int lmax = 2;
+  while (deltaLcp(codes, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2) if (deltaLcp(codes, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = deltaLcp(codes, n, i, j);
+  int s = 0, t = l;
+  do { t = (t + 1) / 2; if (deltaLcp(codes, n, i, i + (s + t) * d) > dnode) s += t; } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  if (lo == gamma) { left[i] = ~gamma; leafParent[gamma] = i; } else { left[i] = gamma; nodeParent[gamma] = i; }
+  if (hi == gamma + 1) { right[i] = ~(gamma + 1); leafParent[gamma + 1] = i; } else { right[i] = gamma + 1; nodeParent[gamma + 1] = i; }
+  if (i == 0) nodeParent[0] = -1;
+}
+
+RT_DEV float ldAgent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RT_DEV void stAgent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One lane per leaf climbs towards the root; the second arrival at a node merges the child boxes.
+__global__ void fitKernel(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
+                          const int32_t* __restrict__ right, const int32_t* __restrict__ nodeParent, const int32_t* __restrict__ leafParent,
+                          float* nodeBox, uint32_t* arrive) {
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= n) return;
+  int cur = leafParent[leaf];
+  while (cur >= 0) {
+    __threadfence();
+    const uint32_t old = atomicAdd(&arrive[cur], 1u);
+    if (old == 0) return;
+    __threadfence();
+    float b[2][6];
+    const int32_t ch[2] = {left[cur], right[cur]};
+    for (int s = 0; s < 2; ++s) {
+      if (ch[s] < 0) { const uint32_t prim = order[~ch[s]]; for (int k = 0; k < 6; ++k) b[s][k] = triBox[6 * (size_t)prim + k]; }
+      else for (int k = 0; k < 6; ++k) b[s][k] = ldAgent(&nodeBox[6 * (size_t)ch[s] + k]);
+    }
+    for (int k = 0; k < 3; ++k) { stAgent(&nodeBox[6 * (size_t)cur + k], fminf(b[0][k], b[1][k])); stAgent(&nodeBox[6 * (size_t)cur + 3 + k], fmaxf(b[0][3 + k], b[1][3 + k])); }
+    cur = nodeParent[cur];
+  }
+}
+
+__global__ void emitNodes(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
+                          const int32_t* __restrict__ right, const float* __restrict__ nodeBox, BvhNode* __restrict__ nodes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  BvhNode nd;
+  const int32_t l = left[i], r = right[i];
+  const float* lb = l < 0 ? &triBox[6 * (size_t)order[~l]] : &nodeBox[6 * (size_t)l];
+  const float* rb = r < 0 ? &triBox[6 * (size_t)order[~r]] : &nodeBox[6 * (size_t)r];
+  for (int k = 0; k < 3; ++k) { nd.lmin[k] = lb[k]; nd.lmax[k] = lb[3 + k]; nd.rmin[k] = rb[k]; nd.rmax[k] = rb[3 + k]; }
+  nd.left = l; nd.right = r; nd.pad[0] = 0; nd.pad[1] = 0;
+  nodes[i] = nd;
+}
+__global__ void emitTris(int n, const uint32_t* __restrict__ order, const float* __restrict__ verts, const uint32_t* __restrict__ idx, BvhTri* __restrict__ tris) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t prim = order[s];
+  BvhTri t;
+  for (int k = 0; k < 3; ++k) {
+    t.v0[k] = verts[6 * (size_t)idx[3 * (size_t)prim] + k];
+    t.v1[k] = verts[6 * (size_t)idx[3 * (size_t)prim + 1] + k];
+    t.v2[k] = verts[6 * (size_t)idx[3 * (size_t)prim + 2] + k];
+  }
+  t.prim = prim; t.pad[0] = 0; t.pad[1] = 0;
+  tris[s] = t;
+}
+
+int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
+  MeshDev& m = c->mesh[slot];
+  const uint32_t n = m.numTris;
+  if (m.nodes) { RT_HIP(hipFree(m.nodes)); m.nodes = nullptr; }
+  if (m.tris) { RT_HIP(hipFree(m.tris)); m.tris = nullptr; }
+  m.root = -1;
+  if (n == 0) return 0;
+  RT_HIP(hipMalloc(&m.tris, sizeof(BvhTri) * (size_t)n));
+  RT_HIP(hipMalloc(&m.nodes, sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)));
+
+  const float* mn = m.bmin; const float* mx = m.bmax;   // vertex bounds recorded by rtggx_set_mesh
+  float3 bmin = make_float3(mn[0], mn[1], mn[2]);
+  float3 invExt = make_float3(mx[0] > mn[0] ? 1.0f / (mx[0] - mn[0]) : 0.0f, mx[1] > mn[1] ? 1.0f / (mx[1] - mn[1]) : 0.0f, mx[2] > mn[2] ? 1.0f / (mx[2] - mn[2]) : 0.0f);
+
+  const uint32_t nb = (n + 255) / 256;
+  uint32_t *codes[2], *order[2], *hist; float *triBox, *nodeBox; int32_t *left, *right, *nodeParent, *leafParent; uint32_t* arrive;
+  RT_HIP(hipMalloc(&codes[0], 4 * (size_t)n)); RT_HIP(hipMalloc(&codes[1], 4 * (size_t)n));
+  RT_HIP(hipMalloc(&order[0], 4 * (size_t)n)); RT_HIP(hipMalloc(&order[1], 4 * (size_t)n));
+  RT_HIP(hipMalloc(&hist, 4 * (size_t)256 * nb));
+  RT_HIP(hipMalloc(&triBox, 4 * 6 * (size_t)n)); RT_HIP(hipMalloc(&nodeBox, 4 * 6 * (size_t)n));
+  RT_HIP(hipMalloc(&left, 4 * (size_t)n)); RT_HIP(hipMalloc(&right, 4 * (size_t)n));
+  RT_HIP(hipMalloc(&nodeParent, 4 * (size_t)n)); RT_HIP(hipMalloc(&leafParent, 4 * (size_t)n));
+  RT_HIP(hipMalloc(&arrive, 4 * (size_t)n));
+  RT_HIP(hipMemsetAsync(arrive, 0, 4 * (size_t)n, s));
+
+  hipLaunchKernelGGL(mortonKernel, dim3(nb), dim3(256), 0, s, m.verts, m.indices, n, bmin, invExt, codes[0], order[0], triBox);
+  int cur = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    hipLaunchKernelGGL(radixHist, dim3(nb), dim3(256), 0, s, codes[cur], n, shift, hist, nb);
+    hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, s, hist, 256u * nb);
+    hipLaunchKernelGGL(radixScatter, dim3(nb), dim3(256), 0, s, codes[cur], order[cur], n, shift, hist, nb, codes[cur ^ 1], order[cur ^ 1]);
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(emitTris, dim3(nb), dim3(256), 0, s, (int)n, order[cur], m.verts, m.indices, m.tris);
+  if (n == 1) m.root = ~0;
+  else {
+    hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, s, codes[cur], (int)n, left, right, nodeParent, leafParent);
+    hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, leafParent, nodeBox, arrive);
+    hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeBox, m.nodes);
+    m.root = 0;
+  }
+  RT_HIP(hipGetLastError());
+  RT_HIP(hipStreamSynchronize(s));
+  hipFree(codes[0]); hipFree(codes[1]); hipFree(order[0]); hipFree(order[1]); hipFree(hist); hipFree(triBox); hipFree(nodeBox);
+  hipFree(left); hipFree(right); hipFree(nodeParent); hipFree(leafParent); hipFree(arrive);
+  return 0;
+}
+
+}  // namespace rt

@@ -1,0 +1,119 @@
+// Context of librtggx: device memory, streams and per-frame state behind the C ABI of rtggx.h.
+//
+// HBM layout (all buffers are linear, row-major, one element per pixel, W*H elements):
+//   visDepth   u64   (D24 << 32) | visibility word -- the visibility pass resolves depth order
+//                    with one 64-bit atomicMin per fragment; consumers read the halves
+//   normal     u32   R10G10B10A2_UNORM      roughMetal u16 R8G8_UNORM     velocity u32 R16G16_FLOAT
+//   rtRefl/rtDiff u32 R11G11B10_FLOAT       tss[2], fltRfl, fltDff u64 R16G16B16A16_FLOAT
+//   backbuffer u32   R8G8B8A8_UNORM
+// Scene: per mesh 24-byte vertices, u32 indices, 64-byte BVH nodes, 48-byte leaf triangles;
+// environment as RGBA16F mip-major (6 faces per mip); 9 float3 SH coefficients.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "rtggx_device.h"
+
+namespace rt {
+
+struct MeshDev {
+  float* verts = nullptr;        // 6 floats per vertex
+  uint32_t* indices = nullptr;
+  uint32_t numVerts = 0, numIndices = 0, numTris = 0;
+  BvhNode* nodes = nullptr;      // numTris - 1 (0 when numTris == 1)
+  BvhTri* tris = nullptr;        // numTris, leaf (Morton) order
+  int32_t root = -1;             // 0, or ~0 for a single-triangle mesh
+  float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // vertex bounds (Morton normalisation box)
+};
+
+struct EnvDev {
+  uint2* texels = nullptr;       // RGBA16F, mip-major, 6 faces per mip
+  uint32_t size = 0, mips = 0;
+  uint32_t mipOffset[16] = {};   // texel offset of mip m (face 0)
+  uint64_t totalTexels = 0;
+};
+
+// Everything the per-frame kernels need, passed by value as one kernel argument.
+struct FrameParams {
+  RtggxCBGlobal g;
+  RtggxRayGenConstants rg;
+  RtggxCBPerObject po[2];
+  RtggxCBMaterial mat;
+  float invWorld[2][16];         // TLAS: world -> object, row-vector row-major
+  uint32_t W, H;
+  uint32_t rowBegin, rowEnd;     // strip of the frame this context renders
+};
+
+// Scene pointers as the trace/shade kernels see them (device-resident copy in rtggx_context::dScene).
+struct Scene {
+  const float* verts[2]; const uint32_t* idx[2];
+  const BvhNode* nodes[2]; const BvhTri* tris[2]; int32_t root[2];
+  const uint2* env; uint32_t envSize, envMips; uint32_t mipOffset[12];
+  const float* sh; const float* cosSin;
+};
+
+}  // namespace rt
+
+struct rtggx_context {
+  int device = 0;
+  uint32_t W = 0, H = 0;
+  uint32_t rowBegin = 0, rowEnd = 0;
+  hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
+  hipEvent_t evAS = nullptr, evFrameStart = nullptr;
+  bool externalStream = false;
+
+  rt::MeshDev mesh[2];
+  rt::EnvDev env;
+  float* sh = nullptr;           // 27 floats
+  float* cosSinTab = nullptr;    // 512 floats: cos[256], sin[256]
+
+  // render targets
+  unsigned long long* visDepth = nullptr;
+  uint32_t *normal = nullptr, *velocity = nullptr, *rtRefl = nullptr, *rtDiff = nullptr, *backbuffer = nullptr;
+  uint16_t* roughMetal = nullptr;
+  uint2 *tss[2] = {nullptr, nullptr}, *fltRfl = nullptr, *fltDff = nullptr;
+  uint32_t frameParity = 0;
+
+  // visibility scratch
+  void* largeTris = nullptr;     // LargeTri records
+  uint32_t* largeCount = nullptr;
+  uint32_t largeCapacity = 0;
+
+  // counters
+  unsigned long long* rayCounter = nullptr;
+
+  // per-frame constants: ring of RayTracer::FrameCount slots (host side; kernels take them by value)
+  rt::FrameParams slots[3];
+  uint32_t slot = 0;
+  rt::FrameParams* dParams = nullptr;   // device ring, 3 slots; kernels read their constants from here
+  rt::Scene* dScene = nullptr;          // device copy of the scene pointers
+  bool sceneDirty = true, slotUploaded = false;
+  RtggxCBMaterial material;
+  float invWorld[2][16];
+  bool haveConstants = false, asBuilt = false, shDone = false;
+
+  // timing
+  bool timing = false;
+  hipEvent_t tev[12];
+  RtggxTimings lastTimings{};
+  bool timingsPending = false;
+};
+
+namespace rt {
+void setError(const char* fmt, ...);
+#define RT_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rt::setError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return -2; } } while (0)
+
+// kernels / launchers implemented in the .hip files
+int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s);
+int uploadScene(rtggx_context* c, hipStream_t s);
+int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s);
+int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
+int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s);
+int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s);
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s);
+int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s);
+int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* hostData, size_t bytes, hipStream_t s);
+int projectSH(rtggx_context* c, hipStream_t s);
+int unpackVisDepth(rtggx_context* c, uint32_t* dVis, uint32_t* dDepth, hipStream_t s);
+int packVisDepth(rtggx_context* c, const uint32_t* dVis, const uint32_t* dDepth, hipStream_t s);
+}  // namespace rt

@@ -1,0 +1,188 @@
+// Visibility pass: RayTracer::visibility (RayTracedGGX/Content/RayTracer.cpp:751-791) with
+// VSVisibility.hlsl:26-32 and PSVisibility.hlsl:18-24, as a software rasteriser for gfx950
+// (CDNA4 has no fixed-function raster).
+//
+// D3D11 rasterisation rules, integer-exact: 8 sub-pixel bits, pixel centres at +0.5, top-left
+// rule, clockwise = front, back faces culled, depth LESS on D24, depth clip [0,1].
+// Depth order is resolved with ONE 64-bit atomicMin per fragment on the key
+//     (D24 << 32) | (((instance << 24) | primitive) + 1)
+// so equal depth keeps the fragment drawn first (lower instance, then lower primitive), exactly
+// what LESS does for two ordered draws.  The cleared key is (0xFFFFFF << 32) | 0.
+//
+// Two kernels: rasterSmall -- one lane per triangle, walks its own bounding box when it covers
+// <= 256 pixels (almost every model triangle), otherwise appends a setup record to a queue;
+// rasterLarge -- one 64x4 pixel tile per workgroup, one pixel per lane, loops over the queued
+// large triangles (the ground slab's faces) and merges with a plain read-min-write.
+// Roofline: HBM; algorithmic bytes 8 B/pixel (clear) + 8 B/covered fragment.
+#include "rtggx_context.h"
+
+namespace rt {
+
+struct LargeTri { int32_t X[3], Y[3]; float z[3]; uint32_t word; };
+
+struct RVert { long long X, Y; float z; bool ok; };
+
+RT_DEV RVert rasterVertex(const float* __restrict__ pos, const M4& wvp, float bx, float by, uint32_t W, uint32_t H) {
+  f4 p = mulPoint(mk3(pos[0], pos[1], pos[2]), wvp);
+  p.x += bx * p.w;
+  p.y += by * p.w;
+  RVert r; r.X = 0; r.Y = 0; r.z = 0.0f; r.ok = false;
+  if (!(p.w > 0.0f)) return r;
+  const float nx = p.x / p.w, ny = p.y / p.w;
+  r.z = p.z / p.w;
+  const float sx = (nx + 1.0f) * ((float)W * 0.5f);
+  const float sy = (1.0f - ny) * ((float)H * 0.5f);
+  const float fx = floorf(sx * 256.0f + 0.5f), fy = floorf(sy * 256.0f + 0.5f);
+  if (!(fabsf(fx) < 1073741824.0f) || !(fabsf(fy) < 1073741824.0f)) return r;
+  r.X = (long long)fx; r.Y = (long long)fy; r.ok = true;
+  return r;
+}
+RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
+  const long long dx = bx - ax, dy = by - ay;
+  return (dy == 0 && dx > 0) || dy < 0;
+}
+
+__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end) {
+  const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < end) vd[i] = 0x00FFFFFF00000000ull;
+}
+
+// Fragment test + depth for one pixel; returns the key or ~0 when not covered.
+RT_DEV unsigned long long fragmentKey(long long PX, long long PY, const long long X[3], const long long Y[3],
+                                      bool tl0, bool tl1, bool tl2, double invA, double z0, double dz1, double dz2, uint32_t word) {
+  const long long w0 = (X[2] - X[1]) * (PY - Y[1]) - (Y[2] - Y[1]) * (PX - X[1]);
+  const long long w1 = (X[0] - X[2]) * (PY - Y[2]) - (Y[0] - Y[2]) * (PX - X[2]);
+  const long long w2 = (X[1] - X[0]) * (PY - Y[0]) - (Y[1] - Y[0]) * (PX - X[0]);
+  if (w0 < 0 || w1 < 0 || w2 < 0) return ~0ull;
+  if ((w0 == 0 && !tl0) || (w1 == 0 && !tl1) || (w2 == 0 && !tl2)) return ~0ull;
+  const double l1 = (double)w1 * invA, l2 = (double)w2 * invA;
+  const double z = z0 + l1 * dz1 + l2 * dz2;
+  if (!(z >= 0.0) || !(z <= 1.0)) return ~0ull;
+  const uint32_t d24 = (uint32_t)(z * 16777215.0 + 0.5);
+  return ((unsigned long long)d24 << 32) | word;
+}
+
+__global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict__ fpp, const float* __restrict__ v0, const uint32_t* __restrict__ i0, uint32_t nt0,
+                                                   const float* __restrict__ v1, const uint32_t* __restrict__ i1, uint32_t nt1,
+                                                   unsigned long long* __restrict__ vd, LargeTri* __restrict__ large,
+                                                   uint32_t* __restrict__ largeCount, uint32_t largeCap) {
+  const FrameParams& fp = *fpp;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt0 + nt1) return;
+  const uint32_t inst = t < nt0 ? 0u : 1u;
+  const uint32_t prim = inst ? t - nt0 : t;
+  const float* verts = inst ? v1 : v0;
+  const uint32_t* idx = inst ? i1 : i0;
+  const M4 wvp = cbLoad4x4(fp.po[inst].WorldViewProj);
+  const float bx = fp.po[inst].ProjBias[0], by = fp.po[inst].ProjBias[1];
+  long long X[3], Y[3]; float z[3];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const RVert r = rasterVertex(verts + 6 * (size_t)idx[3 * (size_t)prim + k], wvp, bx, by, fp.W, fp.H);
+    X[k] = r.X; Y[k] = r.Y; z[k] = r.z; ok = ok && r.ok;
+  }
+  if (!ok) return;
+  const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+  if (area2 <= 0) return;
+  const long long minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
+  const long long minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
+  long long px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
+  long long py0 = (minY - 128 + 255) >> 8, py1 = (maxY - 128) >> 8;
+  px0 = max(px0, 0ll); py0 = max(py0, (long long)fp.rowBegin);
+  px1 = min(px1, (long long)fp.W - 1); py1 = min(py1, (long long)fp.rowEnd - 1);
+  if (px0 > px1 || py0 > py1) return;
+  const uint32_t word = ((inst << 24) | prim) + 1u;
+  const long long area = (px1 - px0 + 1) * (py1 - py0 + 1);
+  if (area > 256) {
+    const uint32_t slot = atomicAdd(largeCount, 1u);
+    if (slot < largeCap) {
+      LargeTri lt;
+      for (int k = 0; k < 3; ++k) { lt.X[k] = (int32_t)X[k]; lt.Y[k] = (int32_t)Y[k]; lt.z[k] = z[k]; }
+      lt.word = word;
+      large[slot] = lt;
+      return;
+    }
+    // queue full: fall through and rasterise here (correct, slow)
+  }
+  const bool tl0 = isTopLeft(X[1], Y[1], X[2], Y[2]), tl1 = isTopLeft(X[2], Y[2], X[0], Y[0]), tl2 = isTopLeft(X[0], Y[0], X[1], Y[1]);
+  const double invA = 1.0 / (double)area2;
+  const double z0 = (double)z[0], dz1 = (double)z[1] - z0, dz2 = (double)z[2] - z0;
+  for (long long py = py0; py <= py1; ++py)
+    for (long long px = px0; px <= px1; ++px) {
+      const unsigned long long key = fragmentKey(px * 256 + 128, py * 256 + 128, X, Y, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
+      if (key == ~0ull) continue;
+      unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
+      if (key < *dst) atomicMin(dst, key);
+    }
+}
+
+__global__ void __launch_bounds__(256) rasterLarge(const FrameParams* __restrict__ fpp, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
+                                                   const uint32_t* __restrict__ largeCount, uint32_t largeCap) {
+  const FrameParams& fp = *fpp;
+  const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63);
+  const uint32_t py = fp.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const uint32_t n = min(*largeCount, largeCap);
+  const long long tileX0 = (long long)(blockIdx.x * 64) * 256 + 128, tileX1 = tileX0 + 63 * 256;
+  const long long tileY0 = (long long)(fp.rowBegin + blockIdx.y * 4) * 256 + 128, tileY1 = tileY0 + 3 * 256;
+  const long long PX = (long long)px * 256 + 128, PY = (long long)py * 256 + 128;
+  unsigned long long best = ~0ull;
+  for (uint32_t i = 0; i < n; ++i) {
+    const LargeTri lt = large[i];
+    long long X[3], Y[3];
+    for (int k = 0; k < 3; ++k) { X[k] = lt.X[k]; Y[k] = lt.Y[k]; }
+    const long long minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
+    const long long minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
+    if (maxX < tileX0 || minX > tileX1 || maxY < tileY0 || minY > tileY1) continue;   // uniform per workgroup
+    const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+    const bool tl0 = isTopLeft(X[1], Y[1], X[2], Y[2]), tl1 = isTopLeft(X[2], Y[2], X[0], Y[0]), tl2 = isTopLeft(X[0], Y[0], X[1], Y[1]);
+    const double invA = 1.0 / (double)area2;
+    const double z0 = (double)lt.z[0], dz1 = (double)lt.z[1] - z0, dz2 = (double)lt.z[2] - z0;
+    const unsigned long long key = fragmentKey(PX, PY, X, Y, tl0, tl1, tl2, invA, z0, dz1, dz2, lt.word);
+    best = key < best ? key : best;
+  }
+  if (px < fp.W && py < fp.rowEnd && best != ~0ull) {
+    unsigned long long* dst = vd + (size_t)py * fp.W + px;
+    if (best < *dst) *dst = best;
+  }
+}
+
+__global__ void unpackVisDepthKernel(const unsigned long long* __restrict__ vd, uint32_t* __restrict__ vis, uint32_t* __restrict__ depth, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const unsigned long long k = vd[i]; vis[i] = (uint32_t)k; depth[i] = (uint32_t)(k >> 32); }
+}
+__global__ void packVisDepthKernel(unsigned long long* __restrict__ vd, const uint32_t* __restrict__ vis, const uint32_t* __restrict__ depth, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vd[i] = ((unsigned long long)depth[i] << 32) | vis[i];
+}
+
+int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
+  const uint32_t begin = fp.rowBegin * fp.W, end = fp.rowEnd * fp.W;
+  if (end <= begin) return 0;
+  RT_HIP(hipMemsetAsync(c->largeCount, 0, sizeof(uint32_t), s));
+  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end);
+  const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
+  if (nt) {
+    hipLaunchKernelGGL(rasterSmall, dim3((nt + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, c->mesh[0].verts, c->mesh[0].indices, c->mesh[0].numTris,
+                       c->mesh[1].verts, c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
+    hipLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (fp.rowEnd - fp.rowBegin + 3) / 4), dim3(256), 0, s, c->dParams + c->slot, c->visDepth,
+                       (const LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
+  }
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+
+int unpackVisDepth(rtggx_context* c, uint32_t* dVis, uint32_t* dDepth, hipStream_t s) {
+  const uint32_t n = c->W * c->H;
+  hipLaunchKernelGGL(unpackVisDepthKernel, dim3((n + 255) / 256), dim3(256), 0, s, c->visDepth, dVis, dDepth, n);
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+int packVisDepth(rtggx_context* c, const uint32_t* dVis, const uint32_t* dDepth, hipStream_t s) {
+  const uint32_t n = c->W * c->H;
+  hipLaunchKernelGGL(packVisDepthKernel, dim3((n + 255) / 256), dim3(256), 0, s, c->visDepth, dVis, dDepth, n);
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace rt

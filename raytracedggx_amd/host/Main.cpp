@@ -1,0 +1,33 @@
+// Headless replacement of WinMain + Win32Application::Run (RayTracedGGX/Main.cpp:15-20,
+// Common/Win32Application.cpp:17-79, 205-211): one OnUpdate + OnRender per frame, no window.
+// The argument tail of each Bin/*.bat works unchanged, e.g.
+//   RayTracedGGX -mesh Assets/bunny.obj 0.0 0.0 0.0 1.0 -width 1920 -height 1080 -frames 64 -dump out
+#include <chrono>
+#include <cstdio>
+#include <exception>
+#include "RayTracedGGX.h"
+
+int main(int argc, char* argv[]) {
+  RayTracedGGX app(1280, 720, "DXR Ray-Traced GGX");   // Main.cpp:17
+  app.ParseCommandLineArgs(argv, argc);
+  try {
+    app.OnInit();
+    rtggx_context* ctx = app.GetContext();
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t rays = 0;
+    for (uint32_t f = 0; f < app.GetNumFrames(); ++f) { app.OnUpdate(); app.OnRender(); }
+    rtggx_ray_count(ctx, &rays);   // synchronises
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("%u frames %ux%u: %.3f ms/frame, last frame %llu rays\n", app.GetNumFrames(), app.GetWidth(), app.GetHeight(),
+                ms / app.GetNumFrames(), (unsigned long long)rays);
+    if (!app.GetDumpPrefix().empty()) {
+      const std::string name = app.GetDumpPrefix() + ".ppm";
+      if (app.SaveImage(name.c_str())) std::printf("wrote %s\n", name.c_str());
+    }
+    app.OnDestroy();
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "RayTracedGGX: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

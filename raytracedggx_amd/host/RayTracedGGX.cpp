@@ -1,0 +1,129 @@
+#include "RayTracedGGX.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <vector>
+
+#define PIDIV4 0.785398163f
+
+static const float g_FOVAngleY = PIDIV4;   // RayTracedGGX.cpp:19-23
+static const float g_zNear = 1.0f;
+static const float g_zFar = 1000.0f;
+
+RayTracedGGX::RayTracedGGX(uint32_t width, uint32_t height, std::string name) : m_width(width), m_height(height), m_title(std::move(name)) {
+  for (auto& metallic : m_metallics) metallic = 1.0f;   // RayTracedGGX.cpp:51
+}
+
+RayTracedGGX::~RayTracedGGX() {}
+
+// LoadPipeline + LoadAssets (RayTracedGGX.cpp:61-279)
+void RayTracedGGX::OnInit() {
+  m_rayTracer = std::make_unique<RayTracer>();
+  if (!m_rayTracer->Init(m_width, m_height, m_meshFileName.c_str(), m_envFileName.c_str(), m_meshPosScale, m_device))
+    throw std::runtime_error("RayTracer::Init failed: " + m_rayTracer->GetLastError());
+  m_denoiser = std::make_unique<Denoiser>();
+  if (!m_denoiser->Init(m_rayTracer->GetContext(), m_width, m_height)) throw std::runtime_error("Denoiser::Init failed");
+  if (!m_rayTracer->BuildAccelerationStructures()) throw std::runtime_error("BuildAccelerationStructures failed: " + m_rayTracer->GetLastError());
+  if (!m_rayTracer->Postinit()) throw std::runtime_error("Postinit failed");
+  if (m_hasMetallicOverride) for (uint32_t i = 0; i < RayTracer::NUM_MESH; ++i) m_rayTracer->SetMetallic(i, m_metallics[i]);
+
+  // Projection and view (RayTracedGGX.cpp:262-277)
+  const float aspectRatio = (float)m_width / (float)m_height;
+  m_proj = xm::PerspectiveFovLH(g_FOVAngleY, aspectRatio, g_zNear, g_zFar);
+  m_focusPt = {0.0f, 3.0f, 0.0f};
+  m_eyePt = {10.0f, 10.0f, -24.0f};
+  m_view = xm::LookAtLH(m_eyePt, m_focusPt, xm::Float3{0.0f, 1.0f, 0.0f});
+  m_initialized = true;
+}
+
+// RayTracedGGX.cpp:282-299
+void RayTracedGGX::OnUpdate() {
+  const float timeStep = m_isPaused ? 0.0f : m_fixedTimeStep;
+  m_rayTracer->UpdateFrame(m_frameIndex, m_eyePt, m_view * m_proj, timeStep);
+}
+
+// RayTracedGGX.cpp:302-353.  asyncCompute: TLAS update on its own stream beside the visibility pass,
+// the ray trace waits for it; otherwise everything in submission order (PopulateCommandList :513-556).
+void RayTracedGGX::OnRender() {
+  m_rayTracer->UpdateAccelerationStructure(m_frameIndex);
+  m_rayTracer->RenderVisibility(m_frameIndex, m_asyncCompute != 0);
+  m_rayTracer->RayTrace(m_frameIndex);
+  m_denoiser->Denoise(m_useSharedMem, m_asyncCompute != 0);
+  m_denoiser->ToneMap();
+  m_frameIndex = (uint8_t)((m_frameIndex + 1) % FrameCount);   // MoveToNextFrame :684-701
+}
+
+void RayTracedGGX::OnDestroy() {
+  if (m_rayTracer && m_rayTracer->GetContext()) rtggx_sync(m_rayTracer->GetContext());   // WaitForGpu
+  m_denoiser.reset();
+  m_rayTracer.reset();
+  m_initialized = false;
+}
+
+// RayTracedGGX.cpp:365-398 (key codes: ' ' pause, 0x25/0x27 mesh select, 0x26/0x28 metallic, 'V', 'A')
+void RayTracedGGX::OnKeyUp(uint8_t key) {
+  float& metallic = m_metallics[m_currentMesh];
+  switch (key) {
+    case ' ': m_isPaused = !m_isPaused; break;
+    case 0x25: m_currentMesh = (m_currentMesh + RayTracer::NUM_MESH - 1) % RayTracer::NUM_MESH; break;
+    case 0x27: m_currentMesh = (m_currentMesh + 1) % RayTracer::NUM_MESH; break;
+    case 0x26: metallic = std::min(metallic + 0.25f, 1.0f); m_rayTracer->SetMetallic(m_currentMesh, metallic); break;
+    case 0x28: metallic = std::max(metallic - 0.25f, 0.0f); m_rayTracer->SetMetallic(m_currentMesh, metallic); break;
+    case 'V': m_useSharedMem = !m_useSharedMem; break;
+    case 'A': m_asyncCompute = !m_asyncCompute; break;
+    default: break;
+  }
+}
+
+// RayTracedGGX.cpp:462-511: '-' or '/' prefix, case-insensitive names; a following token is a value
+// unless it starts with '/' or with '-' not followed by a digit or '.'.
+void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
+  const auto lower = [](std::string s) { std::transform(s.begin(), s.end(), s.begin(), [](unsigned char ch) { return (char)std::tolower(ch); }); return s; };
+  const auto isArgMatched = [&](int i, const char* name) {
+    const char* arg = argv[i];
+    return (arg[0] == '-' || arg[0] == '/') && lower(arg + 1) == lower(name);
+  };
+  const auto hasNextArgValue = [&](int i) {
+    if (i + 1 >= argc) return false;
+    const char* arg = argv[i + 1];
+    return arg[0] != '/' && (arg[0] != '-' || (arg[1] >= '0' && arg[1] <= '9') || arg[1] == '.');
+  };
+  const auto nextFloat = [&](int& i, float& dst) { if (hasNextArgValue(i)) { float v; if (std::sscanf(argv[i + 1], "%f", &v) == 1) { dst = v; ++i; } } };
+  for (int i = 1; i < argc; ++i) {
+    if (isArgMatched(i, "warp") || isArgMatched(i, "uma")) continue;   // device selection of the D3D sample: ignored
+    else if (isArgMatched(i, "mesh")) {
+      if (hasNextArgValue(i)) m_meshFileName = argv[++i];
+      nextFloat(i, m_meshPosScale[0]); nextFloat(i, m_meshPosScale[1]); nextFloat(i, m_meshPosScale[2]); nextFloat(i, m_meshPosScale[3]);
+    } else if (isArgMatched(i, "env")) { if (hasNextArgValue(i)) m_envFileName = argv[++i]; }
+    // extensions replacing the window / message loop
+    else if (isArgMatched(i, "width")) { if (hasNextArgValue(i)) m_width = (uint32_t)std::atoi(argv[++i]); }
+    else if (isArgMatched(i, "height")) { if (hasNextArgValue(i)) m_height = (uint32_t)std::atoi(argv[++i]); }
+    else if (isArgMatched(i, "frames")) { if (hasNextArgValue(i)) m_numFrames = (uint32_t)std::atoi(argv[++i]); }
+    else if (isArgMatched(i, "dt")) { nextFloat(i, m_fixedTimeStep); }
+    else if (isArgMatched(i, "metallic")) { nextFloat(i, m_metallics[0]); nextFloat(i, m_metallics[1]); m_hasMetallicOverride = true; }
+    else if (isArgMatched(i, "sharedmem")) m_useSharedMem = true;
+    else if (isArgMatched(i, "sync")) m_asyncCompute = 0;
+    else if (isArgMatched(i, "device")) { if (hasNextArgValue(i)) m_device = std::atoi(argv[++i]); }
+    else if (isArgMatched(i, "dump")) { if (hasNextArgValue(i)) m_dumpPrefix = argv[++i]; }
+  }
+}
+
+bool RayTracedGGX::SaveImage(const char* fileName) {
+  rtggx_context* ctx = GetContext();
+  if (!ctx) return false;
+  std::vector<uint32_t> px((size_t)m_width * m_height);
+  if (rtggx_readback(ctx, RTGGX_BUF_BACKBUFFER, px.data(), px.size() * 4) != 0) { std::fprintf(stderr, "SaveImage: %s\n", rtggx_last_error()); return false; }
+  FILE* f = std::fopen(fileName, "wb");
+  if (!f) return false;
+  std::fprintf(f, "P6\n%u %u\n255\n", m_width, m_height);
+  std::vector<uint8_t> row((size_t)m_width * 3);
+  for (uint32_t y = 0; y < m_height; ++y) {
+    for (uint32_t x = 0; x < m_width; ++x) { const uint32_t p = px[(size_t)y * m_width + x]; row[3 * x] = (uint8_t)p; row[3 * x + 1] = (uint8_t)(p >> 8); row[3 * x + 2] = (uint8_t)(p >> 16); }
+    std::fwrite(row.data(), 1, row.size(), f);
+  }
+  std::fclose(f);
+  return true;
+}

@@ -1,0 +1,67 @@
+// Headless frame driver with the reference's entry points (RayTracedGGX/RayTracedGGX.h:27-146,
+// DXFramework virtuals RayTracedGGX/Common/DXFramework.h:23-26): OnInit / OnUpdate / OnRender /
+// OnDestroy, the same command line (RayTracedGGX.cpp:462-511) and the same defaults
+// (RayTracedGGX.cpp:37-39, camera :19-23, 267-277).  What the window supplied interactively is
+// supplied by extra flags: -width -height -frames -dt -metallic -sharedmem -sync -device -dump.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include "Denoiser.h"
+#include "RayTracer.h"
+#include "XMath.h"
+
+class RayTracedGGX {
+ public:
+  RayTracedGGX(uint32_t width, uint32_t height, std::string name);
+  virtual ~RayTracedGGX();
+
+  virtual void OnInit();
+  virtual void OnUpdate();
+  virtual void OnRender();
+  virtual void OnDestroy();
+  virtual void OnKeyUp(uint8_t key);
+
+  void ParseCommandLineArgs(char* argv[], int argc);
+
+  bool IsInitialized() const { return m_initialized; }
+  uint32_t GetWidth() const { return m_width; }
+  uint32_t GetHeight() const { return m_height; }
+  uint32_t GetNumFrames() const { return m_numFrames; }
+  const std::string& GetDumpPrefix() const { return m_dumpPrefix; }
+  RayTracer* GetRayTracer() const { return m_rayTracer.get(); }
+  rtggx_context* GetContext() const { return m_rayTracer ? m_rayTracer->GetContext() : nullptr; }
+  void SetFixedTimeStep(float dt) { m_fixedTimeStep = dt; }
+  bool SaveImage(const char* fileName);   // tone-mapped back buffer as binary PPM (screenshot, RayTracedGGX.cpp:719-739)
+
+ protected:
+  static const uint8_t FrameCount = RayTracer::FrameCount;
+
+  uint32_t m_width, m_height;
+  std::string m_title;
+  std::unique_ptr<RayTracer> m_rayTracer;
+  std::unique_ptr<Denoiser> m_denoiser;
+  uint8_t m_frameIndex = 0;
+  bool m_initialized = false;
+
+  // toggles of the reference (RayTracedGGX.h:118-124)
+  int m_asyncCompute = 1;
+  uint32_t m_currentMesh = 0;
+  bool m_useSharedMem = false;
+  bool m_isPaused = false;
+  float m_metallics[RayTracer::NUM_MESH];
+
+  // camera (RayTracedGGX.h:100-104)
+  xm::Matrix m_proj, m_view;
+  xm::Float3 m_focusPt, m_eyePt;
+
+  // command line
+  std::string m_meshFileName = "Assets/dragon.obj";
+  std::string m_envFileName = "Assets/rnl_cross.dds";
+  float m_meshPosScale[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+  uint32_t m_numFrames = 1;
+  float m_fixedTimeStep = 1.0f / 60.0f;   // the reference steps by the wall clock (StepTimer); fixed here for reproducible runs
+  int m_device = 0;
+  std::string m_dumpPrefix;
+  bool m_hasMetallicOverride = false;
+};

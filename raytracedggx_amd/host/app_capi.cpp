@@ -1,0 +1,69 @@
+// C entry points over the C++ host classes, for drivers that are not C++ (bench.py, tests):
+// the frame entry stays RayTracedGGX::OnUpdate / OnRender.
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+#include "ObjLoader.h"
+#include "RayTracedGGX.h"
+
+static thread_local std::string g_appError;
+
+extern "C" {
+
+const char* rtggx_app_last_error(void) { return g_appError.c_str(); }
+
+// argv-style construction: the same flags as the RayTracedGGX executable.
+void* rtggx_app_create(int argc, char** argv) {
+  try {
+    RayTracedGGX* app = new RayTracedGGX(1280, 720, "DXR Ray-Traced GGX");
+    app->ParseCommandLineArgs(argv, argc);
+    app->OnInit();
+    return app;
+  } catch (const std::exception& e) { g_appError = e.what(); return nullptr; }
+}
+void rtggx_app_destroy(void* h) { RayTracedGGX* app = (RayTracedGGX*)h; if (app) { app->OnDestroy(); delete app; } }
+void rtggx_app_on_update(void* h) { ((RayTracedGGX*)h)->OnUpdate(); }
+void rtggx_app_on_render(void* h) { ((RayTracedGGX*)h)->OnRender(); }
+void rtggx_app_on_key_up(void* h, int key) { ((RayTracedGGX*)h)->OnKeyUp((uint8_t)key); }
+void rtggx_app_set_time_step(void* h, float dt) { ((RayTracedGGX*)h)->SetFixedTimeStep(dt); }
+void* rtggx_app_context(void* h) { return ((RayTracedGGX*)h)->GetContext(); }
+void rtggx_app_size(void* h, uint32_t* w, uint32_t* ht) { *w = ((RayTracedGGX*)h)->GetWidth(); *ht = ((RayTracedGGX*)h)->GetHeight(); }
+void rtggx_app_frame_constants(void* h, void* out768) { std::memcpy(out768, &((RayTracedGGX*)h)->GetRayTracer()->GetFrameConstants(), sizeof(RtggxFrameConstants)); }
+int rtggx_app_save_image(void* h, const char* path) { return ((RayTracedGGX*)h)->SaveImage(path) ? 0 : -1; }
+
+// Host-only pieces, usable without a GPU: the OBJ importer and the Halton sequence.
+static ObjLoader g_obj;
+int rtggx_host_obj_import(const char* path, uint32_t* numVerts, uint32_t* numIndices, float* aabb6) {
+  g_obj = ObjLoader();
+  if (!g_obj.Import(path, true, true)) { g_appError = std::string("cannot import ") + path; return -1; }
+  *numVerts = g_obj.GetNumVertices(); *numIndices = g_obj.GetNumIndices();
+  if (aabb6) { const ObjLoader::AABB& a = g_obj.GetAABB(); aabb6[0] = a.Min.x; aabb6[1] = a.Min.y; aabb6[2] = a.Min.z; aabb6[3] = a.Max.x; aabb6[4] = a.Max.y; aabb6[5] = a.Max.z; }
+  return 0;
+}
+void rtggx_host_obj_copy(float* verts, uint32_t* indices) {
+  std::memcpy(verts, g_obj.GetVertices(), (size_t)g_obj.GetNumVertices() * 24);
+  std::memcpy(indices, g_obj.GetIndices(), (size_t)g_obj.GetNumIndices() * 4);
+}
+void rtggx_host_halton(uint32_t n, float* xy) { HaltonSequence h; for (uint32_t i = 0; i < n; ++i) h.Next(xy[2 * i], xy[2 * i + 1]); }
+
+// RayTracer::UpdateFrame on its own (constants only, no device): `frames` consecutive frames with a
+// fixed time step and the default camera; writes frames x 768 bytes.
+class ConstantsOnlyRayTracer : public RayTracer {
+ public:
+  void Setup(uint32_t w, uint32_t h, const float* ps) { m_width = w; m_height = h; std::memcpy(m_posScale, ps, 16); }
+};
+}  // extern "C"
+
+// UpdateFrame calls rtggx_update_frame; with a null context that call only reports an error, the constants are still produced.
+extern "C" void rtggx_host_frame_constants(uint32_t width, uint32_t height, const float* posScale4, const float* eye3, const float* focus3,
+                                           float dt, uint32_t frames, void* out) {
+  ConstantsOnlyRayTracer rt; rt.Setup(width, height, posScale4);
+  const xm::Float3 eye{eye3[0], eye3[1], eye3[2]}, focus{focus3[0], focus3[1], focus3[2]};
+  const xm::Matrix proj = xm::PerspectiveFovLH(0.785398163f, (float)width / (float)height, 1.0f, 1000.0f);
+  const xm::Matrix view = xm::LookAtLH(eye, focus, xm::Float3{0.0f, 1.0f, 0.0f});
+  for (uint32_t f = 0; f < frames; ++f) {
+    rt.UpdateFrame((uint8_t)(f % 3), eye, view * proj, dt);
+    std::memcpy((char*)out + 768 * (size_t)f, &rt.GetFrameConstants(), 768);
+  }
+}
