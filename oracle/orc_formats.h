@@ -105,8 +105,13 @@ static inline void unpack_r10g10b10a2(uint32_t p, float* v) {
 static inline uint16_t pack_r8g8(float x, float y) {
   return (uint16_t)(f32_to_unorm(x, 255) | (f32_to_unorm(y, 255) << 8));
 }
+// R16G16_FLOAT store (velocity).  The sign of a zero is canonicalised to +0: no consumer can observe
+// it, and D3D does not promise -0/+0 distinction through a typed store.
 static inline uint32_t pack_r16g16f(float x, float y) {
-  return (uint32_t)f32_to_f16(x) | ((uint32_t)f32_to_f16(y) << 16);
+  uint32_t hx = f32_to_f16(x), hy = f32_to_f16(y);
+  if ((hx & 0x7FFFu) == 0) hx = 0;
+  if ((hy & 0x7FFFu) == 0) hy = 0;
+  return hx | (hy << 16);
 }
 static inline uint64_t pack_rgba16f(float r, float g, float b, float a) {
   return (uint64_t)f32_to_f16(r) | ((uint64_t)f32_to_f16(g) << 16) | ((uint64_t)f32_to_f16(b) << 32) | ((uint64_t)f32_to_f16(a) << 48);

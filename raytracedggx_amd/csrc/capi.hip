@@ -377,6 +377,7 @@ int rtggx_readback(rtggx_context* c, int id, void* dst, size_t bytes) {
     uint32_t *dVis, *dDepth;
     RT_HIP(hipMalloc(&dVis, need)); RT_HIP(hipMalloc(&dDepth, need));
     r = unpackVisDepth(c, dVis, dDepth, c->streamMain);
+    if (!r && hipStreamSynchronize(c->streamMain) != hipSuccess) { setError("readback: stream sync failed"); r = -2; }   // the copy below runs on the null stream
     if (!r) { hipError_t e = hipMemcpy(dst, id == RTGGX_BUF_VISIBILITY ? dVis : dDepth, need, hipMemcpyDeviceToHost); if (e != hipSuccess) { setError("hipMemcpy: %s", hipGetErrorString(e)); r = -2; } }
     hipFree(dVis); hipFree(dDepth);
     return r;
@@ -398,6 +399,7 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
     uint32_t *dVis, *dDepth;
     RT_HIP(hipMalloc(&dVis, need)); RT_HIP(hipMalloc(&dDepth, need));
     r = unpackVisDepth(c, dVis, dDepth, c->streamMain);
+    if (!r && hipStreamSynchronize(c->streamMain) != hipSuccess) { setError("upload: stream sync failed"); r = -2; }
     if (!r) { hipError_t e = hipMemcpy(id == RTGGX_BUF_VISIBILITY ? dVis : dDepth, src, need, hipMemcpyHostToDevice); if (e != hipSuccess) { setError("hipMemcpy: %s", hipGetErrorString(e)); r = -2; } }
     if (!r) r = packVisDepth(c, dVis, dDepth, c->streamMain);
     hipStreamSynchronize(c->streamMain);

@@ -85,7 +85,7 @@ __device__ __noinline__ void traceClosest(const Scene& sc, const float* invWorld
   best.t = tmax; best.inst = 0; best.prim = 0; best.b1 = 0.0f; best.b2 = 0.0f; best.valid = false;
   if (!(tmax > tmin)) return;
   for (uint32_t inst = 0; inst < 2; ++inst) {
-    if (sc.root[inst] == -1) continue;
+    if (sc.tris[inst] == nullptr) continue;   // empty mesh (root is ~0 = -1 for a single-triangle mesh)
     const RayX r = rayToObject(o, d, inst ? invWorld1 : invWorld0);
     const BvhNode* __restrict__ nodes = sc.nodes[inst];
     const BvhTri* __restrict__ tris = sc.tris[inst];

@@ -133,7 +133,13 @@ RT_DEV uint32_t packR10G10B10A2(float x, float y, float z, float w) {
   return f32ToUnorm(x, 1023) | (f32ToUnorm(y, 1023) << 10) | (f32ToUnorm(z, 1023) << 20) | (f32ToUnorm(w, 3) << 30);
 }
 RT_DEV uint32_t packR8G8(float x, float y) { return f32ToUnorm(x, 255) | (f32ToUnorm(y, 255) << 8); }
-RT_DEV uint32_t packR16G16F(float x, float y) { return f32ToF16(x) | (f32ToF16(y) << 16); }
+// velocity store: the sign of a zero is canonicalised to +0 (not observable by any consumer)
+RT_DEV uint32_t packR16G16F(float x, float y) {
+  uint32_t hx = f32ToF16(x), hy = f32ToF16(y);
+  if ((hx & 0x7FFFu) == 0) hx = 0;
+  if ((hy & 0x7FFFu) == 0) hy = 0;
+  return hx | (hy << 16);
+}
 RT_DEV uint2 packRGBA16F(float r, float g, float b, float a) {
   return make_uint2(f32ToF16(r) | (f32ToF16(g) << 16), f32ToF16(b) | (f32ToF16(a) << 16));
 }

@@ -86,10 +86,14 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     const char* arg = argv[i];
     return (arg[0] == '-' || arg[0] == '/') && lower(arg + 1) == lower(name);
   };
+  // On POSIX an absolute path also starts with '/': such a token is a flag only when it names one.
+  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump"};
+  const auto isFlagName = [&](const char* name) { for (const char* f : kFlags) if (lower(name) == f) return true; return false; };
   const auto hasNextArgValue = [&](int i) {
     if (i + 1 >= argc) return false;
     const char* arg = argv[i + 1];
-    return arg[0] != '/' && (arg[0] != '-' || (arg[1] >= '0' && arg[1] <= '9') || arg[1] == '.');
+    if (arg[0] == '/') return !isFlagName(arg + 1);
+    return arg[0] != '-' || (arg[1] >= '0' && arg[1] <= '9') || arg[1] == '.';
   };
   const auto nextFloat = [&](int& i, float& dst) { if (hasNextArgValue(i)) { float v; if (std::sscanf(argv[i + 1], "%f", &v) == 1) { dst = v; ++i; } } };
   for (int i = 1; i < argc; ++i) {

@@ -59,6 +59,11 @@ def main():
                                ("velocity", capi.BUF_VELOCITY, O.BUF_VELOCITY), ("backbuffer", capi.BUF_BACKBUFFER, O.BUF_BACKBUFFER)):
             g, r = ctx.readback(gid), o.buffer(oid)
             print("  %-10s mismatching words: %d / %d" % (name, int((g != r).sum()), g.size))
+            if name == "velocity" and (g != r).any():
+                ys, xs = np.nonzero(g != r)
+                for k in range(min(8, ys.size)):
+                    gg, rr = g[ys[k], xs[k]], r[ys[k], xs[k]]
+                    print("     (%d,%d) gpu %08x %s oracle %08x %s" % (xs[k], ys[k], gg, np.array([gg], np.uint32).view(np.float16), rr, np.array([rr], np.uint32).view(np.float16)))
         for name, gid, oid in (("rt_refl", capi.BUF_RT_REFL, O.BUF_RT_REFL), ("rt_diff", capi.BUF_RT_DIFF, O.BUF_RT_DIFF)):
             g, r = ctx.readback(gid), o.buffer(oid)
             print("  %-10s mismatching words: %d  relL2 %.3e" % (name, int((g != r).sum()), rel_l2(O.unpack_r11g11b10f(g), O.unpack_r11g11b10f(r))))

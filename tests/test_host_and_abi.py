@@ -1,0 +1,116 @@
+"""CPU-side tests of the product: the C++ host layer (no GPU needed for the host arithmetic) and the
+C ABI surface.  No compute entry point is called here."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import assets
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol(built):
+    """librtggx.so loads and exports exactly what include/rtggx.h declares."""
+    from raytracedggx_amd import capi
+    header = open(os.path.join(ROOT, "include", "rtggx.h")).read()
+    declared = sorted(set(re.findall(r"\b(rtggx_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 25
+    lib = C.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "librtggx.so does not export " + name
+    assert sorted(capi.EXPORTS) == declared
+    # the constant-buffer mirror has the reference's byte layout
+    txt = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (rtggx_[a-z_0-9]+)", txt))
+    assert exported == set(declared)
+
+
+def test_host_library_exports(built):
+    from raytracedggx_amd import app
+    lib = C.CDLL(app.HOST_LIB_PATH)
+    for name in app.HOST_EXPORTS:
+        assert hasattr(lib, name)
+
+
+def test_product_fails_loudly_without_gpu(built):
+    """No CPU fallback: creating a context without a HIP device is an error, not a silent downgrade."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from raytracedggx_amd import app, capi
+    with pytest.raises(capi.RtggxError):
+        capi.Context(64, 64)
+    with pytest.raises(capi.RtggxError):
+        app.RayTracedGGX(["-mesh", assets.path("triangle.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 64, "-height", 64])
+
+
+def test_host_obj_importer_matches_golden_and_oracle(built):
+    from raytracedggx_amd import app
+    facts = json.load(open(os.path.join(ROOT, "tests", "golden", "obj_import.json")))
+    for name in ("bunny", "dragon"):
+        v, i, aabb = app.obj_import(assets.path(name + ".obj"))
+        assert "%08x" % assets.fnv1a32(i.tobytes()) == facts[name]["fnv_indices"]
+        assert "%08x" % assets.fnv1a32(v.tobytes()) == facts[name]["fnv_verts"]
+        ov, oi, oaabb = O.obj_import(assets.path(name + ".obj"))
+        np.testing.assert_array_equal(v.view(np.uint32), ov.view(np.uint32))
+        np.testing.assert_array_equal(i, oi)
+        np.testing.assert_array_equal(aabb, oaabb)
+
+
+def test_host_obj_importer_edge_cases(built, tmp_path):
+    from raytracedggx_amd import app
+    cases = {
+        "normals_fan_negative.obj": "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvn 0 0 2\nf 1//1 2//1 3//1 4//1\nf -4//2 -3//2 -2//2\n",
+        "texcoords.obj": "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nf 1/1 2/2 3/3\n",
+        "full.obj": "v 0 0 0\nv 2 0 0\nv 0 2 0\nv 0 0 2\nvt 0 0\nvn 0 0 1\nvn 1 0 0\nf 1/1/1 2/1/1 3/1/1\nf 1/1/2 3/1/2 4/1/2\n# end\n",
+        "empty.obj": "# nothing here\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / name
+        p.write_text(text)
+        v, i, aabb = app.obj_import(str(p))
+        ov, oi, oaabb = O.obj_import(str(p))
+        np.testing.assert_array_equal(v.view(np.uint32), ov.view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(i, oi, err_msg=name)
+    with pytest.raises(IOError):
+        app.obj_import(str(tmp_path / "missing.obj"))
+
+
+def test_host_halton_and_frame_constants_match_oracle(built):
+    """RayTracer::UpdateFrame of the host layer vs the oracle's restatement, byte for byte, over a FrameIndex wrap."""
+    from raytracedggx_amd import app
+    xy = app.halton(600)
+    o = O.Oracle(16, 16, threads=1)
+    for k in range(600):
+        np.testing.assert_array_equal(xy[k], o.halton())
+    for (W, H, ps, dt) in ((1920, 1080, (0, 0, 0, 1), 1 / 60), (640, 360, (0.0, 2.8, 0.0, 0.03), 0.0), (3840, 2160, (1, 2, 3, 0.5), 0.125)):
+        frames = 260
+        fc = app.frame_constants(W, H, frames, dt=dt, pos_scale=ps)
+        o = O.Oracle(W, H, threads=1)
+        o.set_pos_scale(ps)
+        vp = O.camera_view_proj(W, H)
+        for f in range(frames):
+            o.update_frame((10, 10, -24), vp, dt)
+            want = o.get_frame_constants()
+            np.testing.assert_array_equal(fc[f][:704], want[:704], err_msg="frame %d" % f)
+        assert fc[-1].view(np.uint32)[111] == (frames - 1) % 256      # CBGlobal::FrameIndex at byte 444
+    # first frame: previous WVP defined as the current one; second frame: the first frame's
+    fc = app.frame_constants(320, 180, 2).view(np.float32)
+    np.testing.assert_array_equal(fc[0][32:64], fc[0][0:32])
+    np.testing.assert_array_equal(fc[1][32:64], fc[0][0:32])
+
+
+def test_headless_executable_reports_missing_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "raytracedggx_amd", "RayTracedGGX")
+    r = subprocess.run([exe, "-mesh", assets.path("triangle.obj"), "-env", assets.path("rnl_cross.dds"), "-width", "64", "-height", "64"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
