@@ -105,7 +105,8 @@ enum {
 /* Per-pass GPU timings of the last completed frame, in milliseconds (hipEvent based). */
 typedef struct RtggxTimings {
   float update_as, visibility, ray_trace, spatial_refl_h, spatial_refl_v, spatial_diff_h, spatial_diff_v,
-        temporal, tone_map, frame;
+        temporal, tone_map, frame,
+        ray_trace_kernel;   /* the fused raygen/trace/shade kernel alone (events right around its launch) */
 } RtggxTimings;
 
 const char* rtggx_last_error(void);
@@ -149,8 +150,15 @@ int  rtggx_tone_map(rtggx_context* ctx);
 int  rtggx_sync(rtggx_context* ctx);
 /* Number of non-degenerate rays (TMax > TMin) traced by the last rtggx_ray_trace; synchronises. */
 int  rtggx_ray_count(rtggx_context* ctx, uint64_t* rays);
+/* Rays traced since the last reset (accumulated on the device, no per-frame synchronisation); synchronises. */
+int  rtggx_ray_total(rtggx_context* ctx, uint64_t* rays, int reset);
 int  rtggx_get_timings(rtggx_context* ctx, RtggxTimings* out);
-int  rtggx_enable_timing(rtggx_context* ctx, int enabled);
+/* mode 0 off, 1 every pass (rtggx_get_timings), 2 only the ray-trace kernel: one HIP event pair per frame,
+ * recorded on the launching stream right around the kernel, kept for up to RTGGX_KERNEL_RING frames. */
+#define RTGGX_KERNEL_RING 4096
+int  rtggx_enable_timing(rtggx_context* ctx, int mode);
+/* Durations (ms) of the ray-trace kernel launches recorded in mode 2 since the last call; synchronises. */
+int  rtggx_kernel_times(rtggx_context* ctx, float* ms, uint32_t capacity, uint32_t* count);
 
 /* Size in bytes of a buffer / synchronous copy into caller memory / raw device pointer. */
 int  rtggx_buffer_size(rtggx_context* ctx, int buffer_id, size_t* bytes);

@@ -28,12 +28,12 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
-           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays"]
+           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times"]
 
 
 class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("update_as", "visibility", "ray_trace", "spatial_refl_h", "spatial_refl_v",
-                                         "spatial_diff_h", "spatial_diff_v", "temporal", "tone_map", "frame")]
+                                         "spatial_diff_h", "spatial_diff_v", "temporal", "tone_map", "frame", "ray_trace_kernel")]
 
 
 _lib = None
@@ -74,6 +74,8 @@ def load():
     L.rtggx_frame_parity.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rtggx_bvh_root.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
     L.rtggx_trace_rays.argtypes = [vp, vp, C.c_uint32, vp]
+    L.rtggx_ray_total.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.rtggx_kernel_times.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -168,8 +170,20 @@ class Context:
         self._check(self.L.rtggx_ray_count(self.h, C.byref(n)))
         return int(n.value)
 
-    def enable_timing(self, on=True):
-        self._check(self.L.rtggx_enable_timing(self.h, 1 if on else 0))
+    def ray_total(self, reset=False):
+        n = C.c_uint64()
+        self._check(self.L.rtggx_ray_total(self.h, C.byref(n), 1 if reset else 0))
+        return int(n.value)
+
+    def enable_timing(self, mode=1):
+        """0 off, 1 every pass (timings()), 2 ray-trace kernel ring (kernel_times())."""
+        self._check(self.L.rtggx_enable_timing(self.h, int(mode)))
+
+    def kernel_times(self):
+        ms = np.zeros(4096, np.float32)
+        n = C.c_uint32()
+        self._check(self.L.rtggx_kernel_times(self.h, _p(ms), ms.size, C.byref(n)))
+        return ms[:n.value].copy()
 
     def timings(self):
         t = Timings()

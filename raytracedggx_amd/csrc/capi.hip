@@ -137,7 +137,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
   c->largeCapacity = 1u << 16;
   RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 40)); RT_HIP(hipMalloc(&c->largeCount, 4));
-  RT_HIP(hipMalloc(&c->rayCounter, 256 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 256 * 8));
+  RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
   RT_HIP(hipMalloc(&c->sh, 27 * 4)); RT_HIP(hipMemset(c->sh, 0, 27 * 4));
   RT_HIP(hipMalloc(&c->cosSinTab, 512 * 4));
   RT_HIP(hipMalloc(&c->dParams, 3 * sizeof(FrameParams)));
@@ -317,7 +317,38 @@ int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
   return 0;
 }
 
-int rtggx_enable_timing(rtggx_context* c, int enabled) { RT_CHECK_CTX(c); c->timing = enabled != 0; c->timingsPending = false; return 0; }
+int rtggx_ray_total(rtggx_context* c, uint64_t* rays, int reset) {
+  RT_CHECK_CTX(c);
+  unsigned long long h[256];
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipMemcpy(h, c->rayCounter + 256, sizeof h, hipMemcpyDeviceToHost));
+  uint64_t s = 0; for (auto v : h) s += v;
+  *rays = s;
+  if (reset) RT_HIP(hipMemset(c->rayCounter + 256, 0, sizeof h));
+  return 0;
+}
+
+// mode 0: off; 1: every pass (rtggx_get_timings); 2: only the ray-trace kernel, one event pair per frame
+// kept in a ring of `RTGGX_KERNEL_RING` frames (rtggx_kernel_times) -- no host synchronisation per frame.
+int rtggx_enable_timing(rtggx_context* c, int mode) {
+  RT_CHECK_CTX(c);
+  c->timing = mode == 1; c->timingsPending = false;
+  c->kernelRing = mode == 2; c->kevCount = 0;
+  if (c->kernelRing && c->kevBegin.empty()) {
+    c->kevBegin.resize(RTGGX_KERNEL_RING); c->kevEnd.resize(RTGGX_KERNEL_RING);
+    for (uint32_t i = 0; i < RTGGX_KERNEL_RING; ++i) { RT_HIP(hipEventCreate(&c->kevBegin[i])); RT_HIP(hipEventCreate(&c->kevEnd[i])); }
+  }
+  return 0;
+}
+int rtggx_kernel_times(rtggx_context* c, float* ms, uint32_t capacity, uint32_t* count) {
+  RT_CHECK_CTX(c);
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  const uint32_t n = c->kevCount < capacity ? c->kevCount : capacity;
+  for (uint32_t i = 0; i < n; ++i) RT_HIP(hipEventElapsedTime(&ms[i], c->kevBegin[i], c->kevEnd[i]));
+  *count = n;
+  c->kevCount = 0;
+  return 0;
+}
 int rtggx_get_timings(rtggx_context* c, RtggxTimings* out) {
   RT_CHECK_CTX(c);
   if (!c->timing || !c->timingsPending) { setError("rtggx_get_timings: timing not enabled or no complete frame"); return -1; }
@@ -326,6 +357,7 @@ int rtggx_get_timings(rtggx_context* c, RtggxTimings* out) {
   RtggxTimings t;
   t.update_as = ms(0, 1); t.visibility = ms(2, 3); t.ray_trace = ms(3, 9); t.spatial_refl_h = ms(9, 4); t.spatial_refl_v = ms(4, 5);
   t.spatial_diff_h = ms(5, 6); t.spatial_diff_v = ms(6, 7); t.temporal = ms(7, 8); t.tone_map = ms(8, 10); t.frame = ms(2, 10);
+  t.ray_trace_kernel = ms(11, 12);
   *out = t; c->lastTimings = t;
   return 0;
 }

@@ -232,12 +232,14 @@ __global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
   T.backbuffer[(size_t)y * W + x] = packRGBA8(col[0].x - 0.2f * lx, col[0].y - 0.2f * ly, col[0].z - 0.2f * lz, col[0].w);
 }
 
-static Targets makeTargets(rtggx_context* c, const FrameParams& fp) {
+static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass) {
   Targets T;
   T.normal = c->normal; T.roughMetal = c->roughMetal; T.visDepth = c->visDepth; T.velocity = c->velocity;
   T.rtRefl = c->rtRefl; T.rtDiff = c->rtDiff;
   T.scratch = c->tss[c->frameParity]; T.history = c->tss[c->frameParity ^ 1u]; T.fltRfl = c->fltRfl; T.fltDff = c->fltDff; T.backbuffer = c->backbuffer;
-  T.W = (int)fp.W; T.H = (int)fp.H; T.rowBegin = (int)fp.rowBegin; T.rowEnd = (int)fp.rowEnd;
+  T.W = (int)fp.W; T.H = (int)fp.H;
+  uint32_t rb, re; passRows(fp, pass, rb, re);
+  T.rowBegin = (int)rb; T.rowEnd = (int)re;
   return T;
 }
 
@@ -245,22 +247,23 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
   (void)useLds;
   c->frameParity ^= 1u;   // Denoiser.cpp:69
   if (fp.rowEnd <= fp.rowBegin) return 0;
-  const Targets T = makeTargets(c, fp);
-  const dim3 grid((fp.W + 63) / 64, (fp.rowEnd - fp.rowBegin + 3) / 4), block(256);
+  const Targets TH = makeTargets(c, fp, ROWS_GBUFFER), TV = makeTargets(c, fp, ROWS_VFILTER), TT = makeTargets(c, fp, ROWS_TEMPORAL);
+  const dim3 block(256);
+  auto grid = [&](const Targets& T) { return dim3((fp.W + 63) / 64, (T.rowEnd - T.rowBegin + 3) / 4); };
   auto mark = [&](int i) { if (c->timing) hipEventRecord(c->tev[i], s); };
-  hipLaunchKernelGGL(spatialKernel<0>, grid, block, 0, s, T); mark(4);
-  hipLaunchKernelGGL(spatialKernel<1>, grid, block, 0, s, T); mark(5);
-  hipLaunchKernelGGL(spatialKernel<2>, grid, block, 0, s, T); mark(6);
-  hipLaunchKernelGGL(spatialKernel<3>, grid, block, 0, s, T); mark(7);
-  hipLaunchKernelGGL(temporalKernel, grid, block, 0, s, T); mark(8);
+  hipLaunchKernelGGL(spatialKernel<0>, grid(TH), block, 0, s, TH); mark(4);
+  hipLaunchKernelGGL(spatialKernel<1>, grid(TV), block, 0, s, TV); mark(5);
+  hipLaunchKernelGGL(spatialKernel<2>, grid(TH), block, 0, s, TH); mark(6);
+  hipLaunchKernelGGL(spatialKernel<3>, grid(TV), block, 0, s, TV); mark(7);
+  hipLaunchKernelGGL(temporalKernel, grid(TT), block, 0, s, TT); mark(8);
   RT_HIP(hipGetLastError());
   return 0;
 }
 
 int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   if (fp.rowEnd <= fp.rowBegin) return 0;
-  const Targets T = makeTargets(c, fp);
-  const dim3 grid((fp.W + 63) / 64, (fp.rowEnd - fp.rowBegin + 3) / 4), block(256);
+  const Targets T = makeTargets(c, fp, ROWS_FINAL);
+  const dim3 grid((fp.W + 63) / 64, (T.rowEnd - T.rowBegin + 3) / 4), block(256);
   hipLaunchKernelGGL(toneMapKernel, grid, block, 0, s, T);
   RT_HIP(hipGetLastError());
   return 0;

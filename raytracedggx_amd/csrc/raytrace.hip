@@ -325,7 +325,7 @@ RT_DEV uint32_t xcdRemap(uint32_t b, uint32_t n) {
 __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restrict__ fpp, const Scene* __restrict__ scp, const unsigned long long* __restrict__ visDepth,
                                                     uint32_t* __restrict__ normalOut, uint16_t* __restrict__ roughMetalOut, uint32_t* __restrict__ velocityOut,
                                                     uint32_t* __restrict__ reflOut, uint32_t* __restrict__ diffOut, unsigned long long* __restrict__ rayCounters,
-                                                    uint32_t tilesX, uint32_t numTiles) {
+                                                    uint32_t tilesX, uint32_t numTiles, uint32_t rowBegin, uint32_t rowEnd) {
   const FrameParams& fp = *fpp;
   const Scene& sc = *scp;
   __shared__ int32_t stackMem[RT_STACK * 256];
@@ -336,9 +336,9 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
   const uint32_t tile = xcdRemap(blockIdx.x, numTiles);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t px = (tile % tilesX) * 16 + (wave & 1u) * 8 + (lane & 7u);
-  const uint32_t py = fp.rowBegin + (tile / tilesX) * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const uint32_t py = rowBegin + (tile / tilesX) * 16 + (wave >> 1) * 8 + (lane >> 3);
   uint32_t rays = 0;
-  if (px < fp.W && py < fp.rowEnd) {
+  if (px < fp.W && py < rowEnd) {
     const uint32_t W = fp.W, H = fp.H;
     const size_t pix = (size_t)py * W + px;
     int32_t* stack = stackMem + threadIdx.x;
@@ -435,18 +435,29 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
       diffOut[pix] = packR11G11B10F(diff);
     }
   }
+  if (py < fp.rowBegin || py >= fp.rowEnd) rays = 0;   // apron rows are recomputed by the neighbouring strip's owner: counted there
   if (rays) atomicAdd(&blockRays, rays);
   __syncthreads();
-  if (threadIdx.x == 0 && blockRays) atomicAdd(&rayCounters[blockIdx.x & 255u], (unsigned long long)blockRays);
+  if (threadIdx.x == 0 && blockRays) {
+    atomicAdd(&rayCounters[blockIdx.x & 255u], (unsigned long long)blockRays);           // this frame
+    atomicAdd(&rayCounters[256u + (blockIdx.x & 255u)], (unsigned long long)blockRays);    // running total (rtggx_ray_total)
+  }
 }
 
 int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
-  if (fp.rowEnd <= fp.rowBegin) return 0;
-  const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (fp.rowEnd - fp.rowBegin + 15) / 16;
+  uint32_t rb, re;
+  passRows(fp, ROWS_GBUFFER, rb, re);
+  if (re <= rb) return 0;
+  const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
   const uint32_t numTiles = tilesX * tilesY;
   RT_HIP(hipMemsetAsync(c->rayCounter, 0, 256 * sizeof(unsigned long long), s));
+  if (c->timing) hipEventRecord(c->tev[11], s);
+  const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size();
+  if (ring) hipEventRecord(c->kevBegin[c->kevCount], s);
   hipLaunchKernelGGL(rayGenKernel, dim3(numTiles), dim3(256), 0, s, c->dParams + c->slot, c->dScene, c->visDepth, c->normal, c->roughMetal, c->velocity,
-                     c->rtRefl, c->rtDiff, c->rayCounter, tilesX, numTiles);
+                     c->rtRefl, c->rtDiff, c->rayCounter, tilesX, numTiles, rb, re);
+  if (c->timing) hipEventRecord(c->tev[12], s);
+  if (ring) hipEventRecord(c->kevEnd[c->kevCount++], s);
   RT_HIP(hipGetLastError());
   return 0;
 }

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "rtggx_device.h"
 
 namespace rt {
@@ -93,13 +94,27 @@ struct rtggx_context {
   bool haveConstants = false, asBuilt = false, shDone = false;
 
   // timing
-  bool timing = false;
-  hipEvent_t tev[12];
+  bool timing = false;        // all per-pass events (rtggx_get_timings)
+  bool kernelRing = false;    // only the ray-trace kernel, one event pair per frame in a ring (rtggx_kernel_times)
+  std::vector<hipEvent_t> kevBegin, kevEnd;
+  uint32_t kevCount = 0;
+  hipEvent_t tev[16];
   RtggxTimings lastTimings{};
   bool timingsPending = false;
 };
 
 namespace rt {
+// Rows each pass must cover so that the strip [rowBegin,rowEnd) of the final image is exact
+// (SURVEY.md 8e): the tone map reads TSS at +-1 row, the temporal pass FilteredOut1 at +-1, the
+// vertical filters the horizontal scratch at +-16.  Pure per-pixel passes recompute the apron
+// instead of exchanging it.
+enum RowPass { ROWS_GBUFFER /* visibility, ray trace, H filters: +-18 */, ROWS_VFILTER /* +-2 */, ROWS_TEMPORAL /* +-1 */, ROWS_FINAL };
+inline void passRows(const FrameParams& fp, RowPass pass, uint32_t& b, uint32_t& e) {
+  const uint32_t apron = pass == ROWS_GBUFFER ? 18u : pass == ROWS_VFILTER ? 2u : pass == ROWS_TEMPORAL ? 1u : 0u;
+  b = fp.rowBegin > apron ? fp.rowBegin - apron : 0u;
+  e = fp.rowEnd + apron < fp.H ? fp.rowEnd + apron : fp.H;
+  if (fp.rowEnd <= fp.rowBegin) { b = e = 0; }
+}
 void setError(const char* fmt, ...);
 #define RT_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rt::setError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return -2; } } while (0)
 

@@ -62,7 +62,7 @@ RT_DEV unsigned long long fragmentKey(long long PX, long long PY, const long lon
   return ((unsigned long long)d24 << 32) | word;
 }
 
-__global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict__ fpp, const float* __restrict__ v0, const uint32_t* __restrict__ i0, uint32_t nt0,
+__global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict__ fpp, uint32_t rowBegin, uint32_t rowEnd, const float* __restrict__ v0, const uint32_t* __restrict__ i0, uint32_t nt0,
                                                    const float* __restrict__ v1, const uint32_t* __restrict__ i1, uint32_t nt1,
                                                    unsigned long long* __restrict__ vd, LargeTri* __restrict__ large,
                                                    uint32_t* __restrict__ largeCount, uint32_t largeCap) {
@@ -89,8 +89,8 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict
   const long long minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
   long long px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
   long long py0 = (minY - 128 + 255) >> 8, py1 = (maxY - 128) >> 8;
-  px0 = max(px0, 0ll); py0 = max(py0, (long long)fp.rowBegin);
-  px1 = min(px1, (long long)fp.W - 1); py1 = min(py1, (long long)fp.rowEnd - 1);
+  px0 = max(px0, 0ll); py0 = max(py0, (long long)rowBegin);
+  px1 = min(px1, (long long)fp.W - 1); py1 = min(py1, (long long)rowEnd - 1);
   if (px0 > px1 || py0 > py1) return;
   const uint32_t word = ((inst << 24) | prim) + 1u;
   const long long area = (px1 - px0 + 1) * (py1 - py0 + 1);
@@ -117,14 +117,14 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict
     }
 }
 
-__global__ void __launch_bounds__(256) rasterLarge(const FrameParams* __restrict__ fpp, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
+__global__ void __launch_bounds__(256) rasterLarge(const FrameParams* __restrict__ fpp, uint32_t rowBegin, uint32_t rowEnd, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
                                                    const uint32_t* __restrict__ largeCount, uint32_t largeCap) {
   const FrameParams& fp = *fpp;
   const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63);
-  const uint32_t py = fp.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const uint32_t py = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
   const uint32_t n = min(*largeCount, largeCap);
   const long long tileX0 = (long long)(blockIdx.x * 64) * 256 + 128, tileX1 = tileX0 + 63 * 256;
-  const long long tileY0 = (long long)(fp.rowBegin + blockIdx.y * 4) * 256 + 128, tileY1 = tileY0 + 3 * 256;
+  const long long tileY0 = (long long)(rowBegin + blockIdx.y * 4) * 256 + 128, tileY1 = tileY0 + 3 * 256;
   const long long PX = (long long)px * 256 + 128, PY = (long long)py * 256 + 128;
   unsigned long long best = ~0ull;
   for (uint32_t i = 0; i < n; ++i) {
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) rasterLarge(const FrameParams* __restrict
     const unsigned long long key = fragmentKey(PX, PY, X, Y, tl0, tl1, tl2, invA, z0, dz1, dz2, lt.word);
     best = key < best ? key : best;
   }
-  if (px < fp.W && py < fp.rowEnd && best != ~0ull) {
+  if (px < fp.W && py < rowEnd && best != ~0ull) {
     unsigned long long* dst = vd + (size_t)py * fp.W + px;
     if (best < *dst) *dst = best;
   }
@@ -157,15 +157,17 @@ __global__ void packVisDepthKernel(unsigned long long* __restrict__ vd, const ui
 }
 
 int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
-  const uint32_t begin = fp.rowBegin * fp.W, end = fp.rowEnd * fp.W;
+  uint32_t rb, re;
+  passRows(fp, ROWS_GBUFFER, rb, re);
+  const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
   RT_HIP(hipMemsetAsync(c->largeCount, 0, sizeof(uint32_t), s));
   hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end);
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
   if (nt) {
-    hipLaunchKernelGGL(rasterSmall, dim3((nt + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, c->mesh[0].verts, c->mesh[0].indices, c->mesh[0].numTris,
+    hipLaunchKernelGGL(rasterSmall, dim3((nt + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->mesh[0].verts, c->mesh[0].indices, c->mesh[0].numTris,
                        c->mesh[1].verts, c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
-    hipLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (fp.rowEnd - fp.rowBegin + 3) / 4), dim3(256), 0, s, c->dParams + c->slot, c->visDepth,
+    hipLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (re - rb + 3) / 4), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->visDepth,
                        (const LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
   }
   RT_HIP(hipGetLastError());

@@ -44,7 +44,7 @@ def main():
     env_g = ctx.readback(capi.BUF_ENV)
     print("env texels equal:", np.array_equal(env_o, env_g), env_g.shape)
     o.transform_sh()
-    ctx.enable_timing(True)
+    ctx.enable_timing(1)
     vp = O.camera_view_proj(W, H)
     for f in range(frames):
         a.OnUpdate(); a.OnRender(); ctx.sync()
