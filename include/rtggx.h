@@ -94,7 +94,7 @@ enum {
   RTGGX_BUF_BACKBUFFER = 11, /* uint32  R8G8B8A8_UNORM */
   RTGGX_BUF_SH_COEFFS = 12,  /* 27 floats: 9 x float3 */
   RTGGX_BUF_BVH_NODES0 = 13, /* 64-byte nodes of mesh 0 (see DESIGN.md "BVH layout") */
-  RTGGX_BUF_BVH_TRIS0 = 14,  /* 48-byte leaf triangles of mesh 0 */
+  RTGGX_BUF_BVH_TRIS0 = 14,  /* 64-byte leaf triangles of mesh 0: v0,v1,v2 (9 floats), 3 pad, primitive id (word 12), 3 pad */
   RTGGX_BUF_BVH_NODES1 = 15,
   RTGGX_BUF_BVH_TRIS1 = 16,
   RTGGX_BUF_TLAS = 17,       /* 2 x 16 floats: world->object matrices (row-vector, row-major) */
@@ -152,6 +152,9 @@ int  rtggx_sync(rtggx_context* ctx);
 int  rtggx_ray_count(rtggx_context* ctx, uint64_t* rays);
 /* Rays traced since the last reset (accumulated on the device, no per-frame synchronisation); synchronises. */
 int  rtggx_ray_total(rtggx_context* ctx, uint64_t* rays, int reset);
+/* Diagnostic counters (non-zero only in builds with -DRT_TRACE_STATS): [0] lane node steps, [1] lane leaf steps,
+ * [2] wave iterations, [3] refills of the trace kernel since the last reset. */
+int  rtggx_debug_counters(rtggx_context* ctx, uint32_t* out, uint32_t n, int reset);
 int  rtggx_get_timings(rtggx_context* ctx, RtggxTimings* out);
 /* mode 0 off, 1 every pass (rtggx_get_timings), 2 only the ray-trace kernel: one HIP event pair per frame,
  * recorded on the launching stream right around the kernel, kept for up to RTGGX_KERNEL_RING frames. */

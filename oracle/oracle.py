@@ -163,13 +163,13 @@ class Oracle:
         nodes = np.ascontiguousarray(nodes)
         tris = np.ascontiguousarray(tris)
         self.L.orc_set_bvh(self.h, C.c_uint32(slot), _fp(nodes), C.c_uint32(nodes.nbytes // 64), _fp(tris),
-                           C.c_uint32(tris.nbytes // 48), C.c_int32(root))
+                           C.c_uint32(tris.nbytes // 64), C.c_int32(root))
 
     def get_bvh(self, slot):
         nn, nt, root = C.c_uint32(), C.c_uint32(), C.c_int32()
         self.L.orc_bvh_info(self.h, C.c_uint32(slot), C.byref(nn), C.byref(nt), C.byref(root))
         nodes = np.zeros((nn.value, 16), np.uint32)
-        tris = np.zeros((nt.value, 12), np.uint32)
+        tris = np.zeros((nt.value, 16), np.uint32)
         self.L.orc_bvh_copy(self.h, C.c_uint32(slot), _fp(nodes), _fp(tris))
         return nodes, tris, root.value
 

@@ -87,6 +87,10 @@ static inline void slab(const RayXform& r, const float* bmin, const float* bmax,
   tf = std::fmin(std::fmin(std::fmax(x1, x2), std::fmax(y1, y2)), std::fmin(std::fmax(z1, z2), tmax));
 }
 
+// traversal statistics for performance analysis (node visits, leaf tests, deepest stack), per thread
+struct TraverseStats { uint64_t nodes = 0, leaves = 0, rays = 0; int maxStack = 0; };
+static thread_local TraverseStats g_tstats;
+
 static inline void traverse_blas(const Bvh& bvh, const RayXform& r, float tmin, uint32_t inst, Hit& best,
                                  uint32_t skipInst, uint32_t skipPrim) {
   if (bvh.tris.empty()) return;
@@ -94,12 +98,15 @@ static inline void traverse_blas(const Bvh& bvh, const RayXform& r, float tmin, 
   int32_t cur = bvh.root;
   for (;;) {
     if (cur < 0) {
+      ++g_tstats.leaves;
       consider(best, tmin, inst, bvh.tris[(size_t)~cur], r, skipInst, skipPrim);
       if (sp == 0) break;
       cur = stack[--sp];
       continue;
     }
     const BvhNode& n = bvh.nodes[(size_t)cur];
+    ++g_tstats.nodes;
+    if (sp > g_tstats.maxStack) g_tstats.maxStack = sp;
     float ln, lf, rn, rf;
     slab(r, n.lmin, n.lmax, tmin, best.t, ln, lf);
     slab(r, n.rmin, n.rmax, tmin, best.t, rn, rf);

@@ -203,6 +203,18 @@ void orc_trace_rays(void* h, const float* rays, uint32_t n, int brute, float* ou
   });
 }
 
+// traversal statistics of a ray list on the calling thread: out = {node visits, leaf tests, max stack depth}
+void orc_trace_stats(void* h, const float* rays, uint32_t n, uint64_t* out3) {
+  Ctx* c = (Ctx*)h;
+  g_tstats = TraverseStats{};
+  for (uint32_t i = 0; i < n; ++i) { const float* r = rays + 8 * (size_t)i; trace_closest(*c, f3(r[0], r[1], r[2]), f3(r[3], r[4], r[5]), r[6], r[7]); }
+  out3[0] = g_tstats.nodes; out3[1] = g_tstats.leaves; out3[2] = (uint64_t)g_tstats.maxStack;
+}
+
+// statistics accumulated on the calling thread (use orc_set_threads(h, 1) so that passes run on it)
+void orc_tstats_reset(void) { g_tstats = TraverseStats{}; }
+void orc_tstats_get(uint64_t* out3) { out3[0] = g_tstats.nodes; out3[1] = g_tstats.leaves; out3[2] = (uint64_t)g_tstats.maxStack; }
+
 // ---- small known-answer probes ----------------------------------------------------------------------
 uint32_t orc_rng(uint32_t seed) { return rng(seed); }
 void orc_sample_param(uint32_t x, uint32_t y, uint32_t W, uint32_t frameIndex, uint32_t* s, float* xi2) {

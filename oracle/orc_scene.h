@@ -52,12 +52,13 @@ struct BvhNode {           // 64 B; internal nodes only, node 0 is the root
   int32_t left, right;     // >= 0: internal node index; < 0: leaf, ~ref = slot in the triangle array
   int32_t pad[2];
 };
-struct BvhTri {            // 48 B, leaf order
+struct BvhTri {            // 64 B, leaf order
   float v0[3], v1[3], v2[3];
-  uint32_t prim;           // primitive index in the index buffer (= SV_PrimitiveID / PrimitiveIndex())
-  uint32_t pad[2];
+  uint32_t pad0[3];
+  uint32_t prim;           // word 12: primitive index in the index buffer (= SV_PrimitiveID / PrimitiveIndex())
+  uint32_t pad1[3];
 };
-static_assert(sizeof(BvhNode) == 64 && sizeof(BvhTri) == 48, "bvh layout");
+static_assert(sizeof(BvhNode) == 64 && sizeof(BvhTri) == 64, "bvh layout");
 struct Bvh { std::vector<BvhNode> nodes; std::vector<BvhTri> tris; int32_t root = -1; };
 
 struct Mesh { std::vector<float> verts; std::vector<uint32_t> idx; Bvh bvh; };

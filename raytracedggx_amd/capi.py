@@ -28,7 +28,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
-           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times"]
+           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters"]
 
 
 class Timings(C.Structure):
@@ -175,6 +175,12 @@ class Context:
         self._check(self.L.rtggx_ray_total(self.h, C.byref(n), 1 if reset else 0))
         return int(n.value)
 
+    def debug_counters(self, n=8, reset=True):
+        out = np.zeros(n, np.uint32)
+        self.L.rtggx_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        self._check(self.L.rtggx_debug_counters(self.h, _p(out), n, 1 if reset else 0))
+        return out
+
     def enable_timing(self, mode=1):
         """0 off, 1 every pass (timings()), 2 ray-trace kernel ring (kernel_times())."""
         self._check(self.L.rtggx_enable_timing(self.h, int(mode)))
@@ -213,7 +219,7 @@ class Context:
         if bid in (BUF_BVH_NODES0, BUF_BVH_NODES1):
             return out.reshape(-1, 16)
         if bid in (BUF_BVH_TRIS0, BUF_BVH_TRIS1):
-            return out.reshape(-1, 12)
+            return out.reshape(-1, 16)
         if bid == BUF_TLAS:
             return out.reshape(2, 4, 4)
         if bid == BUF_ENV:

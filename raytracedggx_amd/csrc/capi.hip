@@ -138,6 +138,23 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   c->largeCapacity = 1u << 16;
   RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 40)); RT_HIP(hipMalloc(&c->largeCount, 4));
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
+  RT_HIP(hipMalloc(&c->rayCounter32, 1024 * 4)); RT_HIP(hipMemset(c->rayCounter32, 0, 1024 * 4));   // [0..255] rays; [256..] RT_TRACE_STATS
+  {
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device));
+    c->numCUs = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    // one bin of 128 ray slots per 8x8 pixel sub-tile (4 per 16x16 tile): at most 2 rays per pixel
+    const uint32_t tiles = ((width + 15) / 16) * ((height + 15) / 16);
+    c->numBinsMax = tiles * 4u;
+    if (c->numBinsMax < 64u) c->numBinsMax = 64u;            // room for rtggx_trace_rays batches on tiny frames
+    RT_HIP(hipMalloc(&c->rayQueue, (size_t)c->numBinsMax * 128 * 64));
+    RT_HIP(hipMalloc(&c->hitQueue, (size_t)c->numBinsMax * 128 * 16));
+    RT_HIP(hipMalloc(&c->binCount, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCount, 0, (size_t)c->numBinsMax * 4));
+    RT_HIP(hipMalloc(&c->binHead, 64 * 32 * 4)); RT_HIP(hipMemset(c->binHead, 0, 64 * 32 * 4));
+    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)32 * c->numCUs * 8 * 256 * 4));   // 32 spill entries x (8 workgroups/CU x 256 lanes)
+    RT_HIP(hipMalloc(&c->dEnvMipOffset, 16 * 4)); RT_HIP(hipMemset(c->dEnvMipOffset, 0, 16 * 4));
+    RT_HIP(hipMalloc(&c->dummyRecord, 64)); RT_HIP(hipMemset(c->dummyRecord, 0, 64));
+  }
   RT_HIP(hipMalloc(&c->sh, 27 * 4)); RT_HIP(hipMemset(c->sh, 0, 27 * 4));
   RT_HIP(hipMalloc(&c->cosSinTab, 512 * 4));
   RT_HIP(hipMalloc(&c->dParams, 3 * sizeof(FrameParams)));
@@ -169,6 +186,10 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->visDepth); hipFree(c->normal); hipFree(c->velocity);
   hipFree(c->rtRefl); hipFree(c->rtDiff); hipFree(c->backbuffer); hipFree(c->roughMetal); hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
+  hipFree(c->rayQueue); hipFree(c->hitQueue); hipFree(c->binCount); hipFree(c->binHead); hipFree(c->stackOverflow); hipFree(c->dummyRecord);
+  hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32);
+  for (auto& e : c->kevBegin) hipEventDestroy(e);
+  for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
   hipEventDestroy(c->evAS); hipEventDestroy(c->evFrameStart);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS);
@@ -317,6 +338,17 @@ int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
   return 0;
 }
 
+// Diagnostic counters of builds compiled with -DRT_TRACE_STATS (zero otherwise): lane node steps, lane leaf
+// steps, wave iterations, refills -- accumulated since the last reset.
+int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset) {
+  RT_CHECK_CTX(c);
+  if (n > 768) { setError("rtggx_debug_counters: at most 768 words"); return -1; }
+  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipMemcpy(out, c->rayCounter32 + 256, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (reset) RT_HIP(hipMemset(c->rayCounter32 + 256, 0, 768 * 4));
+  return 0;
+}
+
 int rtggx_ray_total(rtggx_context* c, uint64_t* rays, int reset) {
   RT_CHECK_CTX(c);
   unsigned long long h[256];
@@ -378,7 +410,7 @@ static int bufferInfo(rtggx_context* c, int id, void** ptr, size_t* bytes) {
     case RTGGX_BUF_BACKBUFFER: *ptr = c->backbuffer; *bytes = n * 4; return 0;
     case RTGGX_BUF_SH_COEFFS: *ptr = c->sh; *bytes = 108; return 0;
     case RTGGX_BUF_BVH_NODES0: case RTGGX_BUF_BVH_NODES1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_NODES1]; *ptr = m.nodes; *bytes = m.numTris > 1 && m.nodes ? (size_t)(m.numTris - 1) * 64 : 0; return 0; }
-    case RTGGX_BUF_BVH_TRIS0: case RTGGX_BUF_BVH_TRIS1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_TRIS1]; *ptr = m.tris; *bytes = m.tris ? (size_t)m.numTris * 48 : 0; return 0; }
+    case RTGGX_BUF_BVH_TRIS0: case RTGGX_BUF_BVH_TRIS1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_TRIS1]; *ptr = m.tris; *bytes = m.tris ? (size_t)m.numTris * 64 : 0; return 0; }
     case RTGGX_BUF_TLAS: *ptr = nullptr; *bytes = 128; return 0;
     case RTGGX_BUF_ENV: *ptr = c->env.texels; *bytes = (size_t)c->env.totalTexels * 8; return 0;
     default: setError("unknown buffer id %d", id); return -1;
@@ -455,7 +487,12 @@ int rtggx_trace_rays(rtggx_context* c, const float* rays, uint32_t n, float* out
   float *dR, *dO;
   RT_HIP(hipMalloc(&dR, (size_t)n * 32)); RT_HIP(hipMalloc(&dO, (size_t)n * 24));
   RT_HIP(hipMemcpy(dR, rays, (size_t)n * 32, hipMemcpyHostToDevice));
-  int r = launchTraceRays(c, c->slots[c->slot], dR, n, dO, c->streamMain);
+  int r = 0;
+  const uint32_t perLaunch = c->numBinsMax * 128u;
+  for (uint32_t done = 0; done < n && !r; done += perLaunch) {   // the ray bins' capacity per launch
+    const uint32_t m = n - done < perLaunch ? n - done : perLaunch;
+    r = launchTraceRays(c, c->slots[c->slot], dR + (size_t)done * 8, m, dO + (size_t)done * 6, c->streamMain);
+  }
   if (!r) { hipError_t e = hipStreamSynchronize(c->streamMain); if (e == hipSuccess) e = hipMemcpy(out, dO, (size_t)n * 24, hipMemcpyDeviceToHost); if (e != hipSuccess) { setError("trace_rays: %s", hipGetErrorString(e)); r = -2; } }
   hipFree(dR); hipFree(dO);
   return r;

@@ -190,6 +190,7 @@ int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const 
   RT_HIP(hipStreamSynchronize(s));
   hipFree(dSrc);
   if (dModes) hipFree(dModes);
+  RT_HIP(hipMemcpy(c->dEnvMipOffset, c->env.mipOffset, 16 * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->sceneDirty = true; c->shDone = false;
   return 0;
 }

@@ -6,7 +6,7 @@
 // LBVH (Karras 2012): 30-bit Morton codes of triangle-box centres -> stable LSD radix sort
 // (4 x 8 bits, wave64 ballot ranking) -> radix-tree hierarchy, one lane per internal node ->
 // bottom-up box fit with one arrival counter per node -> 64-byte nodes that carry both child
-// boxes, and 48-byte leaf triangles in Morton order.  Runs on the context's build stream; nothing
+// boxes, and 64-byte leaf triangles in Morton order.  Runs on the context's build stream; nothing
 // here is on the per-frame path (the BLAS is static, the TLAS refresh is rtggx_update_as).
 #include "rtggx_context.h"
 
@@ -167,7 +167,8 @@ __global__ void emitTris(int n, const uint32_t* __restrict__ order, const float*
     t.v1[k] = verts[6 * (size_t)idx[3 * (size_t)prim + 1] + k];
     t.v2[k] = verts[6 * (size_t)idx[3 * (size_t)prim + 2] + k];
   }
-  t.prim = prim; t.pad[0] = 0; t.pad[1] = 0;
+  t.prim = prim;
+  for (int k = 0; k < 3; ++k) { t.pad0[k] = 0; t.pad1[k] = 0; }
   tris[s] = t;
 }
 

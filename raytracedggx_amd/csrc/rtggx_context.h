@@ -80,8 +80,20 @@ struct rtggx_context {
   uint32_t* largeCount = nullptr;
   uint32_t largeCapacity = 0;
 
+  // ray bins of the trace pass (rt_queue.h): numBinsMax bins of 128 64-byte ray records + 16-byte hit records
+  void* rayQueue = nullptr;
+  void* hitQueue = nullptr;
+  uint32_t* binCount = nullptr;         // rays in each bin
+  uint32_t* binHead = nullptr;          // 64 list heads, 128 bytes apart (trace.hip)
+  uint32_t numBinsMax = 0;
+  int32_t* stackOverflow = nullptr;     // traversal-stack spill area (entries beyond the LDS stack)
+  void* dummyRecord = nullptr;          // 64 zero bytes: record base for meshes without nodes / absent meshes
+  uint32_t* dEnvMipOffset = nullptr;    // device copy of env.mipOffset
+  uint32_t numCUs = 256;
+
   // counters
-  unsigned long long* rayCounter = nullptr;
+  uint32_t* rayCounter32 = nullptr;     // 256 per-frame partial counts written by the trace kernel
+  unsigned long long* rayCounter = nullptr;   // [0..255] last frame, [256..511] running total
 
   // per-frame constants: ring of RayTracer::FrameCount slots (host side; kernels take them by value)
   rt::FrameParams slots[3];

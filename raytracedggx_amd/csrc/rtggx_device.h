@@ -157,10 +157,11 @@ struct BvhNode {           // 64 B, internal nodes only; node 0 is the root
   int32_t left, right;     // >= 0 internal node, < 0 leaf: ~ref = slot in the triangle array
   int32_t pad[2];
 };
-struct BvhTri {            // 48 B
+struct BvhTri {            // 64 B (same record size as a node: one cooperative 64-byte gather serves both)
   float v0[3], v1[3], v2[3];
-  uint32_t prim;
-  uint32_t pad[2];
+  uint32_t pad0[3];
+  uint32_t prim;           // word 12: same position as a node's left-child word, so one 4th quarter serves both record kinds
+  uint32_t pad1[3];
 };
 
 }  // namespace rt

@@ -105,12 +105,12 @@ class StripRenderer:
 
     def scene_vertex_index_bytes(self):
         # vertices 24 B, indices 4 B: from the leaf-triangle counts (3 indices per triangle); vertex counts from the importer
-        nt = (self.context.buffer_size(capi.BUF_BVH_TRIS0) + self.context.buffer_size(capi.BUF_BVH_TRIS1)) // 48
+        nt = (self.context.buffer_size(capi.BUF_BVH_TRIS0) + self.context.buffer_size(capi.BUF_BVH_TRIS1)) // 64
         return 12 * nt + 24 * (24 + self._model_vertices())
 
     def _model_vertices(self):
         if not hasattr(self, "_nv"):
-            self._nv = int(np.unique(self.context.readback(capi.BUF_BVH_TRIS1).view(np.float32).reshape(-1, 12)[:, :9].reshape(-1, 3), axis=0).shape[0])
+            self._nv = int(np.unique(self.context.readback(capi.BUF_BVH_TRIS1).view(np.float32).reshape(-1, 16)[:, :9].reshape(-1, 3), axis=0).shape[0])
         return self._nv
 
     def last_timings(self):

@@ -1,0 +1,18 @@
+"""Manual probe: per-frame counters of a -DRT_TRACE_STATS build of librtggx
+(make -C raytracedggx_amd EXTRA=-DRT_TRACE_STATS after removing _build/trace.o)."""
+import sys
+sys.path.insert(0, __file__.rsplit("/tests/", 1)[0]); sys.path.insert(0, __file__.rsplit("/", 1)[0])
+import assets
+from raytracedggx_amd import app
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
+a = app.RayTracedGGX(["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", W, "-height", H])
+a.context.enable_timing(1)
+for f in range(3):
+    a.OnUpdate(); a.OnRender(); a.context.sync()
+    c = a.context.debug_counters(8).astype(float)
+    rays = a.context.ray_count()
+    waves = 256 * 4 * 4
+    print("frame %d rays %d  node steps/ray %.1f  leaf steps/ray %.2f  wave iterations %d (%.1f per wave, lane util %.2f)  refills %d (%.1f per wave)" % (
+        f, rays, c[0] / rays, c[1] / rays, c[2], c[2] / waves, (c[0] + c[1]) / max(c[2] * 64.0, 1), c[3], c[3] / waves))
+    print("   per wave (kcycles): lifetime %.0f (max %.0f)  refill %.0f  burst %.0f | cycles per iteration %.0f  cycles per refill %.0f | kernel %.3f ms" % (
+        c[4] / waves, c[7], c[5] / waves, c[6] / waves, c[6] * 1024 / max(c[2], 1), c[5] * 1024 / max(c[3], 1), a.context.timings()["ray_trace_kernel"]))
