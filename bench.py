@@ -58,7 +58,7 @@ def main():
 
     W, H = args.width, args.height
     r = StripRenderer(W, H, assets.path(args.mesh), assets.path("rnl_cross.dds"), rank=rank, world=world, device=local_rank,
-                      dist=dist if world > 1 else None)
+                      dist=dist if world > 1 else None, extra_args=("-sharedmem",))
     ctx = r.context
 
     def barrier():
@@ -101,7 +101,7 @@ def main():
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %s + rnl_cross env, %dx%d, 1spp GGX reflection + full denoise chain (refl H,V; diff H,V; temporal; tone map), "
+            "config": {"workload": "configs[1]: %s + rnl_cross env, %dx%d, 1spp GGX reflection + full denoise chain (refl H,V; diff H,V, shared-memory variant; temporal; tone map), "
                                    "all-metal default materials, dt=1/60" % (args.mesh, W, H),
                        "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "rayGenKernel", "achieved": None if achieved is None else round(achieved, 2),

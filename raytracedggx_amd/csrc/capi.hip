@@ -150,8 +150,6 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     RT_HIP(hipMalloc(&c->rayQueue, (size_t)c->numBinsMax * 128 * 64));
     RT_HIP(hipMalloc(&c->hitQueue, (size_t)c->numBinsMax * 128 * 16));
     RT_HIP(hipMalloc(&c->binCount, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCount, 0, (size_t)c->numBinsMax * 4));
-    RT_HIP(hipMalloc(&c->binHead, 64 * 32 * 4)); RT_HIP(hipMemset(c->binHead, 0, 64 * 32 * 4));
-    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)32 * c->numCUs * 8 * 256 * 4));   // 32 spill entries x (8 workgroups/CU x 256 lanes)
     RT_HIP(hipMalloc(&c->dEnvMipOffset, 16 * 4)); RT_HIP(hipMemset(c->dEnvMipOffset, 0, 16 * 4));
     RT_HIP(hipMalloc(&c->dummyRecord, 64)); RT_HIP(hipMemset(c->dummyRecord, 0, 64));
   }
@@ -186,7 +184,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->visDepth); hipFree(c->normal); hipFree(c->velocity);
   hipFree(c->rtRefl); hipFree(c->rtDiff); hipFree(c->backbuffer); hipFree(c->roughMetal); hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
-  hipFree(c->rayQueue); hipFree(c->hitQueue); hipFree(c->binCount); hipFree(c->binHead); hipFree(c->stackOverflow); hipFree(c->dummyRecord);
+  hipFree(c->rayQueue); hipFree(c->hitQueue); hipFree(c->binCount); hipFree(c->stackOverflow); hipFree(c->dummyRecord);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);

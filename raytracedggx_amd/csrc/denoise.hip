@@ -6,13 +6,16 @@
 //   PSToneMap.hlsl:13-41
 // Ping-pong as in SURVEY.md Appendix C: scratch = TSS[parity], history = TSS[!parity].
 //
-// Spatial passes: a workgroup owns a 64-pixel segment of a row (H) or a 64x4.. column block (V);
-// each texel of the segment plus its 16-texel aprons is unpacked ONCE into LDS as the floats the
-// 33-tap loop consumes (tone-mapped colour, normal*2-1, hit flag, roughness, depth), instead of
-// four packed fetches and their unpacking per tap as in the reference's direct path.  Reads are
-// row-coalesced 4/8-byte words; out-of-range texels are the zeros D3D returns.
-// Roofline: HBM by bytes (22-30 B/pixel/pass); measured, they are VALU-bound
-// (33 taps x ~40 flops + 4 transcendentals per covered pixel) -- see DESIGN.md.
+// Spatial passes, two variants as in the reference (Denoiser.cpp:375-405, key [V]):
+//   shared memory (use_shared_mem = 1): a workgroup stages its pixels plus the 16-texel aprons ONCE in LDS, already
+//     unpacked into the eight floats the 33-tap loop consumes (normal*2-1, depth, roughness, tone-mapped colour;
+//     structure-of-arrays, so that the lanes of a wave read consecutive words: conflict-free).  H pass: 64x4 pixels
+//     from a 96x4 tile (12 KB); V pass: 32x32 pixels, four per thread, from a 32x64 tile (64 KB).
+//   direct access (0): every tap fetches and unpacks its texel from global memory (L1/L2 hits).
+// Both evaluate the same weights: pow(x, 512) / pow(x, 32) as 9 / 5 squarings, and the Gaussian and depth
+// exponentials merged into one exp2 -- ~35 VALU instructions per tap instead of ~400 with libm calls.  The passes
+// are VALU-bound (33 taps per covered pixel); their HBM traffic (22-30 B/pixel/pass) is ~5% of the
+// time.  Out-of-range texels are the zeros D3D returns.
 #include "rtggx_context.h"
 
 namespace rt {
@@ -38,12 +41,6 @@ RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restr
 }
 RT_DEV f3 TM3(f3 c) { const float l = 1.0f + ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f); return mk3(c.x / l, c.y / l, c.z / l); }     // FilterCommon.hlsli:14-19
 RT_DEV f3 ITM3(f3 c) { const float l = 1.0f - ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f); return mk3(c.x / l, c.y / l, c.z / l); }    // :24-27
-RT_DEV float normalWeight(float ax, float ay, float az, const GTexel& g, float sigma) {   // :34-37
-  return powf(fmaxf((ax * g.nx + ay * g.ny) + az * g.nz, 0.0f), sigma);
-}
-RT_DEV float depthWeight(float dc, float d, float sigma) { return expf(-fabsf(dc - d) * dc * sigma); }   // :39-42
-RT_DEV float gaussianW(float r, int radius) { const float sigma = (float)(radius + 1) / 3.0f; const float a = r / sigma; return expf(-0.5f * a * a); }   // :59-71
-
 struct Targets {
   const uint32_t* normal; const uint16_t* roughMetal; const unsigned long long* visDepth; const uint32_t* velocity;
   const uint32_t* rtRefl; const uint32_t* rtDiff;
@@ -51,49 +48,35 @@ struct Targets {
   int W, H, rowBegin, rowEnd;
 };
 
-// mode 0: H_Refl  1: V_Refl  2: H_Diff  3: V_Diff
+#define RT_LOG2E 1.44269504088896341f
+
+// Weight of one tap (SpatialFilter.hlsli:57-75, FilterCommon.hlsli:34-42,59-71) given the centre's constants.
+//   reflection: [nw > 0] * Gaussian(i, blurRadius) * pow(max(N.Nc, 0), 512) * exp(-|dc - d| dc 4) * (1 - smoothstep(0, .5, |r - rc|))
+//   diffuse:    pow(max(N.Nc, 0), 32) * exp(-|dc - d| dc 4)
+// Texels that do not take part (nw = 0; diffuse: metal = 1) are staged with a zero normal: their weight is 0.
+struct Centre { float nx, ny, nz, depth, rough, gaussK /* -0.5 log2(e) / sigma^2 */, depthK /* dc 4 log2(e) */; };
+template <bool DIFFUSE>
+RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, float depth, float rough) {
+  float p = fmaxf((c.nx * nx + c.ny * ny) + c.nz * nz, 0.0f);
+  p *= p; p *= p; p *= p; p *= p; p *= p;                 // ^32
+  const float dd = fabsf(c.depth - depth) * c.depthK;
+  if (DIFFUSE) return p * __builtin_amdgcn_exp2f(-dd);
+  p *= p; p *= p; p *= p; p *= p;                          // ^512
+  const float e = __builtin_fmaf(c.gaussK, (float)(i * i), -dd);
+  const float t = saturatef(fabsf(rough - c.rough) * 2.0f);
+  return (p * __builtin_amdgcn_exp2f(e)) * (1.0f - t * t * (3.0f - 2.0f * t));
+}
+template <bool DIFFUSE>
+RT_DEV Centre makeCentre(float nx, float ny, float nz, float depth, float rough, int W, int H) {
+  Centre c; c.nx = nx; c.ny = ny; c.nz = nz; c.depth = depth; c.rough = rough;
+  const int br = DIFFUSE ? 0 : (int)clampf(0.1f * rough * (float)W, 0.0f, (float)H * 0.05f);   // FilterCommon.hlsli:49-52
+  const float sigma = (float)(br + 1) / 3.0f;
+  c.gaussK = (-0.5f * RT_LOG2E) / (sigma * sigma);
+  c.depthK = depth * (4.0f * RT_LOG2E);
+  return c;
+}
 template <int MODE>
-__global__ void __launch_bounds__(256) spatialKernel(Targets T) {
-  constexpr bool vertical = (MODE & 1) != 0;
-  constexpr bool diffuse = MODE >= 2;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= T.W || y >= T.rowEnd) return;
-  const size_t pix = (size_t)y * T.W + x;
-  const GTexel gc = loadG(T.normal, T.roughMetal, T.visDepth, x, y, T.W, T.H);
-  const bool skip = diffuse ? (gc.nw <= 0.0f || gc.metal >= 1.0f) : (gc.nw <= 0.0f);
-  if (skip) {
-    if (MODE == 1) { const f3 s = unpackR11G11B10F(T.rtRefl[pix]); T.fltRfl[pix] = packRGBA16F(s.x, s.y, s.z, 0.0f); }
-    if (MODE == 3) T.fltDff[pix] = T.fltRfl[pix];
-    return;
-  }
-  const int br = diffuse ? 0 : (int)clampf(0.1f * gc.rough * (float)T.W, 0.0f, (float)T.H * 0.05f);   // FilterCommon.hlsli:49-52
-  float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
-  for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
-    const int tx = vertical ? x : x + i, ty = vertical ? y + i : y;
-    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);
-    if (diffuse && (g.nw <= 0.0f || g.metal >= 1.0f)) continue;
-    const bool inside = tx >= 0 && ty >= 0 && tx < T.W && ty < T.H;
-    f3 src = mk3(0.0f, 0.0f, 0.0f);
-    if (inside) {
-      const size_t ti = (size_t)ty * T.W + tx;
-      if (vertical) { const f4 v = unpackRGBA16F(T.scratch[ti]); src = mk3(v.x, v.y, v.z); }
-      else src = TM3(unpackR11G11B10F(diffuse ? T.rtDiff[ti] : T.rtRefl[ti]));
-    }
-    float w;
-    if (!diffuse) {   // ReflectionWeight, SpatialFilter.hlsli:57-67
-      w = g.nw > 0.0f ? 1.0f : 0.0f;
-      w *= gaussianW(vertical ? (float)i : (float)abs(i), br);
-      w *= normalWeight(gc.nx, gc.ny, gc.nz, g, 512.0f);
-      w *= depthWeight(gc.depth, g.depth, 4.0f);
-      w *= 1.0f - smoothstepf(0.0f, 0.5f, fabsf(g.rough - gc.rough));
-    } else {          // DiffuseWeight, SpatialFilter.hlsli:69-75
-      w = normalWeight(gc.nx, gc.ny, gc.nz, g, 32.0f);
-      w *= depthWeight(gc.depth, g.depth, 4.0f);
-    }
-    mx += src.x * w; my += src.y * w; mz += src.z * w;
-    wsum += w;
-  }
+RT_DEV void storeFiltered(const Targets& T, size_t pix, float mx, float my, float mz, float wsum) {
   f3 mu = mk3(mx / wsum, my / wsum, mz / wsum);
   if (MODE == 0 || MODE == 2) T.scratch[pix] = packRGBA16F(mu.x, mu.y, mu.z, 0.0f);
   if (MODE == 1) { mu = ITM3(mu); T.fltRfl[pix] = packRGBA16F(mu.x, mu.y, mu.z, 1.0f); }
@@ -101,6 +84,109 @@ __global__ void __launch_bounds__(256) spatialKernel(Targets T) {
     const f4 dest = unpackRGBA16F(T.fltRfl[pix]);
     mu = ITM3(mu);
     T.fltDff[pix] = packRGBA16F(dest.x + mu.x, dest.y + mu.y, dest.z + mu.z, dest.w);
+  }
+}
+// Pixels the pass does not filter (no surface; diffuse: pure metal) -- CSSpatial_V_Refl.hlsl:27-31, CSSpatial_V_Diff.hlsl:28-32
+template <int MODE>
+RT_DEV void storeSkipped(const Targets& T, size_t pix) {
+  if (MODE == 1) { const f3 s = unpackR11G11B10F(T.rtRefl[pix]); T.fltRfl[pix] = packRGBA16F(s.x, s.y, s.z, 0.0f); }
+  if (MODE == 3) T.fltDff[pix] = T.fltRfl[pix];
+}
+// Source colour of a tap: the ray-traced result tone-mapped (H passes) or the H pass's scratch (V passes).
+template <int MODE>
+RT_DEV f3 tapColour(const Targets& T, size_t ti) {
+  if (MODE & 1) { const f4 v = unpackRGBA16F(T.scratch[ti]); return mk3(v.x, v.y, v.z); }
+  return TM3(unpackR11G11B10F(MODE >= 2 ? T.rtDiff[ti] : T.rtRefl[ti]));
+}
+
+// mode 0: H_Refl  1: V_Refl  2: H_Diff  3: V_Diff -- direct-access variant
+template <int MODE>
+__global__ void __launch_bounds__(256) spatialDirectKernel(Targets T) {
+  constexpr bool vertical = (MODE & 1) != 0;
+  constexpr bool diffuse = MODE >= 2;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= T.W || y >= T.rowEnd) return;
+  const size_t pix = (size_t)y * T.W + x;
+  const GTexel gc = loadG(T.normal, T.roughMetal, T.visDepth, x, y, T.W, T.H);
+  if (diffuse ? (gc.nw <= 0.0f || gc.metal >= 1.0f) : (gc.nw <= 0.0f)) { storeSkipped<MODE>(T, pix); return; }
+  const Centre c = makeCentre<diffuse>(gc.nx, gc.ny, gc.nz, gc.depth, gc.rough, T.W, T.H);
+  float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
+  for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
+    const int tx = vertical ? x : x + i, ty = vertical ? y + i : y;
+    if (tx < 0 || ty < 0 || tx >= T.W || ty >= T.H) continue;       // zero texel: weight 0
+    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);
+    if (g.nw <= 0.0f || (diffuse && g.metal >= 1.0f)) continue;
+    const f3 src = tapColour<MODE>(T, (size_t)ty * T.W + tx);
+    const float w = tapWeight<diffuse>(c, i, g.nx, g.ny, g.nz, g.depth, g.rough);
+    mx = __builtin_fmaf(src.x, w, mx); my = __builtin_fmaf(src.y, w, my); mz = __builtin_fmaf(src.z, w, mz);
+    wsum += w;
+  }
+  storeFiltered<MODE>(T, pix, mx, my, mz, wsum);
+}
+
+// Shared-memory variant.  Block geometry: H passes 64x4 pixels (one per thread), tile 96x4; V passes 32x32 pixels
+// (thread (lx, ly) filters rows ly, ly+8, ly+16, ly+24 of column lx), tile 32x64.
+template <int MODE>
+__global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
+  constexpr bool vertical = (MODE & 1) != 0;
+  constexpr bool diffuse = MODE >= 2;
+  constexpr int BW = vertical ? 32 : 64, BH = vertical ? 32 : 4;      // pixels of the block
+  constexpr int TW = vertical ? 32 : 96, TH = vertical ? 64 : 4;      // texels of the tile
+  constexpr int PER = vertical ? 4 : 1, ROWSTEP = 256 / BW;           // pixels per thread, their row distance
+  constexpr int N = TW * TH;
+  __shared__ float sm[8][N];                                          // nx ny nz depth rough r g b
+  const int bx0 = blockIdx.x * BW, by0 = T.rowBegin + blockIdx.y * BH;
+  const int lx = threadIdx.x % BW, ly = threadIdx.x / BW;
+  const int x = bx0 + lx;
+
+  // which of my pixels are filtered at all; the others get their pass-through value now
+  bool todo[PER]; bool any = false;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int y = by0 + ly + k * ROWSTEP;
+    todo[k] = false;
+    if (x < T.W && y < T.rowEnd) {
+      const size_t pix = (size_t)y * T.W + x;
+      const bool skip = (T.normal[pix] >> 30) == 0u || (diffuse && (T.roughMetal[pix] >> 8) == 255u);
+      if (skip) storeSkipped<MODE>(T, pix); else { todo[k] = true; any = true; }
+    }
+  }
+  if (!__syncthreads_or(any ? 1 : 0)) return;
+
+  // stage the tile
+  const int ox = vertical ? bx0 : bx0 - RT_RADIUS, oy = vertical ? by0 - RT_RADIUS : by0;
+  for (int t = threadIdx.x; t < N; t += 256) {
+    const int tx = ox + t % TW, ty = oy + t / TW;
+    float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (tx >= 0 && ty >= 0 && tx < T.W && ty < T.H) {
+      const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);
+      v[3] = g.depth; v[4] = g.rough;
+      if (g.nw > 0.0f && !(diffuse && g.metal >= 1.0f)) {
+        const f3 src = tapColour<MODE>(T, (size_t)ty * T.W + tx);
+        v[0] = g.nx; v[1] = g.ny; v[2] = g.nz; v[5] = src.x; v[6] = src.y; v[7] = src.z;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sm[q][t] = v[q];
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (!todo[k]) continue;
+    const int y = by0 + ly + k * ROWSTEP;
+    const int ci = vertical ? (ly + k * ROWSTEP + RT_RADIUS) * TW + lx : ly * TW + lx + RT_RADIUS;
+    const Centre c = makeCentre<diffuse>(sm[0][ci], sm[1][ci], sm[2][ci], sm[3][ci], sm[4][ci], T.W, T.H);
+    float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
+#pragma unroll
+    for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
+      const int ti = ci + (vertical ? i * TW : i);
+      const float w = tapWeight<diffuse>(c, i, sm[0][ti], sm[1][ti], sm[2][ti], sm[3][ti], sm[4][ti]);
+      mx = __builtin_fmaf(sm[5][ti], w, mx); my = __builtin_fmaf(sm[6][ti], w, my); mz = __builtin_fmaf(sm[7][ti], w, mz);
+      wsum += w;
+    }
+    storeFiltered<MODE>(T, (size_t)y * T.W + x, mx, my, mz, wsum);
   }
 }
 
@@ -244,18 +330,24 @@ static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass
 }
 
 int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s) {
-  (void)useLds;
   c->frameParity ^= 1u;   // Denoiser.cpp:69
   if (fp.rowEnd <= fp.rowBegin) return 0;
   const Targets TH = makeTargets(c, fp, ROWS_GBUFFER), TV = makeTargets(c, fp, ROWS_VFILTER), TT = makeTargets(c, fp, ROWS_TEMPORAL);
   const dim3 block(256);
-  auto grid = [&](const Targets& T) { return dim3((fp.W + 63) / 64, (T.rowEnd - T.rowBegin + 3) / 4); };
+  auto grid = [&](const Targets& T, uint32_t bw, uint32_t bh) { return dim3((fp.W + bw - 1) / bw, (T.rowEnd - T.rowBegin + bh - 1) / bh); };
   auto mark = [&](int i) { if (c->timing) hipEventRecord(c->tev[i], s); };
-  hipLaunchKernelGGL(spatialKernel<0>, grid(TH), block, 0, s, TH); mark(4);
-  hipLaunchKernelGGL(spatialKernel<1>, grid(TV), block, 0, s, TV); mark(5);
-  hipLaunchKernelGGL(spatialKernel<2>, grid(TH), block, 0, s, TH); mark(6);
-  hipLaunchKernelGGL(spatialKernel<3>, grid(TV), block, 0, s, TV); mark(7);
-  hipLaunchKernelGGL(temporalKernel, grid(TT), block, 0, s, TT); mark(8);
+  if (useLds) {
+    hipLaunchKernelGGL(spatialTiledKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
+    hipLaunchKernelGGL(spatialTiledKernel<1>, grid(TV, 32, 32), block, 0, s, TV); mark(5);
+    hipLaunchKernelGGL(spatialTiledKernel<2>, grid(TH, 64, 4), block, 0, s, TH); mark(6);
+    hipLaunchKernelGGL(spatialTiledKernel<3>, grid(TV, 32, 32), block, 0, s, TV); mark(7);
+  } else {
+    hipLaunchKernelGGL(spatialDirectKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
+    hipLaunchKernelGGL(spatialDirectKernel<1>, grid(TV, 64, 4), block, 0, s, TV); mark(5);
+    hipLaunchKernelGGL(spatialDirectKernel<2>, grid(TH, 64, 4), block, 0, s, TH); mark(6);
+    hipLaunchKernelGGL(spatialDirectKernel<3>, grid(TV, 64, 4), block, 0, s, TV); mark(7);
+  }
+  hipLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, TT); mark(8);
   RT_HIP(hipGetLastError());
   return 0;
 }

@@ -145,6 +145,15 @@ __global__ void fitKernel(int n, const uint32_t* __restrict__ order, const float
   }
 }
 
+// Leaf depth = number of ancestors = the most stack entries a traversal reaching that leaf can hold.
+__global__ void depthKernel(int n, const int32_t* __restrict__ nodeParent, const int32_t* __restrict__ leafParent, uint32_t* __restrict__ maxDepth) {
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t d = 0;
+  if (leaf < n) for (int cur = leafParent[leaf]; cur >= 0; cur = nodeParent[cur]) ++d;
+  for (int o = 32; o > 0; o >>= 1) d = max(d, (uint32_t)__shfl_down((int)d, o));
+  if ((threadIdx.x & 63) == 0 && d) atomicMax(maxDepth, d);
+}
+
 __global__ void emitNodes(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
                           const int32_t* __restrict__ right, const float* __restrict__ nodeBox, BvhNode* __restrict__ nodes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,7 +186,7 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   const uint32_t n = m.numTris;
   if (m.nodes) { RT_HIP(hipFree(m.nodes)); m.nodes = nullptr; }
   if (m.tris) { RT_HIP(hipFree(m.tris)); m.tris = nullptr; }
-  m.root = -1;
+  m.root = -1; m.depth = 0;
   if (n == 0) return 0;
   RT_HIP(hipMalloc(&m.tris, sizeof(BvhTri) * (size_t)n));
   RT_HIP(hipMalloc(&m.nodes, sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)));
@@ -194,8 +203,8 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   RT_HIP(hipMalloc(&triBox, 4 * 6 * (size_t)n)); RT_HIP(hipMalloc(&nodeBox, 4 * 6 * (size_t)n));
   RT_HIP(hipMalloc(&left, 4 * (size_t)n)); RT_HIP(hipMalloc(&right, 4 * (size_t)n));
   RT_HIP(hipMalloc(&nodeParent, 4 * (size_t)n)); RT_HIP(hipMalloc(&leafParent, 4 * (size_t)n));
-  RT_HIP(hipMalloc(&arrive, 4 * (size_t)n));
-  RT_HIP(hipMemsetAsync(arrive, 0, 4 * (size_t)n, s));
+  RT_HIP(hipMalloc(&arrive, 4 * ((size_t)n + 1)));            // + 1: the depthKernel result
+  RT_HIP(hipMemsetAsync(arrive, 0, 4 * ((size_t)n + 1), s));
 
   hipLaunchKernelGGL(mortonKernel, dim3(nb), dim3(256), 0, s, m.verts, m.indices, n, bmin, invExt, codes[0], order[0], triBox);
   int cur = 0;
@@ -212,9 +221,11 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
     hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, s, codes[cur], (int)n, left, right, nodeParent, leafParent);
     hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, leafParent, nodeBox, arrive);
     hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeBox, m.nodes);
+    hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, s, (int)n, nodeParent, leafParent, arrive + n);
     m.root = 0;
   }
   RT_HIP(hipGetLastError());
+  RT_HIP(hipMemcpyAsync(&m.depth, arrive + n, 4, hipMemcpyDeviceToHost, s));
   RT_HIP(hipStreamSynchronize(s));
   hipFree(codes[0]); hipFree(codes[1]); hipFree(order[0]); hipFree(order[1]); hipFree(hist); hipFree(triBox); hipFree(nodeBox);
   hipFree(left); hipFree(right); hipFree(nodeParent); hipFree(leafParent); hipFree(arrive);

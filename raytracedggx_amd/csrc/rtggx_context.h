@@ -6,7 +6,7 @@
 //   normal     u32   R10G10B10A2_UNORM      roughMetal u16 R8G8_UNORM     velocity u32 R16G16_FLOAT
 //   rtRefl/rtDiff u32 R11G11B10_FLOAT       tss[2], fltRfl, fltDff u64 R16G16B16A16_FLOAT
 //   backbuffer u32   R8G8B8A8_UNORM
-// Scene: per mesh 24-byte vertices, u32 indices, 64-byte BVH nodes, 48-byte leaf triangles;
+// Scene: per mesh 24-byte vertices, u32 indices, 64-byte BVH nodes, 64-byte leaf triangles;
 // environment as RGBA16F mip-major (6 faces per mip); 9 float3 SH coefficients.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -24,6 +24,7 @@ struct MeshDev {
   BvhNode* nodes = nullptr;      // numTris - 1 (0 when numTris == 1)
   BvhTri* tris = nullptr;        // numTris, leaf (Morton) order
   int32_t root = -1;             // 0, or ~0 for a single-triangle mesh
+  uint32_t depth = 0;            // deepest leaf (number of ancestors): bounds the traversal stack
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // vertex bounds (Morton normalisation box)
 };
 
@@ -84,9 +85,9 @@ struct rtggx_context {
   void* rayQueue = nullptr;
   void* hitQueue = nullptr;
   uint32_t* binCount = nullptr;         // rays in each bin
-  uint32_t* binHead = nullptr;          // 64 list heads, 128 bytes apart (trace.hip)
   uint32_t numBinsMax = 0;
-  int32_t* stackOverflow = nullptr;     // traversal-stack spill area (entries beyond the LDS stack)
+  int32_t* stackOverflow = nullptr;     // traversal-stack spill area (entries beyond the LDS stack), sized from
+  uint32_t spillEntries = 0;            // the depth of the built trees: [spillEntries][numBinsMax * 128] words
   void* dummyRecord = nullptr;          // 64 zero bytes: record base for meshes without nodes / absent meshes
   uint32_t* dEnvMipOffset = nullptr;    // device copy of env.mipOffset
   uint32_t numCUs = 256;

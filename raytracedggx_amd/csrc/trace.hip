@@ -1,27 +1,31 @@
-// Kernel 2 of the ray-tracing pass: TraceRay (RayTracedGGX/Content/Shaders/RayTracing.hlsl:183-198) as
-// persistent wavefronts over the ray bins filled by rayGenKernel (raytrace.hip, rt_queue.h).
+// Kernel 2 of the ray-tracing pass: TraceRay (RayTracedGGX/Content/Shaders/RayTracing.hlsl:183-198) over the ray
+// bins filled by rayGenKernel (raytrace.hip, rt_queue.h).
 //
-// One lane = one ray.  Every traversal step is a DEPENDENT random 64-byte fetch (a BVH node with both child
-// boxes, or a leaf triangle), so the kernel is bound by the latency of those fetches, not by arithmetic or
-// bandwidth (tools/microbench/gather.hip, profiles/r01_*).  Design rules that follow from the measurements:
+// One lane = one ray, one wave = one bin: the (usually <= 64) rays of one 8x8 pixel sub-tile, which
+// start next to each other and mostly walk the same nodes.  Every traversal step is a DEPENDENT random 64-byte
+// fetch (a BVH node with both child boxes, or a leaf triangle), so the kernel is bound by the latency of those
+// fetches, not by arithmetic or bandwidth (tools/microbench/gather.hip, profiles/r01_*).  What the measurements
+// settled:
 //   * exactly ONE round trip to memory per step: the record of a lane -- node or triangle -- is fetched in one
 //     phase and pinned in registers before the type branch (hipcc otherwise narrows the loads per use and sinks
 //     them behind the branch: three round trips per step);
-//   * no atomics: the bins a wave drains are fixed by its index (bins b, b+B, b+2B, ... of the workgroup's
-//     residue class, interleaved over the screen for balance), their ray counts are fetched once at start;
-//   * idle lanes are refilled together (>= 24 idle, found with __ballot) so that the refill's own fetch latency
-//     is paid once per group of rays, not once per ray;
-//   * the world-space ray stays in registers: switching from the ground instance to the model costs no fetch.
-// Per-lane traversal stack in LDS ([entry][lane] layout: conflict-free ds_read/ds_write_b32), 16 entries,
-// deeper pushes spill to global memory.  Semantics (DESIGN.md "Traversal"): two-level, rays carried into each
+//   * no persistence, no work queue: the rays of this workload are short (~16 node visits and ~1.5 triangle tests
+//     each) and there are only ~2 of them per resident lane, so a persistent kernel that re-deals rays to idle
+//     lanes spent more on dealing (atomics on list heads, refill fetches, tail imbalance) than it saved: 0.55 ms
+//     against 0.22 ms for this kernel on the 1080p bunny frame (profiles/r01_c).  The hardware dispatcher balances
+//     the ~10^4 short-lived waves over the CUs;
+//   * the world-space ray stays in registers as two object-space rays: switching from the ground instance to the
+//     model costs no fetch.
+// Per-lane traversal stack in LDS ([entry][lane] layout: conflict-free ds_read/ds_write_b32), RT_STACK entries,
+// deeper pushes spill to global memory (launchTrace sizes the spill area from the depth of the built trees; the
+// bunny and dragon trees never need it).  Semantics (DESIGN.md "Traversal"): two-level, rays carried into each
 // instance's object space, nearer child first, watertight ray/triangle test (Woop, Benthin, Wald 2013), no
 // culling, TMin < t < TMax, ties to the lower (instance, primitive).
 #include "rt_queue.h"
 
 namespace rt {
 
-#define RT_STACK 16          // LDS stack entries per lane
-#define RT_BLOCKS_PER_CU 4u  // 4 workgroups of 4 waves per CU (~106 VGPRs: 4 waves per SIMD)
+#define RT_STACK 16          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: 12)
 
 struct TraceArgs {
   const float4* nodes0; const float4* tris0;   // 64-byte records: 4 x float4 each
@@ -30,10 +34,10 @@ struct TraceArgs {
   uint32_t haveMesh0, haveMesh1;
   const RayRec* rays; HitRec* hits;
   const uint32_t* binCount; uint32_t numBins;
-  uint32_t* binHead; uint32_t numGroups;   // head word of list g at binHead[g * 32] (128 bytes apart)
-  int32_t* overflow;        // [entry][gridDim*256] spill area for stacks deeper than RT_STACK
+  int32_t* overflow;        // [entry][numBinsMax * RT_BIN] spill area for stacks deeper than RT_STACK
   uint32_t* rayTotals;       // 256 per-frame partial counters (+ RT_TRACE_STATS words from 256)
   uint32_t countRowBegin, countRowEnd, width;
+  size_t spillStride;
 };
 
 struct LaneRay {
@@ -95,194 +99,127 @@ RT_DEV void slabTest(const LaneRay& r, float mnx, float mny, float mnz, float mx
   tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), tmax));
 }
 
-__global__ void __launch_bounds__(256, 4) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
+// Wave w of the grid traces the rays of bin w, 64 at a time (a second round only where a sub-tile has more than 64
+// rays, i.e. diffuse rays besides the reflection rays).
+__global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
   __shared__ int32_t stackMem[RT_STACK * 256];
   const FrameParams& fp = *fpp;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  int32_t* const stack = stackMem + wave * (RT_STACK * 64) + lane;               // entry e at stack[e * 64]
-  int32_t* const spill = A.overflow + (size_t)blockIdx.x * 256 + threadIdx.x;      // entry e at spill[e * spillStride]
-  const size_t spillStride = (size_t)gridDim.x * 256;
-
-  // Work distribution.  The bins are split into numGroups interleaved lists: list g holds the four bins of the
-  // rayGen tiles g, g + numGroups, g + 2 numGroups, ... (a sample of the whole screen).  A wave takes CHUNKS of 8
-  // consecutive list entries with one returning atomic on the list's head word; the head words sit 128 bytes apart
-  // and each is shared by gridDim/numGroups workgroups only, so they are never a hot spot (a single shared head
-  // serialised at ~11 ns per atomic at the memory side and tripled the kernel time).  A wave whose home list is
-  // drained steals from the following lists.
-  const uint32_t numTiles = A.numBins / 4u;
-  uint32_t group = blockIdx.x % A.numGroups, groupsTried = 0;
-  uint32_t chunkFirst = 0, laneCount = 0;            // lane j < 8 keeps the ray count of bin j of the current chunk
-  uint32_t m = 8, cursor = 0, curCount = 0;          // wave-uniform: bin of the chunk being dealt, rays of it already dealt
-  bool more = true;                                  // wave-uniform: undealt rays may exist somewhere
+  const uint32_t bin = blockIdx.x * 4u + wave;
+  if (bin >= A.numBins) return;
+  const uint32_t count = min(A.binCount[bin], RT_BIN);
+  if (count == 0u) return;
+  int32_t* const stack = stackMem + wave * (RT_STACK * 64) + lane;                      // entry e at stack[e * 64]
+  const size_t spillStride = A.spillStride;
+  int32_t* const spill = A.overflow + bin * RT_BIN + lane;                               // entry e at spill[e * spillStride]
   uint32_t nRays = 0;
-#define RT_GROUP_LEN(g) ((((numTiles) > (g) ? ((numTiles) - (g) + A.numGroups - 1u) / A.numGroups : 0u)) * 4u)
-#define RT_BIN_OF(g, i) ((((g) + ((i) >> 2) * A.numGroups) << 2) + ((i) & 3u))
-  // Make (m, cursor) point at an undealt ray, taking new chunks as needed; clears `more` when every list is drained.
-  auto advance = [&]() {
-    for (;;) {
-      if (m < 8u && cursor < curCount) return;
-      if (m < 8u) { ++m; cursor = 0; curCount = m < 8u ? (uint32_t)__shfl((int)laneCount, (int)m) : 0u; continue; }
-      if (!more) return;
-      const uint32_t len = RT_GROUP_LEN(group);
-      uint32_t i0 = 0;
-      if (lane == 0) i0 = atomicAdd(&A.binHead[group * 32u], 8u);
-      i0 = (uint32_t)__shfl((int)i0, 0);
-      if (i0 < len) {
-        chunkFirst = i0;
-        laneCount = (lane < 8u && i0 + lane < len) ? min(A.binCount[RT_BIN_OF(group, i0 + lane)], RT_BIN) : 0u;
-        m = 0; cursor = 0; curCount = (uint32_t)__shfl((int)laneCount, 0);
-      } else {
-        group = (group + 1u) % A.numGroups;
-        if (++groupsTried >= min(A.numGroups, 8u)) more = false;
-      }
-    }
-  };
 #ifdef RT_TRACE_STATS
-  uint32_t stNode = 0, stLeaf = 0, stIter = 0, stRefill = 0;
-  unsigned long long stT0 = clock64(), stTRefill = 0, stTBurst = 0, stMark = 0;
+  uint32_t stNode = 0, stLeaf = 0, stIter = 0, stDeep = 0;
 #endif
+  for (uint32_t base = 0; base < count; base += 64u) {
+  const uint32_t slot = bin * RT_BIN + base + lane;
+  bool active = base + lane < count;
 
-  bool active = false;
-  LaneRay r; r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.Sx = r.Sy = r.Sz = 0.0f; r.kx = r.ky = r.kz = 0;
-  LaneRay r1 = r;                                   // the ray in the model instance's object space
-  float tmin = 0.0f, bestT = 0.0f, bestB1 = 0.0f, bestB2 = 0.0f;
-  uint32_t bestId = 0xFFFFFFFFu, skip = 0xFFFFFFFFu, inst = 0, slot = 0;
-  int32_t cur = 0; int sp = 0;
-
-  for (;;) {
-    // ---- refill idle lanes together ------------------------------------------------------------------------
-    const unsigned long long idleMask = __ballot(!active);
-    const uint32_t nIdle = (uint32_t)__popcll(idleMask);
-    if (nIdle >= 24u && more) advance();                // only look for work when it can be used
-    const bool raysLeft = m < 8u && cursor < curCount;
-    if (nIdle == 64u && !raysLeft) { if (!more) break; continue; }
-    if (raysLeft && nIdle >= 24u) {
-#ifdef RT_TRACE_STATS
-      stMark = clock64(); ++stRefill;
-#endif
-      // deal rays to the idle lanes in lane order; a refill may span several bins
-      uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));   // my position among the idle lanes
-      uint32_t dealt = 0; bool got = false; uint32_t mySlot = 0;
-      while (dealt < nIdle && m < 8u && cursor < curCount) {
-        const uint32_t take = min(nIdle - dealt, curCount - cursor);
-        if (!active && !got && rank >= dealt && rank < dealt + take) { got = true; mySlot = RT_BIN_OF(group, chunkFirst + m) * RT_BIN + cursor + (rank - dealt); }
-        dealt += take; cursor += take;
-        if (dealt < nIdle) advance();
-      }
-      if (got) {
-        slot = mySlot;
-        const float4* rp = reinterpret_cast<const float4*>(A.rays + slot);
-        const float4 ra = rp[0], rb = rp[1];
-        const uint4 rc = reinterpret_cast<const uint4*>(A.rays + slot)[2];
-        const float wox = ra.x, woy = ra.y, woz = ra.z, wdx = rb.x, wdy = rb.y, wdz = rb.z;   // world-space ray
-        tmin = ra.w; bestT = rb.w; bestId = 0xFFFFFFFFu; bestB1 = 0.0f; bestB2 = 0.0f; skip = rc.y;
-        const uint32_t row = rc.x / A.width;
-        if (row >= A.countRowBegin && row < A.countRowEnd) ++nRays;
-        inst = A.haveMesh0 ? 0u : 1u;
-        // both object-space rays are prepared here, where every refilled lane does the same work; inside the
-        // traversal loop the switch to the model instance is then a register copy, not 150 divergent instructions
-        r1 = toObject(wox, woy, woz, wdx, wdy, wdz, fp.invWorld[1]);
-        r = inst ? r1 : toObject(wox, woy, woz, wdx, wdy, wdz, fp.invWorld[0]);
-        cur = inst ? A.root1 : A.root0; sp = 0;
-        active = (inst == 0u) || (A.haveMesh1 != 0u);
-        if (!(bestT > tmin)) active = false;   // degenerate interval: never queued by rayGenKernel, but honoured
-        if (!active) { HitRec h; h.t = bestT; h.b1 = 0.0f; h.b2 = 0.0f; h.id = 0xFFFFFFFFu; A.hits[slot] = h; }
-      }
-#ifdef RT_TRACE_STATS
-      stTRefill += clock64() - stMark;
-#endif
-      continue;
-    }
-
-    // ---- a burst of traversal steps ---------------------------------------------------------------------------
-#ifdef RT_TRACE_STATS
-    stMark = clock64();
-#endif
-#pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-#ifdef RT_TRACE_STATS
-      ++stIter; if (active) { if (cur < 0) ++stLeaf; else ++stNode; }
-#endif
-      if (active) {
-        bool needPop = false;
-        // ONE fetch phase per step: the 64-byte record of this lane, node or leaf triangle alike
-        const bool leaf = cur < 0;
-        const float4* rec = leaf ? (inst ? A.tris1 : A.tris0) + (size_t)(~cur) * 4 : (inst ? A.nodes1 : A.nodes0) + (size_t)cur * 4;
-        float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-        // pin all the words here: without it hipcc narrows the loads per use and sinks some of them behind the type
-        // branch, turning one round trip to memory into three (profiles/r01_c)
-        asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w));
-        asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y));
-        const int32_t w12 = __float_as_int(n3.x);             // node: left child; triangle: primitive id
-        if (!leaf) {
-          // n0 = lmin.xyz lmax.x | n1 = lmax.yz rmin.xy | n2 = rmin.z rmax.xyz | n3 = left right pad pad
-          float ln, lf, rn, rf;
-          slabTest(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, bestT, ln, lf);
-          slabTest(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, bestT, rn, rf);
-          const bool hl = ln <= lf * 1.0000004f, hr = rn <= rf * 1.0000004f;
-          const int32_t left = w12, right = __float_as_int(n3.y);
-          if (hl && hr) {
-            const bool leftFirst = ln <= rn;
-            const int32_t far = leftFirst ? right : left;
-            if (sp < RT_STACK) stack[sp * 64] = far; else spill[(size_t)(sp - RT_STACK) * spillStride] = far;
-            ++sp;
-            cur = leftFirst ? left : right;
-          } else if (hl) cur = left;
-          else if (hr) cur = right;
-          else needPop = true;
-        } else {
-          // n0 = v0.xyz v1.x | n1 = v1.yz v2.xy | n2 = v2.z pad pad pad | n3 = prim pad pad pad
-          const uint32_t id = (inst << 24) | (uint32_t)w12;
-          if (id != skip) {
-            float t, b1, b2;
-            if (woopTest(r, n0, n1, n2, t, b1, b2) && t > tmin) {
-              const bool closer = t < bestT;
-              const bool tie = bestId != 0xFFFFFFFFu && t == bestT && id < bestId;
-              if (closer || tie) { bestT = t; bestId = id; bestB1 = b1; bestB2 = b2; }
-            }
-          }
-          needPop = true;
-        }
-        if (needPop) {
-          if (sp > 0) {
-            --sp;
-            if (sp < RT_STACK) cur = stack[sp * 64]; else cur = spill[(size_t)(sp - RT_STACK) * spillStride];
-          } else if (inst == 0u && A.haveMesh1 != 0u) {
-            inst = 1u;                                         // ground done: continue in the model's object space
-            r = r1;
-            cur = A.root1;
-          } else {
-            HitRec h; h.t = bestT; h.b1 = bestB1; h.b2 = bestB2; h.id = bestId;
-            A.hits[slot] = h;
-            active = false;
-          }
-        }
-      }
-      if ((it & 3) == 3) {
-        const uint32_t idle = (uint32_t)__popcll(__ballot(!active));
-        if (idle == 64u || (idle >= 32u && more)) break;   // go refill (or finish)
-      }
-    }
-#ifdef RT_TRACE_STATS
-    stTBurst += clock64() - stMark;
-#endif
+  // ---- the ray: world space -> the object spaces of both instances --------------------------------------------
+  const float4* rp = reinterpret_cast<const float4*>(A.rays + (active ? slot : bin * RT_BIN));
+  const float4 ra = rp[0], rb = rp[1];
+  const uint4 rc = reinterpret_cast<const uint4*>(rp)[2];
+  const float tmin = ra.w;
+  float bestT = rb.w, bestB1 = 0.0f, bestB2 = 0.0f;
+  uint32_t bestId = 0xFFFFFFFFu;
+  const uint32_t skip = rc.y;
+  uint32_t inst = A.haveMesh0 ? 0u : 1u;
+  const LaneRay r1 = toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[1]);
+  LaneRay r = inst ? r1 : toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[0]);
+  int32_t cur = inst ? A.root1 : A.root0;
+  int sp = 0;
+  {
+    const uint32_t row = rc.x / A.width;
+    if (active && row >= A.countRowBegin && row < A.countRowEnd) ++nRays;
   }
+  if (active && (!(bestT > tmin) || (inst == 1u && A.haveMesh1 == 0u))) {   // degenerate interval / empty scene: a miss
+    HitRec h; h.t = bestT; h.b1 = 0.0f; h.b2 = 0.0f; h.id = 0xFFFFFFFFu; A.hits[slot] = h;
+    active = false;
+  }
+
+  // ---- traversal -----------------------------------------------------------------------------------------------
+  while (__ballot(active)) {
+#ifdef RT_TRACE_STATS
+    ++stIter; if (active) { if (cur < 0) ++stLeaf; else ++stNode; }
+#endif
+    if (active) {
+      bool needPop = false;
+      // ONE fetch phase per step: the 64-byte record of this lane, node or leaf triangle alike
+      const bool leaf = cur < 0;
+      const float4* rec = leaf ? (inst ? A.tris1 : A.tris0) + (size_t)(~cur) * 4 : (inst ? A.nodes1 : A.nodes0) + (size_t)cur * 4;
+      float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+      asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w));
+      asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y));
+      const int32_t w12 = __float_as_int(n3.x);             // node: left child; triangle: primitive id
+      if (!leaf) {
+        // n0 = lmin.xyz lmax.x | n1 = lmax.yz rmin.xy | n2 = rmin.z rmax.xyz | n3 = left right pad pad
+        float ln, lf, rn, rf;
+        slabTest(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, bestT, ln, lf);
+        slabTest(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, bestT, rn, rf);
+        const bool hl = ln <= lf * 1.0000004f, hr = rn <= rf * 1.0000004f;
+        const int32_t left = w12, right = __float_as_int(n3.y);
+        if (hl && hr) {
+          const bool leftFirst = ln <= rn;
+          const int32_t far = leftFirst ? right : left;
+          if (sp < RT_STACK) stack[sp * 64] = far; else spill[(size_t)(sp - RT_STACK) * spillStride] = far;
+          ++sp;
+#ifdef RT_TRACE_STATS
+          if ((uint32_t)sp > stDeep) stDeep = (uint32_t)sp;
+#endif
+          cur = leftFirst ? left : right;
+        } else if (hl) cur = left;
+        else if (hr) cur = right;
+        else needPop = true;
+      } else {
+        // n0 = v0.xyz v1.x | n1 = v1.yz v2.xy | n2 = v2.z pad pad pad | n3 = prim pad pad pad
+        const uint32_t id = (inst << 24) | (uint32_t)w12;
+        if (id != skip) {
+          float t, b1, b2;
+          if (woopTest(r, n0, n1, n2, t, b1, b2) && t > tmin) {
+            const bool closer = t < bestT;
+            const bool tie = bestId != 0xFFFFFFFFu && t == bestT && id < bestId;
+            if (closer || tie) { bestT = t; bestId = id; bestB1 = b1; bestB2 = b2; }
+          }
+        }
+        needPop = true;
+      }
+      if (needPop) {
+        if (sp > 0) {
+          --sp;
+          if (sp < RT_STACK) cur = stack[sp * 64]; else cur = spill[(size_t)(sp - RT_STACK) * spillStride];
+        } else if (inst == 0u && A.haveMesh1 != 0u) {
+          inst = 1u; r = r1; cur = A.root1;                  // ground done: continue in the model's object space
+        } else {
+          HitRec h; h.t = bestT; h.b1 = bestB1; h.b2 = bestB2; h.id = bestId;
+          A.hits[slot] = h;
+          active = false;
+        }
+      }
+    }
+  }
+  }   // base
+
   // ray statistics: one fire-and-forget atomic per wave, spread over 256 words
   for (int o = 32; o > 0; o >>= 1) nRays += __shfl_down(nRays, o);
-  if (lane == 0 && nRays) atomicAdd(&A.rayTotals[(blockIdx.x * 4u + wave) & 255u], nRays);
+  if (lane == 0 && nRays) atomicAdd(&A.rayTotals[bin & 255u], nRays);
 #ifdef RT_TRACE_STATS
-  for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); }
-  if (lane == 0) {
-    atomicAdd(&A.rayTotals[256], stNode); atomicAdd(&A.rayTotals[257], stLeaf); atomicAdd(&A.rayTotals[258], stIter); atomicAdd(&A.rayTotals[259], stRefill);
-    // wave lifetime / time in refill sections / time in traversal bursts, in units of 1024 shader cycles
-    atomicAdd(&A.rayTotals[260], (uint32_t)((clock64() - stT0) >> 10)); atomicAdd(&A.rayTotals[261], (uint32_t)(stTRefill >> 10)); atomicAdd(&A.rayTotals[262], (uint32_t)(stTBurst >> 10));
-    atomicMax(&A.rayTotals[263], (uint32_t)((clock64() - stT0) >> 10));
+  for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); stDeep = max(stDeep, (uint32_t)__shfl_down((int)stDeep, o)); }
+  if (lane == 0) {   // lane node steps, lane leaf steps, wave iterations, waves, deepest stack
+    atomicAdd(&A.rayTotals[256], stNode); atomicAdd(&A.rayTotals[257], stLeaf); atomicAdd(&A.rayTotals[258], stIter);
+    atomicAdd(&A.rayTotals[259], 1u); atomicMax(&A.rayTotals[260], stDeep);
   }
 #endif
 }
 
 int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays) {
   TraceArgs T;
+  if (numBins == 0) return 0;
+  if (numBins > c->numBinsMax) { setError("launchTrace: %u bins exceed the %u allocated", numBins, c->numBinsMax); return -1; }
   const bool have0 = c->mesh[0].tris != nullptr, have1 = c->mesh[1].tris != nullptr;
   // a mesh with one triangle has no internal nodes; an absent mesh has nothing: point those bases at the dummy record
   T.nodes0 = (const float4*)(have0 && c->mesh[0].nodes ? (const void*)c->mesh[0].nodes : c->dummyRecord);
@@ -292,12 +229,18 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.root0 = c->mesh[0].root; T.root1 = c->mesh[1].root; T.haveMesh0 = have0; T.haveMesh1 = have1;
   T.rays = (const RayRec*)c->rayQueue; T.hits = (HitRec*)c->hitQueue;
   T.binCount = c->binCount; T.numBins = numBins;
+  // stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get
+  const uint32_t deepest = c->mesh[0].depth > c->mesh[1].depth ? c->mesh[0].depth : c->mesh[1].depth;
+  if (deepest > RT_STACK + c->spillEntries) {
+    RT_HIP(hipStreamSynchronize(s));
+    if (c->stackOverflow) { RT_HIP(hipFree(c->stackOverflow)); c->stackOverflow = nullptr; }
+    c->spillEntries = deepest - RT_STACK;
+    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)c->spillEntries * c->numBinsMax * RT_BIN * 4));
+  }
   T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32;
+  T.spillStride = (size_t)c->numBinsMax * RT_BIN;
   T.countRowBegin = countRays ? fp.rowBegin : 0u; T.countRowEnd = countRays ? fp.rowEnd : 0u; T.width = fp.W;
-  const uint32_t grid = c->numCUs * RT_BLOCKS_PER_CU;   // persistent grid
-  T.binHead = c->binHead; T.numGroups = 64u;             // 64 lists: 16 workgroups share a head word
-  RT_HIP(hipMemsetAsync(c->binHead, 0, 64 * 32 * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(traceKernel, dim3(grid), dim3(256), 0, s, c->dParams + c->slot, T);
+  hipLaunchKernelGGL(traceKernel, dim3((numBins + 3u) / 4u), dim3(256), 0, s, c->dParams + c->slot, T);
   RT_HIP(hipGetLastError());
   return 0;
 }

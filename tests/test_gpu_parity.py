@@ -21,13 +21,15 @@ def rel_l2(a, b):
 class Pair:
     """The product's RayTracedGGX application object and an oracle on the same scene."""
 
-    def __init__(self, W, H, mesh="bunny.obj", metallic=None, pos_scale=None, env_const=None):
+    def __init__(self, W, H, mesh="bunny.obj", metallic=None, pos_scale=None, env_const=None, shared_mem=False):
         from raytracedggx_amd import app, capi
         self.capi = capi
         args = ["-mesh", assets.path(mesh)] + ([str(x) for x in pos_scale] if pos_scale else []) + \
                ["-env", assets.path("rnl_cross.dds"), "-width", W, "-height", H]
         if metallic is not None:
             args += ["-metallic", metallic[0], metallic[1]]
+        if shared_mem:
+            args += ["-sharedmem"]          # the [V] toggle of the sample: LDS-staged spatial filters
         self.app = app.RayTracedGGX(args)
         self.ctx = self.app.context
         self.o = O.Oracle(W, H)
@@ -96,8 +98,9 @@ def test_config_c1_single_triangle_constant_env(built):
         p.close()
 
 
-def test_bunny_three_frames(built):
-    p = Pair(640, 360)
+@pytest.mark.parametrize("shared_mem", [False, True], ids=["direct", "sharedmem"])
+def test_bunny_three_frames(built, shared_mem):
+    p = Pair(640, 360, shared_mem=shared_mem)
     try:
         np.testing.assert_array_equal(p.ctx.readback(p.capi.BUF_ENV), p.o.env_texels()[2])          # BC6H decode: bit-exact
         for f in range(3):
@@ -110,7 +113,7 @@ def test_bunny_three_frames(built):
 
 def test_dragon_diffuse_path(built):
     # metallic < 1 on both meshes: second ray per pixel, SH irradiance, both closest-hit groups (RayTracing.hlsl:559-564, 593-614)
-    p = Pair(480, 270, mesh="dragon.obj", metallic=(0.25, 0.5))
+    p = Pair(480, 270, mesh="dragon.obj", metallic=(0.25, 0.5), shared_mem=True)
     try:
         for f in range(2):
             p.frame(); p.check_frame("dragon metallic<1 frame %d" % f)
@@ -195,7 +198,8 @@ def test_lbvh_structure_and_device_traversal(built):
         p.close()
 
 
-def test_denoiser_in_isolation_on_uploaded_inputs(built):
+@pytest.mark.parametrize("shared_mem", [False, True], ids=["direct", "sharedmem"])
+def test_denoiser_in_isolation_on_uploaded_inputs(built, shared_mem):
     """Feed the oracle's G-buffer and raw ray-traced images to rtggx_denoise: isolates the filter chain."""
     from raytracedggx_amd import capi
     W, H = 384, 216
@@ -211,7 +215,7 @@ def test_denoiser_in_isolation_on_uploaded_inputs(built):
                          (capi.BUF_ROUGH_METAL, O.BUF_ROUGH_METAL), (capi.BUF_VELOCITY, O.BUF_VELOCITY), (capi.BUF_RT_REFL, O.BUF_RT_REFL),
                          (capi.BUF_RT_DIFF, O.BUF_RT_DIFF), (capi.BUF_TSS0, O.BUF_TSS0), (capi.BUF_TSS1, O.BUF_TSS1)):
             ctx.upload(gid, o.buffer(oid))
-        ctx.denoise(); ctx.tone_map(); ctx.sync()
+        ctx.denoise(shared_mem); ctx.tone_map(); ctx.sync()
         o.denoise(); o.tone_map()
         par = ctx.frame_parity()
         assert par == o.parity()
@@ -227,7 +231,7 @@ def test_full_size_1080p_properties(built):
     """BASELINE.json config 2 at full size: integer buffers against the oracle, determinism, strip independence."""
     from raytracedggx_amd import capi
     W, H = 1920, 1080
-    p = Pair(W, H)
+    p = Pair(W, H, shared_mem=True)
     try:
         p.frame()
         ctx, o = p.ctx, p.o

@@ -11,8 +11,6 @@ for f in range(3):
     a.OnUpdate(); a.OnRender(); a.context.sync()
     c = a.context.debug_counters(8).astype(float)
     rays = a.context.ray_count()
-    waves = 256 * 4 * 4
-    print("frame %d rays %d  node steps/ray %.1f  leaf steps/ray %.2f  wave iterations %d (%.1f per wave, lane util %.2f)  refills %d (%.1f per wave)" % (
-        f, rays, c[0] / rays, c[1] / rays, c[2], c[2] / waves, (c[0] + c[1]) / max(c[2] * 64.0, 1), c[3], c[3] / waves))
-    print("   per wave (kcycles): lifetime %.0f (max %.0f)  refill %.0f  burst %.0f | cycles per iteration %.0f  cycles per refill %.0f | kernel %.3f ms" % (
-        c[4] / waves, c[7], c[5] / waves, c[6] / waves, c[6] * 1024 / max(c[2], 1), c[5] * 1024 / max(c[3], 1), a.context.timings()["ray_trace_kernel"]))
+    waves = max(c[3], 1)
+    print("frame %d rays %d  node steps/ray %.1f  leaf steps/ray %.2f  wave iterations %d (%.1f per wave, lane utilisation %.2f)  waves %d  deepest stack %d  kernel %.3f ms" % (
+        f, rays, c[0] / rays, c[1] / rays, c[2], c[2] / waves, (c[0] + c[1]) / max(c[2] * 64.0, 1), c[3], c[4], a.context.timings()["ray_trace_kernel"]))
