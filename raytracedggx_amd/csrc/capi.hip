@@ -78,6 +78,7 @@ static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint
   if (m.verts) { hipFree(m.verts); m.verts = nullptr; }
   if (m.indices) { hipFree(m.indices); m.indices = nullptr; }
   if (m.nodes) { hipFree(m.nodes); m.nodes = nullptr; }
+  if (m.nodes4) { hipFree(m.nodes4); m.nodes4 = nullptr; }
   if (m.tris) { hipFree(m.tris); m.tris = nullptr; }
   m.root = -1; m.numVerts = nv; m.numIndices = ni; m.numTris = ni / 3;
   for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) { setError("rtggx_set_mesh: index %u out of range (%u vertices)", idx[i], nv); m.numVerts = m.numIndices = m.numTris = 0; return -1; }
@@ -151,7 +152,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     RT_HIP(hipMalloc(&c->hitQueue, (size_t)c->numBinsMax * 128 * 16));
     RT_HIP(hipMalloc(&c->binCount, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCount, 0, (size_t)c->numBinsMax * 4));
     RT_HIP(hipMalloc(&c->dEnvMipOffset, 16 * 4)); RT_HIP(hipMemset(c->dEnvMipOffset, 0, 16 * 4));
-    RT_HIP(hipMalloc(&c->dummyRecord, 64)); RT_HIP(hipMemset(c->dummyRecord, 0, 64));
+    RT_HIP(hipMalloc(&c->dummyRecord, 128)); RT_HIP(hipMemset(c->dummyRecord, 0, 128));
   }
   RT_HIP(hipMalloc(&c->sh, 27 * 4)); RT_HIP(hipMemset(c->sh, 0, 27 * 4));
   RT_HIP(hipMalloc(&c->cosSinTab, 512 * 4));
@@ -180,7 +181,7 @@ void rtggx_destroy(rtggx_context* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipDeviceSynchronize();
-  for (auto& m : c->mesh) { hipFree(m.verts); hipFree(m.indices); hipFree(m.nodes); hipFree(m.tris); }
+  for (auto& m : c->mesh) { hipFree(m.verts); hipFree(m.indices); hipFree(m.nodes); hipFree(m.nodes4); hipFree(m.tris); }
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->visDepth); hipFree(c->normal); hipFree(c->velocity);
   hipFree(c->rtRefl); hipFree(c->rtDiff); hipFree(c->backbuffer); hipFree(c->roughMetal); hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);

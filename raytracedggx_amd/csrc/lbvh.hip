@@ -166,6 +166,37 @@ __global__ void emitNodes(int n, const uint32_t* __restrict__ order, const float
   nd.left = l; nd.right = r; nd.pad[0] = 0; nd.pad[1] = 0;
   nodes[i] = nd;
 }
+// 4-wide collapse: every internal node of even depth becomes a Bvh4Node whose entries are its grandchildren (or
+// its children where those are leaves).  Boxes are the binary tree's own child boxes, so the set of triangles a
+// ray reaches can only grow relative to the binary traversal (one box test per two levels is skipped).
+__global__ void emitNodes4(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
+                           const int32_t* __restrict__ right, const int32_t* __restrict__ nodeParent, const float* __restrict__ nodeBox,
+                           Bvh4Node* __restrict__ nodes4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  int depth = 0;
+  for (int p = nodeParent[i]; p >= 0; p = nodeParent[p]) ++depth;
+  if (depth & 1) return;
+  int32_t refs[4]; int cnt = 0;
+  const int32_t ch[2] = {left[i], right[i]};
+  for (int s = 0; s < 2; ++s) {
+    if (ch[s] < 0) refs[cnt++] = ch[s];
+    else { refs[cnt++] = left[ch[s]]; refs[cnt++] = right[ch[s]]; }
+  }
+  Bvh4Node nd;
+  for (int k = 0; k < 4; ++k) {
+    if (k < cnt) {
+      const float* b = refs[k] < 0 ? &triBox[6 * (size_t)order[~refs[k]]] : &nodeBox[6 * (size_t)refs[k]];
+      nd.minx[k] = b[0]; nd.miny[k] = b[1]; nd.minz[k] = b[2]; nd.maxx[k] = b[3]; nd.maxy[k] = b[4]; nd.maxz[k] = b[5];
+      nd.ref[k] = refs[k];
+    } else {
+      nd.minx[k] = nd.miny[k] = nd.minz[k] = __builtin_inff(); nd.maxx[k] = nd.maxy[k] = nd.maxz[k] = -__builtin_inff();
+      nd.ref[k] = RT_BVH4_EMPTY;
+    }
+    nd.pad[k] = 0;
+  }
+  nodes4[i] = nd;
+}
 __global__ void emitTris(int n, const uint32_t* __restrict__ order, const float* __restrict__ verts, const uint32_t* __restrict__ idx, BvhTri* __restrict__ tris) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
@@ -186,10 +217,13 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   const uint32_t n = m.numTris;
   if (m.nodes) { RT_HIP(hipFree(m.nodes)); m.nodes = nullptr; }
   if (m.tris) { RT_HIP(hipFree(m.tris)); m.tris = nullptr; }
+  if (m.nodes4) { RT_HIP(hipFree(m.nodes4)); m.nodes4 = nullptr; }
   m.root = -1; m.depth = 0;
   if (n == 0) return 0;
   RT_HIP(hipMalloc(&m.tris, sizeof(BvhTri) * (size_t)n));
   RT_HIP(hipMalloc(&m.nodes, sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)));
+  RT_HIP(hipMalloc(&m.nodes4, sizeof(Bvh4Node) * (size_t)(n > 1 ? n - 1 : 1)));
+  RT_HIP(hipMemsetAsync(m.nodes4, 0, sizeof(Bvh4Node) * (size_t)(n > 1 ? n - 1 : 1), s));
 
   const float* mn = m.bmin; const float* mx = m.bmax;   // vertex bounds recorded by rtggx_set_mesh
   float3 bmin = make_float3(mn[0], mn[1], mn[2]);
@@ -221,6 +255,7 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
     hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, s, codes[cur], (int)n, left, right, nodeParent, leafParent);
     hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, leafParent, nodeBox, arrive);
     hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeBox, m.nodes);
+    hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, nodeBox, m.nodes4);
     hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, s, (int)n, nodeParent, leafParent, arrive + n);
     m.root = 0;
   }

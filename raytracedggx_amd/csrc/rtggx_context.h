@@ -21,7 +21,8 @@ struct MeshDev {
   float* verts = nullptr;        // 6 floats per vertex
   uint32_t* indices = nullptr;
   uint32_t numVerts = 0, numIndices = 0, numTris = 0;
-  BvhNode* nodes = nullptr;      // numTris - 1 (0 when numTris == 1)
+  BvhNode* nodes = nullptr;      // numTris - 1 (0 when numTris == 1): the binary LBVH as built
+  Bvh4Node* nodes4 = nullptr;    // same count, sparse: the 4-wide collapse the trace kernel walks
   BvhTri* tris = nullptr;        // numTris, leaf (Morton) order
   int32_t root = -1;             // 0, or ~0 for a single-triangle mesh
   uint32_t depth = 0;            // deepest leaf (number of ancestors): bounds the traversal stack
@@ -88,7 +89,7 @@ struct rtggx_context {
   uint32_t numBinsMax = 0;
   int32_t* stackOverflow = nullptr;     // traversal-stack spill area (entries beyond the LDS stack), sized from
   uint32_t spillEntries = 0;            // the depth of the built trees: [spillEntries][numBinsMax * 128] words
-  void* dummyRecord = nullptr;          // 64 zero bytes: record base for meshes without nodes / absent meshes
+  void* dummyRecord = nullptr;          // 128 zero bytes: record base for meshes without nodes / absent meshes
   uint32_t* dEnvMipOffset = nullptr;    // device copy of env.mipOffset
   uint32_t numCUs = 256;
 

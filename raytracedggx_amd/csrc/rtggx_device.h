@@ -157,6 +157,15 @@ struct BvhNode {           // 64 B, internal nodes only; node 0 is the root
   int32_t left, right;     // >= 0 internal node, < 0 leaf: ~ref = slot in the triangle array
   int32_t pad[2];
 };
+// The 4-wide node the trace kernel walks: binary node i of even depth with its internal children folded in (their
+// children become its own).  128 B = one L2/L1 cache line per traversal step.  Stored at index i of a sparse array
+// (odd-depth slots unused).
+#define RT_BVH4_EMPTY 0x7FFFFFFF
+struct Bvh4Node {
+  float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+  int32_t ref[4];          // >= 0: 4-wide node (= binary node index), < 0: leaf ~slot, RT_BVH4_EMPTY: unused entry
+  int32_t pad[4];
+};
 struct BvhTri {            // 64 B (same record size as a node: one cooperative 64-byte gather serves both)
   float v0[3], v1[3], v2[3];
   uint32_t pad0[3];

@@ -1,34 +1,36 @@
 // Kernel 2 of the ray-tracing pass: TraceRay (RayTracedGGX/Content/Shaders/RayTracing.hlsl:183-198) over the ray
 // bins filled by rayGenKernel (raytrace.hip, rt_queue.h).
 //
-// One lane = one ray, one wave = one bin: the (usually <= 64) rays of one 8x8 pixel sub-tile, which
-// start next to each other and mostly walk the same nodes.  Every traversal step is a DEPENDENT random 64-byte
-// fetch (a BVH node with both child boxes, or a leaf triangle), so the kernel is bound by the latency of those
-// fetches, not by arithmetic or bandwidth (tools/microbench/gather.hip, profiles/r01_*).  What the measurements
-// settled:
-//   * exactly ONE round trip to memory per step: the record of a lane -- node or triangle -- is fetched in one
-//     phase and pinned in registers before the type branch (hipcc otherwise narrows the loads per use and sinks
-//     them behind the branch: three round trips per step);
-//   * no persistence, no work queue: the rays of this workload are short (~16 node visits and ~1.5 triangle tests
-//     each) and there are only ~2 of them per resident lane, so a persistent kernel that re-deals rays to idle
-//     lanes spent more on dealing (atomics on list heads, refill fetches, tail imbalance) than it saved: 0.55 ms
-//     against 0.22 ms for this kernel on the 1080p bunny frame (profiles/r01_c).  The hardware dispatcher balances
-//     the ~10^4 short-lived waves over the CUs;
+// One wave = one bin: the (usually <= 64) rays of one 8x8 pixel sub-tile, which start next to each other and mostly
+// walk the same nodes.  What the measurements settled (tools/microbench, profiles/r01_*):
+//   * a traversal step is a dependent gather.  The vector L1 serves a divergent gather at ~1 lane-request (<= 16 B)
+//     per cycle per CU whatever the width (tools/microbench/lanecost.hip), L2 answers in ~250 cycles: the cost of a
+//     step is the NUMBER of load instructions x active lanes, plus ~300 VALU instructions.  Hence a 4-wide BVH
+//     (lbvh.hip, emitNodes4): 128-byte nodes = one cache line = 7 x 16-byte loads, half the steps of the binary tree;
+//   * the loads of a step are issued together and pinned in registers before use (hipcc otherwise narrows them per
+//     use and sinks them behind branches: several round trips per step);
+//   * no persistent threads, no global work queue: rays are short (~10 node visits, ~1.8 triangle tests) and there
+//     are only ~2 per resident lane; a persistent kernel that re-dealt rays to idle lanes spent more on dealing
+//     (atomics on list heads, refill fetches) than it saved: 0.55 ms against 0.22 ms for one-wave-per-bin on the
+//     1080p bunny frame.  The hardware dispatcher balances the ~10^4 short-lived waves over the CUs;
+//   * what remains is imbalance INSIDE a wave: see "work sharing" at the kernel;
 //   * the world-space ray stays in registers as two object-space rays: switching from the ground instance to the
 //     model costs no fetch.
 // Per-lane traversal stack in LDS ([entry][lane] layout: conflict-free ds_read/ds_write_b32), RT_STACK entries,
 // deeper pushes spill to global memory (launchTrace sizes the spill area from the depth of the built trees; the
 // bunny and dragon trees never need it).  Semantics (DESIGN.md "Traversal"): two-level, rays carried into each
 // instance's object space, nearer child first, watertight ray/triangle test (Woop, Benthin, Wald 2013), no
-// culling, TMin < t < TMax, ties to the lower (instance, primitive).
+// culling, TMin < t < TMax, ties to the lower (instance, primitive).  The closest hit does not depend on the
+// order in which boxes are visited, so the 4-wide collapse, the work sharing and the postponed triangle tests
+// leave every hit record bit-identical to the oracle's binary-tree walk (tests/test_gpu_parity.py).
 #include "rt_queue.h"
 
 namespace rt {
 
-#define RT_STACK 16          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: 12)
+#define RT_STACK 24          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: see tests/trace_stats_probe.py)
 
 struct TraceArgs {
-  const float4* nodes0; const float4* tris0;   // 64-byte records: 4 x float4 each
+  const float4* nodes0; const float4* tris0;   // 128-byte 4-wide nodes (8 x float4), 64-byte leaf triangles (4 x float4)
   const float4* nodes1; const float4* tris1;
   int32_t root0, root1;
   uint32_t haveMesh0, haveMesh1;
@@ -101,105 +103,208 @@ RT_DEV void slabTest(const LaneRay& r, float mnx, float mny, float mnz, float mx
 
 // Wave w of the grid traces the rays of bin w, 64 at a time (a second round only where a sub-tile has more than 64
 // rays, i.e. diffuse rays besides the reflection rays).
+//
+// Work sharing inside the wave.  Ray lengths are very uneven (mean 12 steps, longest ~200): without sharing the
+// wave runs at 44% lane utilisation and the kernel ends with a long tail of waves in which one lane chases one ray
+// at ~2000 cycles per dependent step.  So a lane is not tied to its ray: the unit of work is a JOB -- a subtree of
+// one ray -- and in every step in which at least half of the lanes have no job, those lanes take the BOTTOM stack
+// entry (the farthest, largest pending subtree) of lanes that have one.  The helper copies the ray and the victim's best hit so far, walks the subtree
+// with its own stack and merges what it finds into the ray's record in LDS: key = (t bits << 32) | id, combined
+// with a 64-bit min, which is exactly the closest-hit rule (smaller t, then smaller id) whatever the order in
+// which the subtrees finish.  pending[] counts the helpers of a ray; its hit record is written when the primary
+// job has ended and pending is 0.
+// Tuned on the 1080p bunny frame (tools/sweep: kernel 0.26 ms without sharing, 0.19 ms with these):
+#define RT_STEAL_MIN_IDLE 32u    // share work once half of the lanes have none
+#define RT_STEAL_ROUNDS 2        // entries a lane can give away per step
+#define RT_LEAF_BATCH 8u         // lanes standing on a leaf that make a triangle-test phase worthwhile
 __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
   __shared__ int32_t stackMem[RT_STACK * 256];
+  __shared__ unsigned long long keyMem[256];       // per ray (owner lane): best (t, id) over all its jobs
+  __shared__ float2 baryMem[256];                  // barycentrics of that hit
+  __shared__ uint32_t pendingMem[256];             // helpers still walking subtrees of the ray
+  __shared__ uint32_t victimMem[256];              // scratch: the lanes offering work, compacted
   const FrameParams& fp = *fpp;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t bin = blockIdx.x * 4u + wave;
   if (bin >= A.numBins) return;
   const uint32_t count = min(A.binCount[bin], RT_BIN);
   if (count == 0u) return;
-  int32_t* const stack = stackMem + wave * (RT_STACK * 64) + lane;                      // entry e at stack[e * 64]
+  int32_t* const stackBase = stackMem + wave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
+  int32_t* const stack = stackBase + lane;
+  unsigned long long* const key = keyMem + wave * 64; float2* const bary = baryMem + wave * 64;
+  uint32_t* const pending = pendingMem + wave * 64; uint32_t* const victims = victimMem + wave * 64;
   const size_t spillStride = A.spillStride;
   int32_t* const spill = A.overflow + bin * RT_BIN + lane;                               // entry e at spill[e * spillStride]
+  const unsigned long long laneLt = (1ull << lane) - 1ull;
   uint32_t nRays = 0;
 #ifdef RT_TRACE_STATS
-  uint32_t stNode = 0, stLeaf = 0, stIter = 0, stDeep = 0;
+  uint32_t stNode = 0, stLeaf = 0, stIter = 0, stDeep = 0, stSteal = 0, stLeafPhase = 0;
+  const unsigned long long stT0 = clock64(), stW0 = wall_clock64();
 #endif
   for (uint32_t base = 0; base < count; base += 64u) {
   const uint32_t slot = bin * RT_BIN + base + lane;
-  bool active = base + lane < count;
+  bool hasRay = base + lane < count;                 // my slot holds a ray whose hit record is not written yet
 
   // ---- the ray: world space -> the object spaces of both instances --------------------------------------------
-  const float4* rp = reinterpret_cast<const float4*>(A.rays + (active ? slot : bin * RT_BIN));
+  const float4* rp = reinterpret_cast<const float4*>(A.rays + (hasRay ? slot : bin * RT_BIN));
   const float4 ra = rp[0], rb = rp[1];
   const uint4 rc = reinterpret_cast<const uint4*>(rp)[2];
-  const float tmin = ra.w;
+  float tmin = ra.w;
   float bestT = rb.w, bestB1 = 0.0f, bestB2 = 0.0f;
   uint32_t bestId = 0xFFFFFFFFu;
-  const uint32_t skip = rc.y;
+  uint32_t skip = rc.y;
   uint32_t inst = A.haveMesh0 ? 0u : 1u;
   const LaneRay r1 = toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[1]);
   LaneRay r = inst ? r1 : toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[0]);
   int32_t cur = inst ? A.root1 : A.root0;
-  int sp = 0;
+  int sp = 0, sb = 0;                                // my stack holds entries [sb, sp)
   {
     const uint32_t row = rc.x / A.width;
-    if (active && row >= A.countRowBegin && row < A.countRowEnd) ++nRays;
+    if (hasRay && row >= A.countRowBegin && row < A.countRowEnd) ++nRays;
   }
-  if (active && (!(bestT > tmin) || (inst == 1u && A.haveMesh1 == 0u))) {   // degenerate interval / empty scene: a miss
+  if (hasRay && (!(bestT > tmin) || (inst == 1u && A.haveMesh1 == 0u))) {   // degenerate interval / empty scene: a miss
     HitRec h; h.t = bestT; h.b1 = 0.0f; h.b2 = 0.0f; h.id = 0xFFFFFFFFu; A.hits[slot] = h;
-    active = false;
+    hasRay = false;
   }
+  // job state: the primary job of my own ray
+  bool job = hasRay, helper = false, primaryDone = !hasRay;
+  uint32_t owner = lane;
+  key[lane] = ((unsigned long long)__float_as_uint(bestT) << 32) | 0xFFFFFFFFull;
+  pending[lane] = 0u;
 
   // ---- traversal -----------------------------------------------------------------------------------------------
-  while (__ballot(active)) {
+  while (__ballot(job || hasRay)) {
+    // -- idle lanes take over pending subtrees
+    if ((uint32_t)__popcll(__ballot(!job)) >= RT_STEAL_MIN_IDLE) {
+      for (int round = 0; round < RT_STEAL_ROUNDS; ++round) {
+        const bool offers = job && sb < sp && sb < RT_STACK;                 // bottom entry exists and lives in LDS
+        const unsigned long long victimMask = __ballot(offers), idleMask = __ballot(!job);
+        if (victimMask == 0ull || idleMask == 0ull) break;
+        const uint32_t nv = (uint32_t)__popcll(victimMask), ni = (uint32_t)__popcll(idleMask);
+        const uint32_t myV = (uint32_t)__popcll(victimMask & laneLt), myI = (uint32_t)__popcll(idleMask & laneLt);
+        if (offers) victims[myV] = lane;
+        const bool thief = !job && myI < nv;
+        const uint32_t v = thief ? victims[myI] : lane;
+        // everything a helper needs, read from the victim's registers
+        const int vsb = __shfl(sb, (int)v);
+        const float v_ox = __shfl(r.ox, (int)v), v_oy = __shfl(r.oy, (int)v), v_oz = __shfl(r.oz, (int)v);
+        const float v_ix = __shfl(r.ix, (int)v), v_iy = __shfl(r.iy, (int)v), v_iz = __shfl(r.iz, (int)v);
+        const float v_Sx = __shfl(r.Sx, (int)v), v_Sy = __shfl(r.Sy, (int)v), v_Sz = __shfl(r.Sz, (int)v);
+        const int v_kx = __shfl(r.kx, (int)v), v_ky = __shfl(r.ky, (int)v), v_kz = __shfl(r.kz, (int)v);
+        const float v_tmin = __shfl(tmin, (int)v), v_bestT = __shfl(bestT, (int)v), v_b1 = __shfl(bestB1, (int)v), v_b2 = __shfl(bestB2, (int)v);
+        const uint32_t v_bestId = (uint32_t)__shfl((int)bestId, (int)v), v_skip = (uint32_t)__shfl((int)skip, (int)v);
+        const uint32_t v_inst = (uint32_t)__shfl((int)inst, (int)v), v_owner = (uint32_t)__shfl((int)owner, (int)v);
+        if (thief) {
+          cur = stackBase[vsb * 64 + (int)v];
+          r.ox = v_ox; r.oy = v_oy; r.oz = v_oz; r.ix = v_ix; r.iy = v_iy; r.iz = v_iz; r.Sx = v_Sx; r.Sy = v_Sy; r.Sz = v_Sz;
+          r.kx = v_kx; r.ky = v_ky; r.kz = v_kz;
+          tmin = v_tmin; bestT = v_bestT; bestB1 = v_b1; bestB2 = v_b2; bestId = v_bestId; skip = v_skip; inst = v_inst; owner = v_owner;
+          sp = sb = 0; job = true; helper = true;
+          atomicAdd(&pending[owner], 1u);
 #ifdef RT_TRACE_STATS
-    ++stIter; if (active) { if (cur < 0) ++stLeaf; else ++stNode; }
+          ++stSteal;
 #endif
-    if (active) {
-      bool needPop = false;
-      // ONE fetch phase per step: the 64-byte record of this lane, node or leaf triangle alike
-      const bool leaf = cur < 0;
-      const float4* rec = leaf ? (inst ? A.tris1 : A.tris0) + (size_t)(~cur) * 4 : (inst ? A.nodes1 : A.nodes0) + (size_t)cur * 4;
-      float4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-      asm volatile("" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w), "+v"(n1.x), "+v"(n1.y), "+v"(n1.z), "+v"(n1.w));
-      asm volatile("" : "+v"(n2.x), "+v"(n2.y), "+v"(n2.z), "+v"(n2.w), "+v"(n3.x), "+v"(n3.y));
-      const int32_t w12 = __float_as_int(n3.x);             // node: left child; triangle: primitive id
-      if (!leaf) {
-        // n0 = lmin.xyz lmax.x | n1 = lmax.yz rmin.xy | n2 = rmin.z rmax.xyz | n3 = left right pad pad
-        float ln, lf, rn, rf;
-        slabTest(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tmin, bestT, ln, lf);
-        slabTest(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tmin, bestT, rn, rf);
-        const bool hl = ln <= lf * 1.0000004f, hr = rn <= rf * 1.0000004f;
-        const int32_t left = w12, right = __float_as_int(n3.y);
-        if (hl && hr) {
-          const bool leftFirst = ln <= rn;
-          const int32_t far = leftFirst ? right : left;
-          if (sp < RT_STACK) stack[sp * 64] = far; else spill[(size_t)(sp - RT_STACK) * spillStride] = far;
-          ++sp;
+        }
+        if (offers && myV < ni) ++sb;                                          // my bottom entry was taken
+      }
+    }
 #ifdef RT_TRACE_STATS
-          if ((uint32_t)sp > stDeep) stDeep = (uint32_t)sp;
+    ++stIter; if (job && cur >= 0) ++stNode;
 #endif
-          cur = leftFirst ? left : right;
-        } else if (hl) cur = left;
-        else if (hr) cur = right;
-        else needPop = true;
+    bool finished = false;
+    // Pop the next entry of my stack; with none left the job is over (the primary job first moves on from the ground
+    // instance to the model: same world ray, object-space copy r1).
+    auto popOrFinish = [&]() {
+      if (sp > sb) {
+        --sp;
+        if (sp < RT_STACK) cur = stack[sp * 64]; else cur = spill[(size_t)(sp - RT_STACK) * spillStride];
+        if (sp == sb) sp = sb = 0;
       } else {
-        // n0 = v0.xyz v1.x | n1 = v1.yz v2.xy | n2 = v2.z pad pad pad | n3 = prim pad pad pad
-        const uint32_t id = (inst << 24) | (uint32_t)w12;
-        if (id != skip) {
-          float t, b1, b2;
-          if (woopTest(r, n0, n1, n2, t, b1, b2) && t > tmin) {
-            const bool closer = t < bestT;
-            const bool tie = bestId != 0xFFFFFFFFu && t == bestT && id < bestId;
-            if (closer || tie) { bestT = t; bestId = id; bestB1 = b1; bestB2 = b2; }
+        sp = sb = 0;
+        if (!helper && inst == 0u && A.haveMesh1 != 0u) { inst = 1u; r = r1; cur = A.root1; }
+        else { job = false; finished = true; }
+      }
+    };
+    // -- node phase: lanes standing on a 4-wide node test its boxes (one 128-byte fetch); lanes standing on a leaf wait
+    if (job && cur >= 0) {
+      const float4* rec = (inst ? A.nodes1 : A.nodes0) + (size_t)cur * 8;
+      float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+      asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+      asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+      asm volatile("" : "+v"(q4.x), "+v"(q4.y), "+v"(q4.z), "+v"(q4.w), "+v"(q5.x), "+v"(q5.y), "+v"(q5.z), "+v"(q5.w));
+      asm volatile("" : "+v"(q6.x), "+v"(q6.y), "+v"(q6.z), "+v"(q6.w));
+      // q0..q5 = minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4], q6 = ref[4]
+      float t0, t1, t2, t3, tf;
+      int32_t c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
+      const float inf = __builtin_inff();
+      slabTest(r, q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, tmin, bestT, t0, tf); t0 = (t0 <= tf * 1.0000004f && c0 != RT_BVH4_EMPTY) ? t0 : inf;
+      slabTest(r, q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, tmin, bestT, t1, tf); t1 = (t1 <= tf * 1.0000004f && c1 != RT_BVH4_EMPTY) ? t1 : inf;
+      slabTest(r, q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, tmin, bestT, t2, tf); t2 = (t2 <= tf * 1.0000004f && c2 != RT_BVH4_EMPTY) ? t2 : inf;
+      slabTest(r, q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, tmin, bestT, t3, tf); t3 = (t3 <= tf * 1.0000004f && c3 != RT_BVH4_EMPTY) ? t3 : inf;
+      // order the entries by entry distance (misses last); the order only affects how soon far boxes get culled
+#define RT_CSWAP(ta, ca, tb, cb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; const int32_t cc = sw ? cb : ca; cb = sw ? ca : cb; ca = cc; }
+      RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2) RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2)
+#undef RT_CSWAP
+#define RT_PUSH(v) { if (sp < RT_STACK) stack[sp * 64] = (v); else spill[(size_t)(sp - RT_STACK) * spillStride] = (v); ++sp; }
+      if (t0 < inf) {
+        if (t3 < inf) RT_PUSH(c3)
+        if (t2 < inf) RT_PUSH(c2)
+        if (t1 < inf) RT_PUSH(c1)
+        cur = c0;
+#ifdef RT_TRACE_STATS
+        if ((uint32_t)sp > stDeep) stDeep = (uint32_t)sp;
+#endif
+      } else popOrFinish();
+#undef RT_PUSH
+    }
+    // -- leaf phase: the triangle test is the longest stretch of code, so it runs for many lanes at once: when enough
+    //    lanes stand on a leaf, or when no lane has a node left to visit
+    {
+      const bool atLeaf = job && cur < 0;
+      const unsigned long long leafMask = __ballot(atLeaf);
+      if (leafMask != 0ull && ((uint32_t)__popcll(leafMask) >= RT_LEAF_BATCH || __ballot(job && cur >= 0) == 0ull)) {
+#ifdef RT_TRACE_STATS
+        ++stLeafPhase;
+#endif
+        if (atLeaf) {
+          const float4* rec = (inst ? A.tris1 : A.tris0) + (size_t)(~cur) * 4;
+          float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+          asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+          asm volatile("" : "+v"(q2.x), "+v"(q3.x));
+          // q0 = v0.xyz v1.x | q1 = v1.yz v2.xy | q2 = v2.z pad pad pad | q3 = prim pad pad pad
+          const uint32_t id = (inst << 24) | __float_as_uint(q3.x);
+          if (id != skip) {
+            float t, b1, b2;
+            if (woopTest(r, q0, q1, q2, t, b1, b2) && t > tmin) {
+              const bool closer = t < bestT;
+              const bool tie = bestId != 0xFFFFFFFFu && t == bestT && id < bestId;
+              if (closer || tie) { bestT = t; bestId = id; bestB1 = b1; bestB2 = b2; }
+            }
           }
-        }
-        needPop = true;
-      }
-      if (needPop) {
-        if (sp > 0) {
-          --sp;
-          if (sp < RT_STACK) cur = stack[sp * 64]; else cur = spill[(size_t)(sp - RT_STACK) * spillStride];
-        } else if (inst == 0u && A.haveMesh1 != 0u) {
-          inst = 1u; r = r1; cur = A.root1;                  // ground done: continue in the model's object space
-        } else {
-          HitRec h; h.t = bestT; h.b1 = bestB1; h.b2 = bestB2; h.id = bestId;
-          A.hits[slot] = h;
-          active = false;
+          popOrFinish();
+#ifdef RT_TRACE_STATS
+          ++stLeaf;
+#endif
         }
       }
+    }
+    // -- finished jobs merge their best hit into the ray's record; complete rays are written out
+    if (__ballot(finished)) {
+      const unsigned long long mine = ((unsigned long long)__float_as_uint(bestT) << 32) | bestId;
+      if (finished) atomicMin(&key[owner], mine);
+      if (finished) {
+        if (bestId != 0xFFFFFFFFu && key[owner] == mine) bary[owner] = make_float2(bestB1, bestB2);
+        if (helper) atomicSub(&pending[owner], 1u); else primaryDone = true;
+        helper = false; owner = lane;
+      }
+    }
+    if (hasRay && primaryDone && pending[lane] == 0u) {
+      const unsigned long long k = key[lane];
+      HitRec h; h.t = __uint_as_float((uint32_t)(k >> 32)); h.id = (uint32_t)k;
+      const float2 bb = h.id != 0xFFFFFFFFu ? bary[lane] : make_float2(0.0f, 0.0f);
+      h.b1 = bb.x; h.b2 = bb.y;
+      A.hits[slot] = h;
+      hasRay = false;
     }
   }
   }   // base
@@ -208,13 +313,27 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   for (int o = 32; o > 0; o >>= 1) nRays += __shfl_down(nRays, o);
   if (lane == 0 && nRays) atomicAdd(&A.rayTotals[bin & 255u], nRays);
 #ifdef RT_TRACE_STATS
-  for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); stDeep = max(stDeep, (uint32_t)__shfl_down((int)stDeep, o)); }
-  if (lane == 0) {   // lane node steps, lane leaf steps, wave iterations, waves, deepest stack
-    atomicAdd(&A.rayTotals[256], stNode); atomicAdd(&A.rayTotals[257], stLeaf); atomicAdd(&A.rayTotals[258], stIter);
-    atomicAdd(&A.rayTotals[259], 1u); atomicMax(&A.rayTotals[260], stDeep);
+  for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); stSteal += __shfl_down(stSteal, o); stDeep = max(stDeep, (uint32_t)__shfl_down((int)stDeep, o)); }
+  if (lane == 0) {   // lane node steps, lane leaf steps, wave iterations, waves, deepest stack, wave lifetime (sum, max), most iterations, steals
+    uint32_t* st = A.rayTotals + 256 + (bin & 15u) * 16u;      // 16 copies to keep the atomics off one word
+    atomicAdd(&st[0], stNode); atomicAdd(&st[1], stLeaf); atomicAdd(&st[2], stIter);
+    atomicAdd(&st[3], 1u); atomicMax(&st[4], stDeep);
+    const uint32_t life = (uint32_t)((clock64() - stT0) >> 4);
+    {   // histograms of wave start / end times, 8 us buckets from the stamp of stampKernel (wall clock: 100 MHz)
+      const unsigned long long t0 = *reinterpret_cast<const unsigned long long*>(A.rayTotals + 1020);
+      const unsigned long long now = wall_clock64();
+      const uint32_t be = min((uint32_t)((now - t0) / 800ull), 31u);
+      const uint32_t bs = min((uint32_t)((stW0 - t0) / 800ull), 31u);
+      atomicAdd(&A.rayTotals[512 + be], 1u); atomicAdd(&A.rayTotals[544 + bs], 1u);
+    }
+    atomicAdd(&st[5], life >> 6); atomicMax(&st[6], life); atomicMax(&st[7], stIter); atomicAdd(&st[8], stSteal); atomicAdd(&st[9], stLeafPhase);
   }
 #endif
 }
+
+#ifdef RT_TRACE_STATS
+__global__ void stampKernel(uint32_t* totals) { *reinterpret_cast<unsigned long long*>(totals + 1020) = wall_clock64(); }
+#endif
 
 int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays) {
   TraceArgs T;
@@ -222,15 +341,16 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   if (numBins > c->numBinsMax) { setError("launchTrace: %u bins exceed the %u allocated", numBins, c->numBinsMax); return -1; }
   const bool have0 = c->mesh[0].tris != nullptr, have1 = c->mesh[1].tris != nullptr;
   // a mesh with one triangle has no internal nodes; an absent mesh has nothing: point those bases at the dummy record
-  T.nodes0 = (const float4*)(have0 && c->mesh[0].nodes ? (const void*)c->mesh[0].nodes : c->dummyRecord);
+  T.nodes0 = (const float4*)(have0 && c->mesh[0].nodes4 ? (const void*)c->mesh[0].nodes4 : c->dummyRecord);
   T.tris0 = (const float4*)(have0 ? (const void*)c->mesh[0].tris : c->dummyRecord);
-  T.nodes1 = (const float4*)(have1 && c->mesh[1].nodes ? (const void*)c->mesh[1].nodes : c->dummyRecord);
+  T.nodes1 = (const float4*)(have1 && c->mesh[1].nodes4 ? (const void*)c->mesh[1].nodes4 : c->dummyRecord);
   T.tris1 = (const float4*)(have1 ? (const void*)c->mesh[1].tris : c->dummyRecord);
   T.root0 = c->mesh[0].root; T.root1 = c->mesh[1].root; T.haveMesh0 = have0; T.haveMesh1 = have1;
   T.rays = (const RayRec*)c->rayQueue; T.hits = (HitRec*)c->hitQueue;
   T.binCount = c->binCount; T.numBins = numBins;
   // stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get
-  const uint32_t deepest = c->mesh[0].depth > c->mesh[1].depth ? c->mesh[0].depth : c->mesh[1].depth;
+  // (a 4-wide node leaves at most 3 entries behind, and there is one per two levels of the binary tree)
+  const uint32_t deepest = 3u * ((c->mesh[0].depth > c->mesh[1].depth ? c->mesh[0].depth : c->mesh[1].depth) / 2u + 1u);
   if (deepest > RT_STACK + c->spillEntries) {
     RT_HIP(hipStreamSynchronize(s));
     if (c->stackOverflow) { RT_HIP(hipFree(c->stackOverflow)); c->stackOverflow = nullptr; }
@@ -240,6 +360,9 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32;
   T.spillStride = (size_t)c->numBinsMax * RT_BIN;
   T.countRowBegin = countRays ? fp.rowBegin : 0u; T.countRowEnd = countRays ? fp.rowEnd : 0u; T.width = fp.W;
+#ifdef RT_TRACE_STATS
+  hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounter32);
+#endif
   hipLaunchKernelGGL(traceKernel, dim3((numBins + 3u) / 4u), dim3(256), 0, s, c->dParams + c->slot, T);
   RT_HIP(hipGetLastError());
   return 0;

@@ -9,8 +9,14 @@ a = app.RayTracedGGX(["-mesh", assets.path("bunny.obj"), "-env", assets.path("rn
 a.context.enable_timing(1)
 for f in range(3):
     a.OnUpdate(); a.OnRender(); a.context.sync()
-    c = a.context.debug_counters(8).astype(float)
+    allc = a.context.debug_counters(768, reset=True)
+    raw = allc[:256].astype(float).reshape(16, 16)   # 16 copies of the counters
+    c = raw.sum(axis=0); c[[4, 6, 7]] = raw.max(axis=0)[[4, 6, 7]]
     rays = a.context.ray_count()
     waves = max(c[3], 1)
-    print("frame %d rays %d  node steps/ray %.1f  leaf steps/ray %.2f  wave iterations %d (%.1f per wave, lane utilisation %.2f)  waves %d  deepest stack %d  kernel %.3f ms" % (
-        f, rays, c[0] / rays, c[1] / rays, c[2], c[2] / waves, (c[0] + c[1]) / max(c[2] * 64.0, 1), c[3], c[4], a.context.timings()["ray_trace_kernel"]))
+    print("frame %d rays %d  node steps/ray %.1f  leaf steps/ray %.2f  wave iterations %d (%.1f per wave, lane utilisation %.2f)  waves %d  deepest stack %d  steals %d  leaf phases %d  kernel %.3f ms" % (
+        f, rays, c[0] / rays, c[1] / rays, c[2], c[2] / waves, (c[0] + c[1]) / max(c[2] * 64.0, 1), c[3], c[4], c[8], c[9], a.context.timings()["ray_trace_kernel"]))
+    print("   wave lifetime: mean %.0f cycles, max %.0f cycles; most iterations in one wave %d; cycles per iteration %.0f" % (
+        c[5] * 1024 / waves, c[6] * 16, c[7], c[5] * 1024 / max(c[2], 1)))
+    print("   wave starts per 8 us:", " ".join(str(int(v)) for v in allc[288:320]))
+    print("   wave ends   per 8 us:", " ".join(str(int(v)) for v in allc[256:288]))
