@@ -13,7 +13,7 @@ groups=(
   "SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_INSTS_VALU_TRANS_F32"
   "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TCP_TOTAL_ACCESSES TCP_PENDING_STALL_CYCLES"
   "TCP_TCP_TA_DATA_STALL_CYCLES TCP_TA_TCP_STATE_READ TCP_READ_TAGCONFLICT_STALL_CYCLES TCP_TCC_READ_REQ_LATENCY"
-  "TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TA_FLAT_READ_WAVEFRONTS"
+  "TCP_GATE_EN1 TCP_GATE_EN2 TCP_TCR_TCP_STALL_CYCLES TCP_RFIFO_STALL_CYCLES"   # (TA_* counters abort rocprofv3 7.2 on this pool)
   "TCC_HIT TCC_MISS TCC_REQ TCC_EA_RDREQ"
   "TCC_EA_RDREQ_32B TCC_EA_WRREQ TCC_EA_WRREQ_64B TCC_READ"
   "GRBM_GUI_ACTIVE GRBM_COUNT"
