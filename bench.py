@@ -80,6 +80,7 @@ def main():
     # per-frame ray counts and kernel durations were recorded without host synchronisation; collect them now
     rays_total = r.rays_traced_since_reset()
     kernel_ms = r.ray_kernel_ms_since_reset()
+    own_rays = rays_total
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -93,7 +94,9 @@ def main():
         ms_per_step = dt * 1e3 / args.steps
         value = rays_total / dt / 1e6
         rows = r.strip_rows_with_apron()
-        alg_bytes = r.ray_kernel_algorithmic_bytes(rows)
+        rays_per_launch = own_rays / max(args.steps, 1)     # rays of this rank's strip (apron rays of a strip are not counted)
+        alg_bytes = r.trace_kernel_algorithmic_bytes(rays_per_launch)
+        frame_bytes = r.frame_algorithmic_bytes(rows)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
         out = {
@@ -104,9 +107,12 @@ def main():
             "config": {"workload": "configs[1]: %s + rnl_cross env, %dx%d, 1spp GGX reflection + full denoise chain (refl H,V; diff H,V, shared-memory variant; temporal; tone map), "
                                    "all-metal default materials, dt=1/60" % (args.mesh, W, H),
                        "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "rayGenKernel", "achieved": None if achieved is None else round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4)},
+                         "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
+                         "note": "dependent-gather kernel: bound by L1 request rate and latency, not by HBM (DESIGN.md 'Roofline')",
+                         "frame": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                                   "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
             "passes_ms": r.last_timings(),
         }
         if world == 1 and not args.no_cpu_baseline:

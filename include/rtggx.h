@@ -99,7 +99,9 @@ enum {
   RTGGX_BUF_BVH_TRIS1 = 16,
   RTGGX_BUF_TLAS = 17,       /* 2 x 16 floats: world->object matrices (row-vector, row-major) */
   RTGGX_BUF_ENV = 18,        /* decoded RGBA16F environment, mip-major, 6 faces per mip */
-  RTGGX_BUF_COUNT = 19
+  RTGGX_BUF_BVH4_NODES0 = 19, /* 128-byte 4-wide nodes of mesh 0, indexed like the binary nodes (odd-depth slots unused, zero): */
+  RTGGX_BUF_BVH4_NODES1 = 20, /*   minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4]; ref: >=0 node, <0 ~leaf slot, 0x7FFFFFFF none */
+  RTGGX_BUF_COUNT = 21
 };
 
 /* Per-pass GPU timings of the last completed frame, in milliseconds (hipEvent based). */

@@ -31,9 +31,42 @@ def strip_rows(height, rank, world):
     return (rank * height) // world, ((rank + 1) * height) // world
 
 
+def exchange_plan(height, rank, world, apron=HISTORY_APRON):
+    """The point-to-point transfers of one frame for `rank`: a list of (op, buffer, row_begin, row_end, peer) with op in
+    {"send", "recv"} and buffer in {"history", "backbuffer"}.  Rows are frame rows: every rank allocates full-size
+    targets, so a transfer reads and writes the same rows on both sides.  Ops between a pair of ranks appear in the same
+    order on both (history first, then the back-buffer strip), which is what tag-less send/recv matching needs."""
+    b, e = strip_rows(height, rank, world)
+    ops = []
+    if rank > 0:                       # upper neighbour owns [.., b)
+        ops.append(("send", "history", b, min(b + apron, e), rank - 1))
+        ops.append(("recv", "history", max(b - apron, 0), b, rank - 1))
+    if rank < world - 1:               # lower neighbour owns [e, ..)
+        ops.append(("send", "history", max(e - apron, b), e, rank + 1))
+        ops.append(("recv", "history", e, min(e + apron, height), rank + 1))
+    if rank == 0:                      # frame assembly on rank 0 (the reference presents one back buffer)
+        for r in range(1, world):
+            rb, re = strip_rows(height, r, world)
+            ops.append(("recv", "backbuffer", rb, re, r))
+    else:
+        ops.append(("send", "backbuffer", b, e, 0))
+    return ops
+
+
+def run_exchange(dist, plan, buffers):
+    """Issue `plan` over torch.distributed as one batch (RCCL group launch on GPU tensors; plain isend/irecv on gloo).
+    buffers: {"history": tensor[H, W], "backbuffer": tensor[H, W]}."""
+    ops = [dist.P2POp(dist.isend if op == "send" else dist.irecv, buffers[name][r0:r1], peer) for op, name, r0, r1, peer in plan]
+    for w in dist.batch_isend_irecv(ops) if ops else []:
+        w.wait()                       # on GPU tensors a stream-side wait only: the host does not block
+
+
 class StripRenderer:
-    def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=()):
-        self.W, self.H, self.rank, self.world, self.dist = width, height, rank, world, dist
+    def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
+                 transport=None):
+        """dist: torch.distributed (one process per GPU).  transport: instead of dist, a callable
+        transport(renderer, plan) that carries out the plan some other way (tests drive several strips from one process)."""
+        self.W, self.H, self.rank, self.world, self.dist, self.transport = width, height, rank, world, dist, transport
         args = ["-mesh", mesh_path] + ([str(x) for x in pos_scale] if pos_scale else []) + \
                ["-env", env_path, "-width", width, "-height", height, "-device", device] + list(extra_args)
         self.app = app.RayTracedGGX(args)
@@ -42,13 +75,14 @@ class StripRenderer:
         if world > 1:
             if self.e - self.b < HISTORY_APRON:
                 raise ValueError("strips of %d rows are thinner than the %d-row history apron" % (self.e - self.b, HISTORY_APRON))
-            import torch
-            self.torch = torch
             self.context.set_strip(self.b, self.e)
-            # run the HIP passes on torch's current stream so that RCCL ops and kernels are ordered by the stream
-            self.context.set_stream(torch.cuda.current_stream().cuda_stream)
-            self._tss = [self._wrap(capi.BUF_TSS0, "<u8"), self._wrap(capi.BUF_TSS1, "<u8")]
-            self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
+            if transport is None:
+                import torch
+                self.torch = torch
+                # run the HIP passes on torch's current stream so that RCCL ops and kernels are ordered by the stream
+                self.context.set_stream(torch.cuda.current_stream().cuda_stream)
+                self._tss = [self._wrap(capi.BUF_TSS0, "<u8"), self._wrap(capi.BUF_TSS1, "<u8")]
+                self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
         self._last = None
 
     def _wrap(self, bid, typestr):
@@ -57,31 +91,21 @@ class StripRenderer:
 
     # -- one frame --------------------------------------------------------------------------------------
     def frame(self):
+        self.render()
+        self.exchange()
+
+    def render(self):
         self.app.OnUpdate()
         self.app.OnRender()
-        if self.world > 1:
-            self._exchange()
 
-    def _exchange(self):
-        dist, torch = self.dist, self.torch
-        A, b, e = HISTORY_APRON, self.b, self.e
-        tss = self._tss[self.context.frame_parity()]
-        ops = []
-        if self.rank > 0:                       # upper neighbour owns [.., b)
-            ops.append(dist.P2POp(dist.isend, tss[b:b + A], self.rank - 1))
-            ops.append(dist.P2POp(dist.irecv, tss[b - A:b], self.rank - 1))
-        if self.rank < self.world - 1:          # lower neighbour owns [e, ..)
-            ops.append(dist.P2POp(dist.isend, tss[e - A:e], self.rank + 1))
-            ops.append(dist.P2POp(dist.irecv, tss[e:e + A], self.rank + 1))
-        # frame assembly on rank 0 (the reference presents one back buffer)
-        if self.rank == 0:
-            for r in range(1, self.world):
-                rb, re = strip_rows(self.H, r, self.world)
-                ops.append(dist.P2POp(dist.irecv, self._backbuffer[rb:re], r))
+    def exchange(self):
+        if self.world == 1:
+            return
+        plan = exchange_plan(self.H, self.rank, self.world)
+        if self.transport is not None:
+            self.transport(self, plan)
         else:
-            ops.append(dist.P2POp(dist.isend, self._backbuffer[b:e], 0))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()                            # stream-side wait only: the host does not block
+            run_exchange(self.dist, plan, {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer})
 
     # -- statistics --------------------------------------------------------------------------------------
     def rays_traced_since_reset(self):
@@ -93,25 +117,24 @@ class StripRenderer:
     def strip_rows_with_apron(self):
         return max(self.b - 18, 0), min(self.e + 18, self.H)
 
-    def ray_kernel_algorithmic_bytes(self, rows):
-        """DESIGN.md "Roofline": 18 B/pixel (visibility 4 in; normal 4, roughMetal 2, velocity 4, reflection 4 out;
-        +4 when a diffuse ray is traced) + the scene arrays once (BVH nodes, leaf triangles, vertices, indices)."""
-        px = (rows[1] - rows[0]) * self.W
-        scene = 0
-        for bid in (capi.BUF_BVH_NODES0, capi.BUF_BVH_TRIS0, capi.BUF_BVH_NODES1, capi.BUF_BVH_TRIS1):
-            scene += self.context.buffer_size(bid)
-        scene += self.scene_vertex_index_bytes()
-        return 18 * px + scene
+    def trace_kernel_algorithmic_bytes(self, rays_per_launch):
+        """DESIGN.md "Roofline": what one launch of traceKernel has to move if every byte moved once -- a 64-byte ray
+        record in and a 16-byte hit record out per ray, plus the acceleration structure once (the 4-wide nodes in use
+        and the leaf triangles of both instances)."""
+        return 80 * rays_per_launch + self.bvh_bytes()
 
-    def scene_vertex_index_bytes(self):
-        # vertices 24 B, indices 4 B: from the leaf-triangle counts (3 indices per triangle); vertex counts from the importer
-        nt = (self.context.buffer_size(capi.BUF_BVH_TRIS0) + self.context.buffer_size(capi.BUF_BVH_TRIS1)) // 64
-        return 12 * nt + 24 * (24 + self._model_vertices())
+    def bvh_bytes(self):
+        if not hasattr(self, "_bvh_bytes"):
+            n = 0
+            for b4, bt in ((capi.BUF_BVH4_NODES0, capi.BUF_BVH_TRIS0), (capi.BUF_BVH4_NODES1, capi.BUF_BVH_TRIS1)):
+                nodes4 = self.context.readback(b4)
+                n += 128 * int(nodes4.any(axis=1).sum()) + self.context.buffer_size(bt)
+            self._bvh_bytes = n
+        return self._bvh_bytes
 
-    def _model_vertices(self):
-        if not hasattr(self, "_nv"):
-            self._nv = int(np.unique(self.context.readback(capi.BUF_BVH_TRIS1).view(np.float32).reshape(-1, 16)[:, :9].reshape(-1, 3), axis=0).shape[0])
-        return self._nv
+    def frame_algorithmic_bytes(self, rows, metallic_lt_1=False):
+        """146 B/pixel for the all-metal scene (178 with diffuse rays) + the scene once."""
+        return (178 if metallic_lt_1 else 146) * (rows[1] - rows[0]) * self.W + self.bvh_bytes()
 
     def last_timings(self):
         """Per-pass milliseconds of one extra, fully instrumented frame (outside any timed region)."""

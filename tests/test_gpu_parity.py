@@ -169,14 +169,51 @@ def _bvh_check(nodes_u32, tris_u32, root, num_tris):
     return depth_max
 
 
+def _bvh4_check(nodes, nodes4, root):
+    """The 4-wide nodes the trace kernel walks are the even-depth binary nodes with their internal children folded in."""
+    if root < 0:
+        assert nodes4.size == 0 or not nodes4.any()
+        return 0
+    f = nodes.view(np.float32)
+    child = nodes[:, 12:14].view(np.int32)
+    f4, r4 = nodes4.view(np.float32), nodes4[:, 24:28].view(np.int32)
+    depth = np.full(len(nodes), -1)
+    depth[root] = 0
+    order = [root]
+    for n in order:
+        for c in child[n]:
+            if c >= 0:
+                depth[c] = depth[n] + 1; order.append(c)
+    assert (depth >= 0).all()
+    assert not nodes4[depth % 2 == 1].any(), "odd-depth slots stay unused"
+    used = 0
+    for n in np.nonzero(depth % 2 == 0)[0]:
+        want = []
+        for side, c in ((0, child[n, 0]), (6, child[n, 1])):
+            if c < 0:
+                want.append((c, f[n, side:side + 6]))
+            else:
+                want += [(child[c, 0], f[c, 0:6]), (child[c, 1], f[c, 6:12])]
+        got = [(r4[n, k], f4[n, [k, 4 + k, 8 + k, 12 + k, 16 + k, 20 + k]]) for k in range(4) if r4[n, k] != 0x7FFFFFFF]
+        assert len(got) == len(want)
+        for (rg, bg), (rw, bw) in zip(sorted(got, key=lambda e: e[0]), sorted(want, key=lambda e: e[0])):
+            assert rg == rw and (bg == bw).all()
+        assert all(r < 0 or depth[r] % 2 == 0 for r, _ in got)
+        used += 1
+    return used
+
+
 def test_lbvh_structure_and_device_traversal(built):
     from raytracedggx_amd import capi
     p = Pair(64, 64)
     try:
         p.frame()
         depth = _bvh_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH_TRIS1), p.ctx.bvh_root(1), 69666)
-        assert depth <= 16 + 32, "traversal stack: 16 LDS entries + 32 spill entries; LBVH depth is %d" % depth
+        assert depth <= 62, "a Karras LBVH over 30 Morton + 32 index bits cannot be deeper; got %d" % depth
         _bvh_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH_TRIS0), p.ctx.bvh_root(0), 12)
+        used = _bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH4_NODES1), p.ctx.bvh_root(1))
+        assert 69665 // 3 <= used <= 69665, "4-wide nodes: %d" % used
+        _bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH4_NODES0), p.ctx.bvh_root(0))
         rng = np.random.default_rng(11)
         n = 20000
         org = np.array([10.0, 10.0, -24.0]) + rng.standard_normal((n, 3)) * 2.0
@@ -261,3 +298,47 @@ def test_full_size_1080p_properties(built):
             np.testing.assert_array_equal(ctx.readback(b), ref)
     finally:
         p.close()
+
+
+def test_two_strips_with_history_exchange_equal_one_frame(built):
+    """two row strips (two contexts, the per-frame exchange plan carried out by copies) against one
+    context rendering the whole frame -- every frame's back buffer and temporal history are bit-identical."""
+    from raytracedggx_amd import capi
+    from raytracedggx_amd.strips import StripRenderer
+    W, H = 640, 360
+    mesh, env = assets.path("bunny.obj"), assets.path("rnl_cross.dds")
+    strips = []
+
+    def transport(r, plan):
+        for op, name, r0, r1, peer in plan:
+            if op != "recv":
+                continue
+            bid = capi.BUF_BACKBUFFER if name == "backbuffer" else capi.BUF_TSS0 + r.context.frame_parity()
+            mine = r.context.readback(bid)
+            mine[r0:r1] = strips[peer].context.readback(bid)[r0:r1]
+            r.context.upload(bid, mine)
+
+    full = StripRenderer(W, H, mesh, env, extra_args=("-sharedmem",))
+    strips += [StripRenderer(W, H, mesh, env, rank=r, world=2, transport=transport, extra_args=("-sharedmem",)) for r in range(2)]
+    try:
+        rays = 0
+        for f in range(4):
+            full.frame(); full.context.sync()
+            for s in strips:
+                s.render(); s.context.sync()
+            for s in strips:
+                s.exchange()
+            par = full.context.frame_parity()
+            np.testing.assert_array_equal(strips[0].context.readback(capi.BUF_BACKBUFFER), full.context.readback(capi.BUF_BACKBUFFER),
+                                          err_msg="frame %d: assembled back buffer" % f)
+            ref = full.context.readback(capi.BUF_TSS0 + par)
+            for s in strips:
+                assert s.context.frame_parity() == par
+                np.testing.assert_array_equal(s.context.readback(capi.BUF_TSS0 + par)[s.b:s.e], ref[s.b:s.e], err_msg="frame %d: history" % f)
+            assert sum(s.context.ray_count() for s in strips) == full.context.ray_count(), "rays are counted once, by the strip that owns the pixel"
+            rays += full.context.ray_count()
+        assert rays > 100000
+    finally:
+        full.close()
+        for s in strips:
+            s.close()

@@ -1,0 +1,77 @@
+"""Multi-process path of the strip renderer on CPU (gloo): the per-frame exchange plan of raytracedggx_amd.strips
+delivers every rank's history apron and assembles the frame on rank 0.  The HIP passes themselves are covered by the
+GPU tests (two strips against one full frame, tests/test_gpu_parity.py); here the transport is the thing under test."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracedggx_amd.strips import HISTORY_APRON, exchange_plan, run_exchange, strip_rows
+
+H, W = 120, 16
+
+
+def _truth(rows):
+    """What a correct frame holds in row r, column c (history and back buffer differ by a constant)."""
+    r = torch.arange(rows[0], rows[1], dtype=torch.int64)[:, None]
+    return r * 1000 + torch.arange(W, dtype=torch.int64)[None, :]
+
+
+def _worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b, e = strip_rows(H, rank, world)
+        for frame in range(3):                                   # several frames: the matching must not drift
+            history = torch.full((H, W), -1, dtype=torch.int64)   # rows this rank did not produce are garbage
+            back = torch.full((H, W), -1, dtype=torch.int32)
+            history[b:e] = _truth((b, e)) + frame
+            back[b:e] = (_truth((b, e)) + frame + 7).to(torch.int32)
+            run_exchange(dist, exchange_plan(H, rank, world), {"history": history, "backbuffer": back})
+            lo, hi = max(b - HISTORY_APRON, 0), min(e + HISTORY_APRON, H)
+            assert torch.equal(history[lo:hi], _truth((lo, hi)) + frame), "rank %d frame %d: history apron" % (rank, frame)
+            assert (history[:lo] == -1).all() and (history[hi:] == -1).all(), "nothing beyond the apron is touched"
+            if rank == 0:
+                assert torch.equal(back, (_truth((0, H)) + frame + 7).to(torch.int32)), "frame assembly on rank 0"
+        results[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_over_gloo(world):
+    results = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    assert sorted(results.keys()) == list(range(world))
+
+
+def test_plan_is_consistent():
+    """Every send has the matching recv on the peer (same buffer, same rows), in the same per-pair order; strips tile the frame."""
+    for height, world in ((1080, 8), (2160, 8), (1080, 3), (120, 2), (1081, 4)):
+        plans = [exchange_plan(height, r, world) for r in range(world)]
+        rows = [strip_rows(height, r, world) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == height and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+        for a in range(world):
+            for b in range(world):
+                sends = [(n, r0, r1) for op, n, r0, r1, peer in plans[a] if op == "send" and peer == b]
+                recvs = [(n, r0, r1) for op, n, r0, r1, peer in plans[b] if op == "recv" and peer == a]
+                assert sends == recvs, (height, world, a, b)
+        for r in range(world):
+            for op, name, r0, r1, peer in plans[r]:
+                assert 0 <= r0 < r1 <= height
+                if op == "send":
+                    assert rows[r][0] <= r0 and r1 <= rows[r][1], "a rank only sends rows it produced"
+                elif name == "history":
+                    assert r1 <= rows[r][0] or r0 >= rows[r][1], "and only receives rows it did not"
+        single = exchange_plan(height, 0, 1)
+        assert single == []
