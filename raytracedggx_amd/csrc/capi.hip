@@ -329,9 +329,9 @@ int rtggx_sync(rtggx_context* c) {
 
 int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
   RT_CHECK_CTX(c);
-  unsigned long long h[256];
+  uint32_t h[256];
   RT_HIP(hipStreamSynchronize(c->streamMain));
-  RT_HIP(hipMemcpy(h, c->rayCounter, sizeof h, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(h, c->rayCounter32, sizeof h, hipMemcpyDeviceToHost));
   uint64_t s = 0; for (auto v : h) s += v;
   *rays = s;
   return 0;

@@ -79,18 +79,19 @@ template <int MODE>
 RT_DEV void storeFiltered(const Targets& T, size_t pix, float mx, float my, float mz, float wsum) {
   f3 mu = mk3(mx / wsum, my / wsum, mz / wsum);
   if (MODE == 0 || MODE == 2) T.scratch[pix] = packRGBA16F(mu.x, mu.y, mu.z, 0.0f);
-  if (MODE == 1) { mu = ITM3(mu); T.fltRfl[pix] = packRGBA16F(mu.x, mu.y, mu.z, 1.0f); }
+  if (MODE == 1) { mu = ITM3(mu); const uint2 v = packRGBA16F(mu.x, mu.y, mu.z, 1.0f); T.fltRfl[pix] = v; T.fltDff[pix] = v; }
   if (MODE == 3) {
     const f4 dest = unpackRGBA16F(T.fltRfl[pix]);
     mu = ITM3(mu);
     T.fltDff[pix] = packRGBA16F(dest.x + mu.x, dest.y + mu.y, dest.z + mu.z, dest.w);
   }
 }
-// Pixels the pass does not filter (no surface; diffuse: pure metal) -- CSSpatial_V_Refl.hlsl:27-31, CSSpatial_V_Diff.hlsl:28-32
+// Pixels the pass does not filter (no surface; diffuse: pure metal) -- CSSpatial_V_Refl.hlsl:27-31, CSSpatial_V_Diff.hlsl:28-32.
+// FilteredOut1 = FilteredOut + diffuse: the reflection V pass writes its result to both targets, so the diffuse V pass
+// only touches the pixels it filters (on the all-metal default scene: none) instead of copying the whole image.
 template <int MODE>
 RT_DEV void storeSkipped(const Targets& T, size_t pix) {
-  if (MODE == 1) { const f3 s = unpackR11G11B10F(T.rtRefl[pix]); T.fltRfl[pix] = packRGBA16F(s.x, s.y, s.z, 0.0f); }
-  if (MODE == 3) T.fltDff[pix] = T.fltRfl[pix];
+  if (MODE == 1) { const f3 s = unpackR11G11B10F(T.rtRefl[pix]); const uint2 v = packRGBA16F(s.x, s.y, s.z, 0.0f); T.fltRfl[pix] = v; T.fltDff[pix] = v; }
 }
 // Source colour of a tap: the ray-traced result tone-mapped (H passes) or the H pass's scratch (V passes).
 template <int MODE>
@@ -212,14 +213,29 @@ RT_DEV f4 loadRGBA16(const uint2* __restrict__ b, int x, int y, int W, int H) {
   return unpackRGBA16F(b[(size_t)y * W + x]);
 }
 
+// The 3x3 neighbourhood is read from an LDS tile that holds tssTM(FilteredOut1) (alpha kept) of the block's 64x4
+// pixels and a one-texel apron: each texel is unpacked and tone-mapped (three divisions) once instead of nine times.
 __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
+  __shared__ float4 tile[6][66];
+  const int W = T.W, H = T.H;
+  {
+    const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * 4 - 1;
+    for (int t = threadIdx.x; t < 6 * 66; t += 256) {
+      const f4 raw = loadRGBA16(T.fltDff, ox + t % 66, oy + t / 66, W, H);
+      const f3 tm = tssTM(mk3(raw.x, raw.y, raw.z));
+      tile[t / 66][t % 66] = make_float4(tm.x, tm.y, tm.z, raw.w);
+    }
+  }
+  __syncthreads();
+  const int lx = (threadIdx.x & 63) + 1, ly = (threadIdx.x >> 6) + 1;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= T.W || y >= T.rowEnd) return;
-  const int W = T.W, H = T.H;
   const float Wf = (float)W, Hf = (float)H;
   const float uvx = ((float)x + 0.5f) / Wf, uvy = ((float)y + 0.5f) / Hf;
-  const f4 current = loadRGBA16(T.fltDff, x, y, W, H);
+  const float4 cur = tile[ly][lx];
+  const f3 currentTM = mk3(cur.x, cur.y, cur.z);
+  f4 current; current.x = current.y = current.z = 0.0f; current.w = cur.w;     // only the alpha of the raw value is used below
   // VelocityMax :133-161
   f2 vmax = loadVel(T.velocity, x, y, W, H);
   float speedSq = vmax.x * vmax.x + vmax.y * vmax.y;
@@ -252,7 +268,6 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   float historyBlur = 1.0f - history.w;
   historyBlur = fmaxf(historyBlur, curHistoryBlur);
   history.w = history.w * 15.0f + 1.0f;
-  const f3 currentTM = tssTM(mk3(current.x, current.y, current.z));
   float gamma = current.w <= 0.0f ? 1.0f : clampf(8.0f / historyBlur, 1.0f, 32.0f);
   // NeighborMinMax :166-236
   float fl[4] = {currentTM.x, currentTM.y, currentTM.z, current.w};
@@ -262,9 +277,8 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     const float alpha = current.w;
     float m2[3] = {mu[0] * mu[0], mu[1] * mu[1], mu[2] * mu[2]};
     for (int i = 0; i < 8; ++i) {
-      const f4 nraw = loadRGBA16(T.fltDff, x + ox[i], y + oy[i], W, H);
-      const f3 t = tssTM(mk3(nraw.x, nraw.y, nraw.z));
-      const float nb[4] = {t.x, t.y, t.z, nraw.w};
+      const float4 t = tile[ly + oy[i]][lx + ox[i]];
+      const float nb[4] = {t.x, t.y, t.z, t.w};
       const float wgt = i < 4 ? 0.5f : 0.25f;
       for (int k = 0; k < 4; ++k) fl[k] += nb[k] * wgt;
       for (int k = 0; k < 3; ++k) { mu[k] += nb[k]; m2[k] += nb[k] * nb[k]; }
@@ -305,17 +319,27 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
 
 // PSToneMap.hlsl:13-41; source = TSS[parity] (passed as T.scratch)
 __global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
+  __shared__ float4 tile[6][66];          // c / (c + 0.5) of the block's pixels and a one-texel apron, computed once per texel
+  const int W = T.W, H = T.H;
+  {
+    const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * 4 - 1;
+    for (int t = threadIdx.x; t < 6 * 66; t += 256) {
+      const f4 c = loadRGBA16(T.scratch, ox + t % 66, oy + t / 66, W, H);
+      tile[t / 66][t % 66] = make_float4(c.x / (c.x + 0.5f), c.y / (c.y + 0.5f), c.z / (c.z + 0.5f), c.w);
+    }
+  }
+  __syncthreads();
+  const int lx = (threadIdx.x & 63) + 1, ly = (threadIdx.x >> 6) + 1;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= T.W || y >= T.rowEnd) return;
-  const int W = T.W, H = T.H;
-  f4 col[5];
-  col[0] = loadRGBA16(T.scratch, x, y, W, H); col[1] = loadRGBA16(T.scratch, x - 1, y, W, H); col[2] = loadRGBA16(T.scratch, x + 1, y, W, H);
-  col[3] = loadRGBA16(T.scratch, x, y - 1, W, H); col[4] = loadRGBA16(T.scratch, x, y + 1, W, H);
-  for (int i = 0; i < 5; ++i) { col[i].x /= col[i].x + 0.5f; col[i].y /= col[i].y + 0.5f; col[i].z /= col[i].z + 0.5f; }
-  float lx = -4.0f * col[0].x, ly = -4.0f * col[0].y, lz = -4.0f * col[0].z;
-  for (int i = 1; i < 5; ++i) { lx += col[i].x; ly += col[i].y; lz += col[i].z; }
-  T.backbuffer[(size_t)y * W + x] = packRGBA8(col[0].x - 0.2f * lx, col[0].y - 0.2f * ly, col[0].z - 0.2f * lz, col[0].w);
+  const float4 c0 = tile[ly][lx], c1 = tile[ly][lx - 1], c2 = tile[ly][lx + 1], c3 = tile[ly - 1][lx], c4 = tile[ly + 1][lx];
+  float lx_ = -4.0f * c0.x, ly_ = -4.0f * c0.y, lz_ = -4.0f * c0.z;
+  lx_ += c1.x; ly_ += c1.y; lz_ += c1.z;
+  lx_ += c2.x; ly_ += c2.y; lz_ += c2.z;
+  lx_ += c3.x; ly_ += c3.y; lz_ += c3.z;
+  lx_ += c4.x; ly_ += c4.y; lz_ += c4.z;
+  T.backbuffer[(size_t)y * W + x] = packRGBA8(c0.x - 0.2f * lx_, c0.y - 0.2f * ly_, c0.z - 0.2f * lz_, c0.w);
 }
 
 static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass) {

@@ -203,11 +203,13 @@ struct GenArgs {
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* cosSin;
   RayRec* rays; uint32_t* binCount;
+  uint32_t* frameRays;      // 256 per-frame ray counters, zeroed here, added to by the trace kernel
   uint32_t tilesX, numTiles, rowBegin, rowEnd;
 };
 
 __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restrict__ fpp, GenArgs A) {
   const FrameParams& fp = *fpp;
+  if (blockIdx.x == 0) A.frameRays[threadIdx.x] = 0u;
   // 16x16 pixel tile per workgroup, 8x8 per wave: the 64 rays a wave appends are neighbours on screen
   const uint32_t tile = blockIdx.x;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -388,24 +390,16 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict
 // =========================================================================================================
 // host side
 // =========================================================================================================
-__global__ void accumulateRayTotals(const uint32_t* __restrict__ frame32, unsigned long long* __restrict__ counters) {
-  const uint32_t v = frame32[threadIdx.x];
-  counters[threadIdx.x] = v;            // last frame (rtggx_ray_count)
-  counters[256 + threadIdx.x] += v;     // running total (rtggx_ray_total)
-}
-__global__ void resetFrameRayCounters(uint32_t* frameRays) { frameRays[threadIdx.x] = 0; }   // 256 per-frame counters
-
 int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   uint32_t rb, re;
   passRows(fp, ROWS_GBUFFER, rb, re);
   if (re <= rb) return 0;
   const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
-  hipLaunchKernelGGL(resetFrameRayCounters, dim3(1), dim3(256), 0, s, c->rayCounter32);
   GenArgs G;
   G.visDepth = c->visDepth; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.verts0 = c->mesh[0].verts; G.idx0 = c->mesh[0].indices; G.verts1 = c->mesh[1].verts; G.idx1 = c->mesh[1].indices;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
-  G.rays = (RayRec*)c->rayQueue; G.binCount = c->binCount;
+  G.rays = (RayRec*)c->rayQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;
   G.tilesX = tilesX; G.numTiles = tilesX * tilesY; G.rowBegin = rb; G.rowEnd = re;
   hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, G);
   if (c->timing) hipEventRecord(c->tev[11], s);
@@ -420,7 +414,6 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   S.env = G.env; S.envMipOffset = G.envMipOffset; S.envSize = G.envSize; S.envMips = G.envMips; S.sh = c->sh;
   S.reflOut = c->rtRefl; S.diffOut = c->rtDiff;
   hipLaunchKernelGGL(shadeKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, S);
-  hipLaunchKernelGGL(accumulateRayTotals, dim3(1), dim3(256), 0, s, c->rayCounter32, c->rayCounter);
   RT_HIP(hipGetLastError());
   return 0;
 }

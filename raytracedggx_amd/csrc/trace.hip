@@ -38,6 +38,7 @@ struct TraceArgs {
   const uint32_t* binCount; uint32_t numBins;
   int32_t* overflow;        // [entry][numBinsMax * RT_BIN] spill area for stacks deeper than RT_STACK
   uint32_t* rayTotals;       // 256 per-frame partial counters (+ RT_TRACE_STATS words from 256)
+  unsigned long long* runTotals;   // 256 running totals (rtggx_ray_total)
   uint32_t countRowBegin, countRowEnd, width;
   size_t spillStride;
 };
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
 
   // ray statistics: one fire-and-forget atomic per wave, spread over 256 words
   for (int o = 32; o > 0; o >>= 1) nRays += __shfl_down(nRays, o);
-  if (lane == 0 && nRays) atomicAdd(&A.rayTotals[bin & 255u], nRays);
+  if (lane == 0 && nRays) { atomicAdd(&A.rayTotals[bin & 255u], nRays); atomicAdd(&A.runTotals[bin & 255u], (unsigned long long)nRays); }
 #ifdef RT_TRACE_STATS
   for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); stSteal += __shfl_down(stSteal, o); stDeep = max(stDeep, (uint32_t)__shfl_down((int)stDeep, o)); }
   if (lane == 0) {   // lane node steps, lane leaf steps, wave iterations, waves, deepest stack, wave lifetime (sum, max), most iterations, steals
@@ -357,7 +358,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
     c->spillEntries = deepest - RT_STACK;
     RT_HIP(hipMalloc(&c->stackOverflow, (size_t)c->spillEntries * c->numBinsMax * RT_BIN * 4));
   }
-  T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32;
+  T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32; T.runTotals = c->rayCounter + 256;
   T.spillStride = (size_t)c->numBinsMax * RT_BIN;
   T.countRowBegin = countRays ? fp.rowBegin : 0u; T.countRowEnd = countRays ? fp.rowEnd : 0u; T.width = fp.W;
 #ifdef RT_TRACE_STATS

@@ -42,7 +42,8 @@ RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
   return (dy == 0 && dx > 0) || dy < 0;
 }
 
-__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end) {
+__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *largeCount = 0;      // the large-triangle list of rasterSmall starts empty
   const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < end) vd[i] = 0x00FFFFFF00000000ull;
 }
@@ -161,8 +162,7 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   passRows(fp, ROWS_GBUFFER, rb, re);
   const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
-  RT_HIP(hipMemsetAsync(c->largeCount, 0, sizeof(uint32_t), s));
-  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end);
+  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount);
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
   if (nt) {
     hipLaunchKernelGGL(rasterSmall, dim3((nt + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->mesh[0].verts, c->mesh[0].indices, c->mesh[0].numTris,
