@@ -65,11 +65,23 @@ static void invert4x4(const float* a /*row-major*/, float* out) {
 
 static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
 // Constants reach the device in rtggx_update_as; a caller that skips it still gets them, on the main stream.
-static int ensureParams(rtggx_context* c) {
-  if (c->slotUploaded) return 0;
-  const int r = uploadParams(c, c->slot, c->streamMain);
-  if (!r) c->slotUploaded = true;
-  return r;
+// The constants go up on stream B (which also runs the visibility pass); everything on the main stream that
+// consumes them is ordered behind the event.
+static int uploadParamsStreamB(rtggx_context* c) {
+  const int r = uploadParams(c, c->slot, c->streamAS);
+  if (r) return r;
+  c->slotUploaded = true;
+  RT_HIP(hipEventRecord(c->evAS, c->streamAS));
+  RT_HIP(hipStreamWaitEvent(c->streamMain, c->evAS, 0));
+  return 0;
+}
+static int ensureParams(rtggx_context* c) { return c->slotUploaded ? 0 : uploadParamsStreamB(c); }
+// The main stream has just been given work that reads the current visibility/depth buffer: stream B may not
+// overwrite that buffer (two frames from now) before this point.
+static int markVisRead(rtggx_context* c) {
+  RT_HIP(hipEventRecord(c->evVisRead[c->visIndex], c->streamMain));
+  c->visReadRecorded[c->visIndex] = true;
+  return 0;
 }
 
 static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t ni) {
@@ -127,12 +139,16 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   c->streamMain = c->ownMain;
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evFrameStart, hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
+  for (auto& e : c->evVisRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
-  RT_HIP(hipMalloc(&c->visDepth, n * 8)); RT_HIP(hipMalloc(&c->normal, n * 4)); RT_HIP(hipMalloc(&c->velocity, n * 4));
+  for (auto& b : c->visDepthBuf) { RT_HIP(hipMalloc(&b, n * 8)); RT_HIP(hipMemset(b, 0, n * 8)); }
+  c->visDepth = c->visDepthBuf[0];
+  RT_HIP(hipMalloc(&c->normal, n * 4)); RT_HIP(hipMalloc(&c->velocity, n * 4));
   RT_HIP(hipMalloc(&c->rtRefl, n * 4)); RT_HIP(hipMalloc(&c->rtDiff, n * 4)); RT_HIP(hipMalloc(&c->backbuffer, n * 4));
   RT_HIP(hipMalloc(&c->roughMetal, n * 2));
   RT_HIP(hipMalloc(&c->tss[0], n * 8)); RT_HIP(hipMalloc(&c->tss[1], n * 8)); RT_HIP(hipMalloc(&c->fltRfl, n * 8)); RT_HIP(hipMalloc(&c->fltDff, n * 8));
-  RT_HIP(hipMemset(c->visDepth, 0, n * 8)); RT_HIP(hipMemset(c->normal, 0, n * 4)); RT_HIP(hipMemset(c->velocity, 0, n * 4));
+  RT_HIP(hipMemset(c->normal, 0, n * 4)); RT_HIP(hipMemset(c->velocity, 0, n * 4));
   RT_HIP(hipMemset(c->rtRefl, 0, n * 4)); RT_HIP(hipMemset(c->rtDiff, 0, n * 4)); RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
   RT_HIP(hipMemset(c->roughMetal, 0, n * 2));
   RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
@@ -182,7 +198,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (auto& m : c->mesh) { hipFree(m.verts); hipFree(m.indices); hipFree(m.nodes); hipFree(m.nodes4); hipFree(m.tris); }
-  hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->visDepth); hipFree(c->normal); hipFree(c->velocity);
+  hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->visDepthBuf[0]); hipFree(c->visDepthBuf[1]); hipFree(c->normal); hipFree(c->velocity);
   hipFree(c->rtRefl); hipFree(c->rtDiff); hipFree(c->backbuffer); hipFree(c->roughMetal); hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   hipFree(c->rayQueue); hipFree(c->hitQueue); hipFree(c->binCount); hipFree(c->stackOverflow); hipFree(c->dummyRecord);
@@ -190,7 +206,7 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
-  hipEventDestroy(c->evAS); hipEventDestroy(c->evFrameStart);
+  hipEventDestroy(c->evAS); hipEventDestroy(c->evFrameStart); hipEventDestroy(c->evVis); hipEventDestroy(c->evVisRead[0]); hipEventDestroy(c->evVisRead[1]);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS);
   delete c;
 }
@@ -271,13 +287,9 @@ int rtggx_update_as(rtggx_context* c) {
   memcpy(fp.invWorld, c->invWorld, sizeof fp.invWorld);
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[0], c->streamAS);
-  const int r = uploadParams(c, c->slot, c->streamAS);
+  const int r = uploadParamsStreamB(c);
   if (r) return r;
-  c->slotUploaded = true;
   if (c->timing) hipEventRecord(c->tev[1], c->streamAS);
-  RT_HIP(hipEventRecord(c->evAS, c->streamAS));
-  // every consumer of the constants runs on the main stream behind this event
-  RT_HIP(hipStreamWaitEvent(c->streamMain, c->evAS, 0));
   return 0;
 }
 
@@ -291,8 +303,16 @@ int rtggx_render_visibility(rtggx_context* c) {
   if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
   { const int r = ensureParams(c); if (r) return r; }
   if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamMain); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
-  if (c->timing) hipEventRecord(c->tev[2], c->streamMain);
-  return launchVisibility(c, c->slots[c->slot], c->streamMain);
+  // Stream B: the pass writes the other visibility/depth buffer, so it overlaps whatever the main stream still has
+  // queued from the previous frame (the sample overlaps its two queues the same way, RayTracedGGX.cpp:302-353).
+  c->visIndex ^= 1u; c->visDepth = c->visDepthBuf[c->visIndex];
+  if (c->visReadRecorded[c->visIndex]) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evVisRead[c->visIndex], 0));
+  if (c->timing) hipEventRecord(c->tev[2], c->streamAS);
+  const int r = launchVisibility(c, c->slots[c->slot], c->streamAS);
+  if (c->timing) hipEventRecord(c->tev[13], c->streamAS);
+  RT_HIP(hipEventRecord(c->evVis, c->streamAS));
+  RT_HIP(hipStreamWaitEvent(c->streamMain, c->evVis, 0));
+  return r;
 }
 
 int rtggx_ray_trace(rtggx_context* c) {
@@ -302,14 +322,16 @@ int rtggx_ray_trace(rtggx_context* c) {
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamMain); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[3], c->streamMain);
-  return launchRayTrace(c, c->slots[c->slot], c->streamMain);
+  const int r = launchRayTrace(c, c->slots[c->slot], c->streamMain);
+  return r ? r : markVisRead(c);
 }
 
 int rtggx_denoise(rtggx_context* c, int useSharedMem) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_denoise: no frame constants"); return -1; }
   if (c->timing) hipEventRecord(c->tev[9], c->streamMain);   // start of denoise
-  return launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain);
+  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain);
+  return r ? r : markVisRead(c);
 }
 
 int rtggx_tone_map(rtggx_context* c) {
@@ -386,7 +408,7 @@ int rtggx_get_timings(rtggx_context* c, RtggxTimings* out) {
   RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   auto ms = [&](int a, int b) { float t = 0.0f; hipEventElapsedTime(&t, c->tev[a], c->tev[b]); return t; };
   RtggxTimings t;
-  t.update_as = ms(0, 1); t.visibility = ms(2, 3); t.ray_trace = ms(3, 9); t.spatial_refl_h = ms(9, 4); t.spatial_refl_v = ms(4, 5);
+  t.update_as = ms(0, 1); t.visibility = ms(2, 13); t.ray_trace = ms(3, 9); t.spatial_refl_h = ms(9, 4); t.spatial_refl_v = ms(4, 5);
   t.spatial_diff_h = ms(5, 6); t.spatial_diff_v = ms(6, 7); t.temporal = ms(7, 8); t.tone_map = ms(8, 10); t.frame = ms(2, 10);
   t.ray_trace_kernel = ms(11, 12);
   *out = t; c->lastTimings = t;

@@ -63,6 +63,8 @@ struct rtggx_context {
   uint32_t rowBegin = 0, rowEnd = 0;
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
   hipEvent_t evAS = nullptr, evFrameStart = nullptr;
+  hipEvent_t evVis = nullptr, evVisRead[2] = {nullptr, nullptr};   // visibility done (stream B -> main); last reader of visDepthBuf[i] done (main -> stream B)
+  bool visReadRecorded[2] = {false, false};
   bool externalStream = false;
 
   rt::MeshDev mesh[2];
@@ -71,7 +73,9 @@ struct rtggx_context {
   float* cosSinTab = nullptr;    // 512 floats: cos[256], sin[256]
 
   // render targets
-  unsigned long long* visDepth = nullptr;
+  unsigned long long* visDepth = nullptr;          // = visDepthBuf[visIndex]: the frame being rendered
+  unsigned long long* visDepthBuf[2] = {nullptr, nullptr};   // double-buffered so that the next frame's visibility pass can run
+  uint32_t visIndex = 0;                             // on stream B while this frame's ray trace and denoise still read theirs
   uint32_t *normal = nullptr, *velocity = nullptr, *rtRefl = nullptr, *rtDiff = nullptr, *backbuffer = nullptr;
   uint16_t* roughMetal = nullptr;
   uint2 *tss[2] = {nullptr, nullptr}, *fltRfl = nullptr, *fltDff = nullptr;
