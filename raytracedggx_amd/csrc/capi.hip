@@ -76,11 +76,11 @@ static int uploadParamsStreamB(rtggx_context* c) {
   return 0;
 }
 static int ensureParams(rtggx_context* c) { return c->slotUploaded ? 0 : uploadParamsStreamB(c); }
-// The main stream has just been given work that reads the current visibility/depth buffer: stream B may not
-// overwrite that buffer (two frames from now) before this point.
-static int markVisRead(rtggx_context* c) {
-  RT_HIP(hipEventRecord(c->evVisRead[c->visIndex], c->streamMain));
-  c->visReadRecorded[c->visIndex] = true;
+// The main stream has just been given work that reads the current input set (G-buffer, depth, traced images):
+// stream B may not overwrite that set (two frames from now) before this point.
+static int markSetRead(rtggx_context* c) {
+  RT_HIP(hipEventRecord(c->evSetRead[c->setIndex], c->streamMain));
+  c->setReadRecorded[c->setIndex] = true;
   return 0;
 }
 
@@ -139,18 +139,21 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   c->streamMain = c->ownMain;
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evFrameStart, hipEventDisableTiming));
-  RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
-  for (auto& e : c->evVisRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
+  for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
-  for (auto& b : c->visDepthBuf) { RT_HIP(hipMalloc(&b, n * 8)); RT_HIP(hipMemset(b, 0, n * 8)); }
-  c->visDepth = c->visDepthBuf[0];
-  RT_HIP(hipMalloc(&c->normal, n * 4)); RT_HIP(hipMalloc(&c->velocity, n * 4));
-  RT_HIP(hipMalloc(&c->rtRefl, n * 4)); RT_HIP(hipMalloc(&c->rtDiff, n * 4)); RT_HIP(hipMalloc(&c->backbuffer, n * 4));
-  RT_HIP(hipMalloc(&c->roughMetal, n * 2));
+  for (int i = 0; i < 2; ++i) {
+    RT_HIP(hipMalloc(&c->visDepthBuf[i], n * 8)); RT_HIP(hipMemset(c->visDepthBuf[i], 0, n * 8));
+    RT_HIP(hipMalloc(&c->normalBuf[i], n * 4)); RT_HIP(hipMemset(c->normalBuf[i], 0, n * 4));
+    RT_HIP(hipMalloc(&c->velocityBuf[i], n * 4)); RT_HIP(hipMemset(c->velocityBuf[i], 0, n * 4));
+    RT_HIP(hipMalloc(&c->rtReflBuf[i], n * 4)); RT_HIP(hipMemset(c->rtReflBuf[i], 0, n * 4));
+    RT_HIP(hipMalloc(&c->rtDiffBuf[i], n * 4)); RT_HIP(hipMemset(c->rtDiffBuf[i], 0, n * 4));
+    RT_HIP(hipMalloc(&c->roughMetalBuf[i], n * 2)); RT_HIP(hipMemset(c->roughMetalBuf[i], 0, n * 2));
+  }
+  c->selectSet(0);
+  RT_HIP(hipMalloc(&c->backbuffer, n * 4));
   RT_HIP(hipMalloc(&c->tss[0], n * 8)); RT_HIP(hipMalloc(&c->tss[1], n * 8)); RT_HIP(hipMalloc(&c->fltRfl, n * 8)); RT_HIP(hipMalloc(&c->fltDff, n * 8));
-  RT_HIP(hipMemset(c->normal, 0, n * 4)); RT_HIP(hipMemset(c->velocity, 0, n * 4));
-  RT_HIP(hipMemset(c->rtRefl, 0, n * 4)); RT_HIP(hipMemset(c->rtDiff, 0, n * 4)); RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
-  RT_HIP(hipMemset(c->roughMetal, 0, n * 2));
+  RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
   RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
   c->largeCapacity = 1u << 16;
   RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 40)); RT_HIP(hipMalloc(&c->largeCount, 4));
@@ -198,15 +201,16 @@ void rtggx_destroy(rtggx_context* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (auto& m : c->mesh) { hipFree(m.verts); hipFree(m.indices); hipFree(m.nodes); hipFree(m.nodes4); hipFree(m.tris); }
-  hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->visDepthBuf[0]); hipFree(c->visDepthBuf[1]); hipFree(c->normal); hipFree(c->velocity);
-  hipFree(c->rtRefl); hipFree(c->rtDiff); hipFree(c->backbuffer); hipFree(c->roughMetal); hipFree(c->tss[0]); hipFree(c->tss[1]);
+  hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->backbuffer);
+  for (int i = 0; i < 2; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
+  hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   hipFree(c->rayQueue); hipFree(c->hitQueue); hipFree(c->binCount); hipFree(c->stackOverflow); hipFree(c->dummyRecord);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
-  hipEventDestroy(c->evAS); hipEventDestroy(c->evFrameStart); hipEventDestroy(c->evVis); hipEventDestroy(c->evVisRead[0]); hipEventDestroy(c->evVisRead[1]);
+  hipEventDestroy(c->evAS); hipEventDestroy(c->evFrameStart); hipEventDestroy(c->evRT); hipEventDestroy(c->evSetRead[0]); hipEventDestroy(c->evSetRead[1]);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS);
   delete c;
 }
@@ -220,7 +224,7 @@ int rtggx_set_strip(rtggx_context* c, uint32_t rowBegin, uint32_t rowEnd) {
 
 int rtggx_set_stream(rtggx_context* c, void* stream) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   if (stream) { c->streamMain = (hipStream_t)stream; c->externalStream = true; }
   else { c->streamMain = c->ownMain; c->externalStream = false; }
   return 0;
@@ -235,7 +239,7 @@ int rtggx_set_mesh(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
 int rtggx_set_env(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* data, size_t bytes) {
   RT_CHECK_CTX(c);
   if (!data) { setError("rtggx_set_env: null data"); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   return decodeEnv(c, format, size, mips, data, bytes, c->streamMain);
 }
 
@@ -255,7 +259,7 @@ int rtggx_set_metallic(rtggx_context* c, uint32_t mesh, float metallic) {   // R
 
 int rtggx_build_as(rtggx_context* c) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   for (uint32_t i = 0; i < 2; ++i) { const int r = buildLbvh(c, i, c->streamAS); if (r) return r; }
   c->asBuilt = true; c->sceneDirty = true;
   return 0;
@@ -295,23 +299,21 @@ int rtggx_update_as(rtggx_context* c) {
 
 int rtggx_transform_sh(rtggx_context* c) {
   RT_CHECK_CTX(c);
-  return projectSH(c, c->streamMain);
+  return projectSH(c, c->streamAS);      // consumed by the shading kernel, which runs on stream B
 }
 
 int rtggx_render_visibility(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
   { const int r = ensureParams(c); if (r) return r; }
-  if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamMain); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
-  // Stream B: the pass writes the other visibility/depth buffer, so it overlaps whatever the main stream still has
-  // queued from the previous frame (the sample overlaps its two queues the same way, RayTracedGGX.cpp:302-353).
-  c->visIndex ^= 1u; c->visDepth = c->visDepthBuf[c->visIndex];
-  if (c->visReadRecorded[c->visIndex]) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evVisRead[c->visIndex], 0));
+  if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamAS); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
+  // Stream B renders into the other input set, so the pass overlaps whatever the main stream still has queued from
+  // the previous frame (the sample overlaps its two queues in the same spirit, RayTracedGGX.cpp:302-353).
+  c->selectSet(c->setIndex ^ 1u);
+  if (c->setReadRecorded[c->setIndex]) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
   if (c->timing) hipEventRecord(c->tev[2], c->streamAS);
   const int r = launchVisibility(c, c->slots[c->slot], c->streamAS);
   if (c->timing) hipEventRecord(c->tev[13], c->streamAS);
-  RT_HIP(hipEventRecord(c->evVis, c->streamAS));
-  RT_HIP(hipStreamWaitEvent(c->streamMain, c->evVis, 0));
   return r;
 }
 
@@ -319,11 +321,15 @@ int rtggx_ray_trace(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants || !c->asBuilt) { setError("rtggx_ray_trace: %s", c->asBuilt ? "no frame constants" : "rtggx_build_as has not been called"); return -1; }
   if (!c->env.texels) { setError("rtggx_ray_trace: no environment map"); return -1; }
-  if (c->sceneDirty) { const int r = uploadScene(c, c->streamMain); if (r) return r; }
+  if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
-  if (c->timing) hipEventRecord(c->tev[3], c->streamMain);
-  const int r = launchRayTrace(c, c->slots[c->slot], c->streamMain);
-  return r ? r : markVisRead(c);
+  if (c->timing) hipEventRecord(c->tev[3], c->streamAS);
+  const int r = launchRayTrace(c, c->slots[c->slot], c->streamAS);
+  if (c->timing) hipEventRecord(c->tev[14], c->streamAS);
+  // the denoiser (main stream) consumes this frame's G-buffer and traced images
+  RT_HIP(hipEventRecord(c->evRT, c->streamAS));
+  RT_HIP(hipStreamWaitEvent(c->streamMain, c->evRT, 0));
+  return r;
 }
 
 int rtggx_denoise(rtggx_context* c, int useSharedMem) {
@@ -331,7 +337,7 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
   if (!c->haveConstants) { setError("rtggx_denoise: no frame constants"); return -1; }
   if (c->timing) hipEventRecord(c->tev[9], c->streamMain);   // start of denoise
   const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain);
-  return r ? r : markVisRead(c);
+  return r ? r : markSetRead(c);
 }
 
 int rtggx_tone_map(rtggx_context* c) {
@@ -344,15 +350,14 @@ int rtggx_tone_map(rtggx_context* c) {
 
 int rtggx_sync(rtggx_context* c) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamAS));
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   return 0;
 }
 
 int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
   RT_CHECK_CTX(c);
   uint32_t h[256];
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   RT_HIP(hipMemcpy(h, c->rayCounter32, sizeof h, hipMemcpyDeviceToHost));
   uint64_t s = 0; for (auto v : h) s += v;
   *rays = s;
@@ -364,7 +369,7 @@ int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
 int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset) {
   RT_CHECK_CTX(c);
   if (n > 768) { setError("rtggx_debug_counters: at most 768 words"); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   RT_HIP(hipMemcpy(out, c->rayCounter32 + 256, (size_t)n * 4, hipMemcpyDeviceToHost));
   if (reset) RT_HIP(hipMemset(c->rayCounter32 + 256, 0, 768 * 4));
   return 0;
@@ -373,7 +378,7 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
 int rtggx_ray_total(rtggx_context* c, uint64_t* rays, int reset) {
   RT_CHECK_CTX(c);
   unsigned long long h[256];
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   RT_HIP(hipMemcpy(h, c->rayCounter + 256, sizeof h, hipMemcpyDeviceToHost));
   uint64_t s = 0; for (auto v : h) s += v;
   *rays = s;
@@ -395,7 +400,7 @@ int rtggx_enable_timing(rtggx_context* c, int mode) {
 }
 int rtggx_kernel_times(rtggx_context* c, float* ms, uint32_t capacity, uint32_t* count) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   const uint32_t n = c->kevCount < capacity ? c->kevCount : capacity;
   for (uint32_t i = 0; i < n; ++i) RT_HIP(hipEventElapsedTime(&ms[i], c->kevBegin[i], c->kevEnd[i]));
   *count = n;
@@ -408,7 +413,7 @@ int rtggx_get_timings(rtggx_context* c, RtggxTimings* out) {
   RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   auto ms = [&](int a, int b) { float t = 0.0f; hipEventElapsedTime(&t, c->tev[a], c->tev[b]); return t; };
   RtggxTimings t;
-  t.update_as = ms(0, 1); t.visibility = ms(2, 13); t.ray_trace = ms(3, 9); t.spatial_refl_h = ms(9, 4); t.spatial_refl_v = ms(4, 5);
+  t.update_as = ms(0, 1); t.visibility = ms(2, 13); t.ray_trace = ms(3, 14); t.spatial_refl_h = ms(9, 4); t.spatial_refl_v = ms(4, 5);
   t.spatial_diff_h = ms(5, 6); t.spatial_diff_v = ms(6, 7); t.temporal = ms(7, 8); t.tone_map = ms(8, 10); t.frame = ms(2, 10);
   t.ray_trace_kernel = ms(11, 12);
   *out = t; c->lastTimings = t;
@@ -504,6 +509,7 @@ int rtggx_bvh_root(rtggx_context* c, uint32_t slot, int32_t* root) { RT_CHECK_CT
 int rtggx_trace_rays(rtggx_context* c, const float* rays, uint32_t n, float* out) {
   RT_CHECK_CTX(c);
   if (!c->asBuilt || !c->haveConstants) { setError("rtggx_trace_rays: build_as / update_frame / update_as first"); return -1; }
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));   // the ray bins are shared with the frame path on stream B
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamMain); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
   float *dR, *dO;

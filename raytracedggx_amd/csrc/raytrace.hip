@@ -199,6 +199,7 @@ RT_DEV f2 calcBarycentrics(const f4 p[3], f2 ndc) {   // :204-225
 struct GenArgs {
   const unsigned long long* visDepth;
   uint32_t* normalOut; uint16_t* roughMetalOut; uint32_t* velocityOut; uint32_t* reflOut; uint32_t* diffOut;
+  const uint16_t* roughMetalPrev; const uint32_t* diffPrev;   // the other input set = what these targets held before this frame
   const float* verts0; const uint32_t* idx0; const float* verts1; const uint32_t* idx1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* cosSin;
@@ -259,7 +260,9 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
     }
     // G-buffer stores :552-554
     A.normalOut[pix] = packR10G10B10A2(N.x * 0.5f + 0.5f, N.y * 0.5f + 0.5f, N.z * 0.5f + 0.5f, hit ? 1.0f : 0.0f);
-    if (hit) A.roughMetalOut[pix] = (uint16_t)packR8G8(rghMtl.x, rghMtl.y);
+    // the reference leaves RoughMetal untouched where nothing is hit, and RayTracingOut1 where no diffuse ray is traced:
+    // with double-buffered targets "untouched" means carrying the previous frame's word over
+    A.roughMetalOut[pix] = hit ? (uint16_t)packR8G8(rghMtl.x, rghMtl.y) : A.roughMetalPrev[pix];
     A.velocityOut[pix] = packR16G16F(velocity.x, velocity.y);
 
     if (!hit) {
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
         rd.dx = dir.x; rd.dy = dir.y; rd.dz = dir.z; rd.tmax = 10000.0f;
         rd.pixel = (uint32_t)pix; rd.skip = skip; rd.flags = 1u;
         rd.wx = color.x * (1.0f - 0.04f); rd.wy = color.y * (1.0f - 0.04f); rd.wz = color.z * (1.0f - 0.04f);   // :532
-      }
+      } else A.diffOut[pix] = A.diffPrev[pix];
     }
   }
   // wave-level compaction into this wave's own bin (rt_queue.h): reflection rays first, then diffuse rays
@@ -397,6 +400,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
   GenArgs G;
   G.visDepth = c->visDepth; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
+  G.roughMetalPrev = c->roughMetalBuf[c->setIndex ^ 1u]; G.diffPrev = c->rtDiffBuf[c->setIndex ^ 1u];
   G.verts0 = c->mesh[0].verts; G.idx0 = c->mesh[0].indices; G.verts1 = c->mesh[1].verts; G.idx1 = c->mesh[1].indices;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
   G.rays = (RayRec*)c->rayQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;

@@ -63,8 +63,8 @@ struct rtggx_context {
   uint32_t rowBegin = 0, rowEnd = 0;
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
   hipEvent_t evAS = nullptr, evFrameStart = nullptr;
-  hipEvent_t evVis = nullptr, evVisRead[2] = {nullptr, nullptr};   // visibility done (stream B -> main); last reader of visDepthBuf[i] done (main -> stream B)
-  bool visReadRecorded[2] = {false, false};
+  hipEvent_t evRT = nullptr, evSetRead[2] = {nullptr, nullptr};   // ray trace done (stream B -> main); last reader of input set i done (main -> stream B)
+  bool setReadRecorded[2] = {false, false};
   bool externalStream = false;
 
   rt::MeshDev mesh[2];
@@ -73,11 +73,19 @@ struct rtggx_context {
   float* cosSinTab = nullptr;    // 512 floats: cos[256], sin[256]
 
   // render targets
-  unsigned long long* visDepth = nullptr;          // = visDepthBuf[visIndex]: the frame being rendered
-  unsigned long long* visDepthBuf[2] = {nullptr, nullptr};   // double-buffered so that the next frame's visibility pass can run
-  uint32_t visIndex = 0;                             // on stream B while this frame's ray trace and denoise still read theirs
+  // Everything the visibility and ray-tracing passes (stream B) write and the denoiser (main stream) reads exists
+  // twice, so that frame N+1's visibility + ray trace overlap frame N's denoise + tone map.  The unsuffixed pointers
+  // are set `setIndex`, the frame being rendered (toggled by rtggx_render_visibility).
+  unsigned long long* visDepth = nullptr;
   uint32_t *normal = nullptr, *velocity = nullptr, *rtRefl = nullptr, *rtDiff = nullptr, *backbuffer = nullptr;
   uint16_t* roughMetal = nullptr;
+  unsigned long long* visDepthBuf[2] = {nullptr, nullptr};
+  uint32_t *normalBuf[2] = {nullptr, nullptr}, *velocityBuf[2] = {nullptr, nullptr}, *rtReflBuf[2] = {nullptr, nullptr}, *rtDiffBuf[2] = {nullptr, nullptr};
+  uint16_t* roughMetalBuf[2] = {nullptr, nullptr};
+  uint32_t setIndex = 0;
+  void selectSet(uint32_t i) {
+    setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
+  }
   uint2 *tss[2] = {nullptr, nullptr}, *fltRfl = nullptr, *fltDff = nullptr;
   uint32_t frameParity = 0;
 
