@@ -1,7 +1,7 @@
-for f in gpurun_in/lib_v_*.so; do cp $f raytracedggx_amd/librtggx.so; timeout -k 10 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $f <<'PY'
+for e in RTGGX_PLOC_RADIUS=4 RTGGX_PLOC_RADIUS=8 RTGGX_PLOC_RADIUS=16 RTGGX_PLOC_RADIUS=32 RTGGX_PLOC_RADIUS=64 RTGGX_PLOC_RADIUS=128; do env $e timeout -k 10 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $e <<'PY'
 import json,sys
 for l in open("gpurun_out/sw.log"):
     if l.startswith("{"):
-        d=json.loads(l); p=d["passes_ms"]; print(sys.argv[1], "frame %.4f  refl_v %.4f diff_v %.4f refl_h %.4f" % (d["ms_per_step"], p["spatial_refl_v"], p["spatial_diff_v"], p["spatial_refl_h"]))
+        d=json.loads(l); p=d["passes_ms"]; print(sys.argv[1], "frame %.4f  kernel(ring) %.4f | serial: vis %.4f rt %.4f trace %.4f" % (d["ms_per_step"], d["roofline"]["kernel_ms"], p["visibility"], p["ray_trace"], p["ray_trace_kernel"]))
 PY
 done

@@ -145,6 +145,75 @@ __global__ void fitKernel(int n, const uint32_t* __restrict__ order, const float
   }
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) ------------------------------------
+// Agglomerative build over the Morton-ordered triangles: every cluster looks RT_PLOC_RADIUS positions to either side
+// for the partner that gives the smallest merged box; mutual choices merge into a new node; the survivors are
+// compacted (order kept) and the step repeats until one cluster is left.  Trees come out close to a SAH sweep
+// build -- on the bunny a third fewer traversal steps per ray than the Karras radix tree (profiles/r01_d) -- and the
+// build is off the frame path.  Everything is deterministic: ties go to the lower position, node indices come from
+// prefix sums.
+#define RT_PLOC_RADIUS 16
+RT_DEV float mergedArea(const float* a, const float* b) {
+  const float ex = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), ey = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), ez = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+  return (ex * ey + ey * ez) + ez * ex;
+}
+__global__ void plocInit(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, int32_t* __restrict__ clRef, float* __restrict__ clBox) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  clRef[s] = ~s;
+  for (int k = 0; k < 6; ++k) clBox[6 * (size_t)s + k] = triBox[6 * (size_t)order[s] + k];
+}
+__global__ void plocNearest(int m, int radius, const float* __restrict__ clBox, int32_t* __restrict__ nn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  float mine[6];
+  for (int k = 0; k < 6; ++k) mine[k] = clBox[6 * (size_t)i + k];
+  float best = __builtin_inff(); int bj = -1;
+  const int lo = max(i - radius, 0), hi = min(i + radius, m - 1);
+  for (int j = lo; j <= hi; ++j) {
+    if (j == i) continue;
+    const float d = mergedArea(mine, clBox + 6 * (size_t)j);
+    if (d < best) { best = d; bj = j; }
+  }
+  nn[i] = bj;
+}
+__global__ void plocFlags(int m, const int32_t* __restrict__ nn, uint32_t* __restrict__ keep, uint32_t* __restrict__ merge) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int j = nn[i];
+  const bool mutual = j >= 0 && nn[j] == i;
+  merge[i] = mutual && i < j ? 1u : 0u;        // the lower position carries the new node
+  keep[i] = mutual && i > j ? 0u : 1u;         // the higher one disappears
+}
+// keepPos / mergePos: exclusive prefix sums of the flags (the flags themselves are recovered from nn)
+__global__ void plocScatter(int m, int nodeBase, const int32_t* __restrict__ nn, const uint32_t* __restrict__ keepPos, const uint32_t* __restrict__ mergePos,
+                            const int32_t* __restrict__ clRef, const float* __restrict__ clBox, int32_t* __restrict__ clRefOut, float* __restrict__ clBoxOut,
+                            int32_t* __restrict__ left, int32_t* __restrict__ right, int32_t* __restrict__ nodeParent, int32_t* __restrict__ leafParent,
+                            float* __restrict__ nodeBox) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int j = nn[i];
+  const bool mutual = j >= 0 && nn[j] == i;
+  if (mutual && i > j) return;
+  const uint32_t p = keepPos[i];
+  if (mutual) {
+    const int node = nodeBase + (int)mergePos[i];
+    const int32_t L = clRef[i], R = clRef[j];
+    left[node] = L; right[node] = R;
+    if (L < 0) leafParent[~L] = node; else nodeParent[L] = node;
+    if (R < 0) leafParent[~R] = node; else nodeParent[R] = node;
+    for (int k = 0; k < 3; ++k) {
+      const float mn = fminf(clBox[6 * (size_t)i + k], clBox[6 * (size_t)j + k]), mx = fmaxf(clBox[6 * (size_t)i + 3 + k], clBox[6 * (size_t)j + 3 + k]);
+      nodeBox[6 * (size_t)node + k] = mn; nodeBox[6 * (size_t)node + 3 + k] = mx;
+      clBoxOut[6 * (size_t)p + k] = mn; clBoxOut[6 * (size_t)p + 3 + k] = mx;
+    }
+    clRefOut[p] = node;
+  } else {
+    clRefOut[p] = clRef[i];
+    for (int k = 0; k < 6; ++k) clBoxOut[6 * (size_t)p + k] = clBox[6 * (size_t)i + k];
+  }
+}
+
 // Leaf depth = number of ancestors = the most stack entries a traversal reaching that leaf can hold.
 __global__ void depthKernel(int n, const int32_t* __restrict__ nodeParent, const int32_t* __restrict__ leafParent, uint32_t* __restrict__ maxDepth) {
   const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,12 +321,45 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   hipLaunchKernelGGL(emitTris, dim3(nb), dim3(256), 0, s, (int)n, order[cur], m.verts, m.indices, m.tris);
   if (n == 1) m.root = ~0;
   else {
-    hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, s, codes[cur], (int)n, left, right, nodeParent, leafParent);
-    hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, leafParent, nodeBox, arrive);
+    static const bool radixTree = getenv("RTGGX_BVH_RADIX_TREE") != nullptr;     // A/B switch: the Karras tree this build started with
+    int32_t root = 0;
+    if (radixTree) {
+      hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, s, codes[cur], (int)n, left, right, nodeParent, leafParent);
+      hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, leafParent, nodeBox, arrive);
+    } else {
+      int32_t *clRef[2], *nn; float* clBox[2]; uint32_t *keepPos, *mergePos;
+      RT_HIP(hipMalloc(&clRef[0], 4 * (size_t)n)); RT_HIP(hipMalloc(&clRef[1], 4 * (size_t)n)); RT_HIP(hipMalloc(&nn, 4 * (size_t)n));
+      RT_HIP(hipMalloc(&clBox[0], 24 * (size_t)n)); RT_HIP(hipMalloc(&clBox[1], 24 * (size_t)n));
+      RT_HIP(hipMalloc(&keepPos, 4 * (size_t)n)); RT_HIP(hipMalloc(&mergePos, 4 * (size_t)n));
+      hipLaunchKernelGGL(plocInit, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, clRef[0], clBox[0]);
+      int m = (int)n, nodeBase = 0, a = 0;
+      const int radius = getenv("RTGGX_PLOC_RADIUS") ? atoi(getenv("RTGGX_PLOC_RADIUS")) : RT_PLOC_RADIUS;
+      while (m > 1) {
+        const dim3 g((m + 255) / 256);
+        hipLaunchKernelGGL(plocNearest, g, dim3(256), 0, s, m, radius, clBox[a], nn);
+        hipLaunchKernelGGL(plocFlags, g, dim3(256), 0, s, m, nn, keepPos, mergePos);
+        uint32_t lastFlags[2], lastPos[2];     // totals = last exclusive prefix + last flag
+        RT_HIP(hipMemcpyAsync(&lastFlags[0], keepPos + (m - 1), 4, hipMemcpyDeviceToHost, s)); RT_HIP(hipMemcpyAsync(&lastFlags[1], mergePos + (m - 1), 4, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, s, keepPos, (uint32_t)m);
+        hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, s, mergePos, (uint32_t)m);
+        RT_HIP(hipMemcpyAsync(&lastPos[0], keepPos + (m - 1), 4, hipMemcpyDeviceToHost, s)); RT_HIP(hipMemcpyAsync(&lastPos[1], mergePos + (m - 1), 4, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(plocScatter, g, dim3(256), 0, s, m, nodeBase, nn, keepPos, mergePos, clRef[a], clBox[a], clRef[a ^ 1], clBox[a ^ 1],
+                           left, right, nodeParent, leafParent, nodeBox);
+        RT_HIP(hipStreamSynchronize(s));
+        const int kept = (int)(lastPos[0] + lastFlags[0]), merged = (int)(lastPos[1] + lastFlags[1]);
+        if (merged <= 0 || kept != m - merged) { setError("buildBvh: clustering made no progress (%d clusters, %d merges, %d kept)", m, merged, kept); return -3; }
+        nodeBase += merged; m = kept; a ^= 1;
+      }
+      root = (int32_t)n - 2;                      // the last node created
+      const int32_t none = -1;
+      RT_HIP(hipMemcpyAsync(nodeParent + root, &none, 4, hipMemcpyHostToDevice, s));
+      RT_HIP(hipStreamSynchronize(s));
+      hipFree(clRef[0]); hipFree(clRef[1]); hipFree(nn); hipFree(clBox[0]); hipFree(clBox[1]); hipFree(keepPos); hipFree(mergePos);
+    }
     hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeBox, m.nodes);
     hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, nodeBox, m.nodes4);
     hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, s, (int)n, nodeParent, leafParent, arrive + n);
-    m.root = 0;
+    m.root = root;
   }
   RT_HIP(hipGetLastError());
   RT_HIP(hipMemcpyAsync(&m.depth, arrive + n, 4, hipMemcpyDeviceToHost, s));

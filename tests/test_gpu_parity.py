@@ -138,11 +138,11 @@ def _bvh_check(nodes_u32, tris_u32, root, num_tris):
     tv = tris_u32.view(np.float32).reshape(-1, 16)[:, :9].reshape(-1, 3, 3)
     prims = tris_u32[:, 12]
     assert sorted(prims.tolist()) == list(range(num_tris)), "every primitive in exactly one leaf"
-    assert root == 0 and nodes.shape[0] == num_tris - 1
+    assert 0 <= root < nodes.shape[0] == num_tris - 1
     tmin, tmax = tv.min(axis=1), tv.max(axis=1)
     # subtree bounds, bottom-up by explicit stack; also counts leaves and the depth
     bmin = np.zeros((nodes.shape[0], 3)); bmax = np.zeros((nodes.shape[0], 3)); done = np.zeros(nodes.shape[0], bool)
-    depth_max, leaves, stack = 0, 0, [(0, 1, False)]
+    depth_max, leaves, stack = 0, 0, [(root, 1, False)]
     while stack:
         n, d, visited = stack.pop()
         depth_max = max(depth_max, d)
@@ -209,7 +209,7 @@ def test_lbvh_structure_and_device_traversal(built):
     try:
         p.frame()
         depth = _bvh_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH_TRIS1), p.ctx.bvh_root(1), 69666)
-        assert depth <= 62, "a Karras LBVH over 30 Morton + 32 index bits cannot be deeper; got %d" % depth
+        assert depth <= 48, "unexpectedly deep tree for 69666 triangles: %d levels" % depth
         _bvh_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH_TRIS0), p.ctx.bvh_root(0), 12)
         used = _bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH4_NODES1), p.ctx.bvh_root(1))
         assert 69665 // 3 <= used <= 69665, "4-wide nodes: %d" % used
