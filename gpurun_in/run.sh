@@ -1,4 +1,5 @@
-for e in RTGGX_PLOC_RADIUS=4 RTGGX_PLOC_RADIUS=8 RTGGX_PLOC_RADIUS=16 RTGGX_PLOC_RADIUS=32 RTGGX_PLOC_RADIUS=64 RTGGX_PLOC_RADIUS=128; do env $e timeout -k 10 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $e <<'PY'
+timeout -k 10 400 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -n 3 gpurun_out/t.log
+for e in X=1; do env $e timeout -k 10 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $e <<'PY'
 import json,sys
 for l in open("gpurun_out/sw.log"):
     if l.startswith("{"):

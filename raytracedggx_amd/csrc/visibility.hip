@@ -63,59 +63,109 @@ RT_DEV unsigned long long fragmentKey(long long PX, long long PY, const long lon
   return ((unsigned long long)d24 << 32) | word;
 }
 
+// Small triangles (bounding box <= RT_SMALL_BOX pixels), balanced over the lanes of a wave.  Phase 1: one lane per
+// triangle does the set-up (transform, snap, cull, box) and parks it in LDS.  Phase 2: the candidate pixels of the
+// wave's 64 triangles form one list (prefix sum of the box sizes); lane l takes candidates l, l + 64, ...: finds the
+// triangle by binary search in the prefix sums and the pixel inside the box with a multiply-shift division.  The
+// per-thread box loop this replaces ran as long as the largest box in the wave (42 us on the 1080p bunny frame).
+#define RT_SMALL_BOX 1024
+struct __attribute__((aligned(16))) TriSetup {
+  int32_t X[3], Y[3]; float z[3]; uint32_t word;
+  int32_t px0, py0; uint32_t bwTl /* box width | top-left flags << 16 */, magic /* ceil(2^24 / box width) */;
+  double invA;
+};
 __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict__ fpp, uint32_t rowBegin, uint32_t rowEnd, const float* __restrict__ v0, const uint32_t* __restrict__ i0, uint32_t nt0,
                                                    const float* __restrict__ v1, const uint32_t* __restrict__ i1, uint32_t nt1,
                                                    unsigned long long* __restrict__ vd, LargeTri* __restrict__ large,
                                                    uint32_t* __restrict__ largeCount, uint32_t largeCap) {
+  __shared__ TriSetup setupMem[256];
+  __shared__ uint32_t prefixMem[256];
   const FrameParams& fp = *fpp;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  TriSetup* const setup = setupMem + wave * 64; uint32_t* const prefix = prefixMem + wave * 64;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nt0 + nt1) return;
-  const uint32_t inst = t < nt0 ? 0u : 1u;
-  const uint32_t prim = inst ? t - nt0 : t;
-  const float* verts = inst ? v1 : v0;
-  const uint32_t* idx = inst ? i1 : i0;
-  const M4 wvp = cbLoad4x4(fp.po[inst].WorldViewProj);
-  const float bx = fp.po[inst].ProjBias[0], by = fp.po[inst].ProjBias[1];
-  long long X[3], Y[3]; float z[3];
-  bool ok = true;
+  uint32_t cnt = 0;
+  if (t < nt0 + nt1) {
+    const uint32_t inst = t < nt0 ? 0u : 1u;
+    const uint32_t prim = inst ? t - nt0 : t;
+    const float* verts = inst ? v1 : v0;
+    const uint32_t* idx = inst ? i1 : i0;
+    const M4 wvp = cbLoad4x4(fp.po[inst].WorldViewProj);
+    const float bx = fp.po[inst].ProjBias[0], by = fp.po[inst].ProjBias[1];
+    long long X[3], Y[3]; float z[3];
+    bool ok = true;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const RVert r = rasterVertex(verts + 6 * (size_t)idx[3 * (size_t)prim + k], wvp, bx, by, fp.W, fp.H);
-    X[k] = r.X; Y[k] = r.Y; z[k] = r.z; ok = ok && r.ok;
-  }
-  if (!ok) return;
-  const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
-  if (area2 <= 0) return;
-  const long long minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
-  const long long minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
-  long long px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
-  long long py0 = (minY - 128 + 255) >> 8, py1 = (maxY - 128) >> 8;
-  px0 = max(px0, 0ll); py0 = max(py0, (long long)rowBegin);
-  px1 = min(px1, (long long)fp.W - 1); py1 = min(py1, (long long)rowEnd - 1);
-  if (px0 > px1 || py0 > py1) return;
-  const uint32_t word = ((inst << 24) | prim) + 1u;
-  const long long area = (px1 - px0 + 1) * (py1 - py0 + 1);
-  if (area > 256) {
-    const uint32_t slot = atomicAdd(largeCount, 1u);
-    if (slot < largeCap) {
-      LargeTri lt;
-      for (int k = 0; k < 3; ++k) { lt.X[k] = (int32_t)X[k]; lt.Y[k] = (int32_t)Y[k]; lt.z[k] = z[k]; }
-      lt.word = word;
-      large[slot] = lt;
-      return;
+    for (int k = 0; k < 3; ++k) {
+      const RVert r = rasterVertex(verts + 6 * (size_t)idx[3 * (size_t)prim + k], wvp, bx, by, fp.W, fp.H);
+      X[k] = r.X; Y[k] = r.Y; z[k] = r.z; ok = ok && r.ok;
     }
-    // queue full: fall through and rasterise here (correct, slow)
-  }
-  const bool tl0 = isTopLeft(X[1], Y[1], X[2], Y[2]), tl1 = isTopLeft(X[2], Y[2], X[0], Y[0]), tl2 = isTopLeft(X[0], Y[0], X[1], Y[1]);
-  const double invA = 1.0 / (double)area2;
-  const double z0 = (double)z[0], dz1 = (double)z[1] - z0, dz2 = (double)z[2] - z0;
-  for (long long py = py0; py <= py1; ++py)
-    for (long long px = px0; px <= px1; ++px) {
-      const unsigned long long key = fragmentKey(px * 256 + 128, py * 256 + 128, X, Y, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
-      if (key == ~0ull) continue;
-      unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
-      if (key < *dst) atomicMin(dst, key);
+    const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+    if (ok && area2 > 0) {
+      const long long minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
+      const long long minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
+      long long px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
+      long long py0 = (minY - 128 + 255) >> 8, py1 = (maxY - 128) >> 8;
+      px0 = max(px0, 0ll); py0 = max(py0, (long long)rowBegin);
+      px1 = min(px1, (long long)fp.W - 1); py1 = min(py1, (long long)rowEnd - 1);
+      if (px0 <= px1 && py0 <= py1) {
+        const uint32_t word = ((inst << 24) | prim) + 1u;
+        const long long area = (px1 - px0 + 1) * (py1 - py0 + 1);
+        const bool tl0 = isTopLeft(X[1], Y[1], X[2], Y[2]), tl1 = isTopLeft(X[2], Y[2], X[0], Y[0]), tl2 = isTopLeft(X[0], Y[0], X[1], Y[1]);
+        const double invA = 1.0 / (double)area2;
+        bool here = area <= RT_SMALL_BOX;
+        if (!here) {
+          const uint32_t slot = atomicAdd(largeCount, 1u);
+          if (slot < largeCap) {
+            LargeTri lt;
+            for (int k = 0; k < 3; ++k) { lt.X[k] = (int32_t)X[k]; lt.Y[k] = (int32_t)Y[k]; lt.z[k] = z[k]; }
+            lt.word = word;
+            large[slot] = lt;
+          } else {
+            // queue full (more than 65536 big triangles): rasterise it right here -- correct, slow
+            const double z0 = (double)z[0], dz1 = (double)z[1] - z0, dz2 = (double)z[2] - z0;
+            for (long long py = py0; py <= py1; ++py)
+              for (long long px = px0; px <= px1; ++px) {
+                const unsigned long long key = fragmentKey(px * 256 + 128, py * 256 + 128, X, Y, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
+                if (key == ~0ull) continue;
+                unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
+                if (key < *dst) atomicMin(dst, key);
+              }
+          }
+        } else {
+          TriSetup ts;
+          for (int k = 0; k < 3; ++k) { ts.X[k] = (int32_t)X[k]; ts.Y[k] = (int32_t)Y[k]; ts.z[k] = z[k]; }
+          ts.word = word; ts.px0 = (int32_t)px0; ts.py0 = (int32_t)py0;
+          const uint32_t bw = (uint32_t)(px1 - px0 + 1);
+          ts.bwTl = bw | (tl0 ? 1u << 16 : 0u) | (tl1 ? 1u << 17 : 0u) | (tl2 ? 1u << 18 : 0u);
+          ts.magic = ((1u << 24) + bw - 1u) / bw;
+          ts.invA = invA;
+          setup[lane] = ts;
+          cnt = (uint32_t)area;
+        }
+      }
     }
+  }
+  // exclusive prefix sum of the candidate counts over the wave
+  uint32_t inc = cnt;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += v; }
+  prefix[lane] = inc - cnt;
+  const uint32_t total = (uint32_t)__shfl((int)inc, 63);
+  for (uint32_t w = lane; w < total; w += 64u) {
+    uint32_t lo = 0;                       // last triangle whose candidates start at or before w (its count is > 0)
+#pragma unroll
+    for (uint32_t step = 32u; step > 0u; step >>= 1) if (prefix[lo + step] <= w) lo += step;
+    const TriSetup& S = setup[lo];
+    const uint32_t q = w - prefix[lo], bw = S.bwTl & 0xFFFFu;
+    const uint32_t ry = (q * S.magic) >> 24, rx = q - ry * bw;       // q / bw exactly: q < 1024, bw <= 1024
+    const long long px = S.px0 + (long long)rx, py = S.py0 + (long long)ry;
+    const long long X[3] = {S.X[0], S.X[1], S.X[2]}, Y[3] = {S.Y[0], S.Y[1], S.Y[2]};
+    const double z0 = (double)S.z[0], dz1 = (double)S.z[1] - z0, dz2 = (double)S.z[2] - z0;
+    const unsigned long long key = fragmentKey(px * 256 + 128, py * 256 + 128, X, Y, (S.bwTl >> 16) & 1u, (S.bwTl >> 17) & 1u, (S.bwTl >> 18) & 1u,
+                                               S.invA, z0, dz1, dz2, S.word);
+    if (key == ~0ull) continue;
+    unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
+    if (key < *dst) atomicMin(dst, key);
+  }
 }
 
 __global__ void __launch_bounds__(256) rasterLarge(const FrameParams* __restrict__ fpp, uint32_t rowBegin, uint32_t rowEnd, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
