@@ -98,6 +98,14 @@ def main():
         alg_bytes = r.trace_kernel_algorithmic_bytes(rays_per_launch)
         frame_bytes = r.frame_algorithmic_bytes(rows)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+        # HBM bytes per launch from hardware counters: collected in separate rocprofv3 --pmc runs of this same workload
+        # (tools/pmc.sh), committed under profiles/; null for other workloads
+        traffic, traffic_source = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_pmc_traffic.json")
+        if os.path.exists(tpath) and (W, H, args.mesh, world) == (1920, 1080, "bunny.obj", 1):
+            with open(tpath) as f:
+                traffic = json.load(f)["kernels"]["rt::traceKernel"]["traffic_bytes"]
+            traffic_source = "profiles/r01_e_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
         out = {
             "metric": "Mrays/s + ms/frame, bunny 1920x1080 1spp+denoise, 1/2/4/8 GPUs",
@@ -109,7 +117,7 @@ def main():
                        "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
                          "note": "dependent-gather kernel: bound by L1 request rate and latency, not by HBM (DESIGN.md 'Roofline')",
                          "frame": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                                    "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Hardware-counter passes over a few frames of the bench workload (run on the GPU box through gpurun).
-#   tools/pmc.sh <outdir> [kernel-name-substring]
+#   tools/pmc.sh <outdir> [first-group [last-group]]
 # One rocprofv3 run per counter group (the SQ block has 8 slots, TCC 4), counters only -- never combined with the
 # trace domains (MI355X_MICROARCH.md "rocprofv3 PMC slots").  tools/pmc_report.py sums the CSVs per kernel.
 set -e
@@ -17,10 +17,14 @@ groups=(
   "TCC_HIT TCC_MISS TCC_REQ TCC_EA_RDREQ"
   "TCC_EA_RDREQ_32B TCC_EA_WRREQ TCC_EA_WRREQ_64B TCC_READ"
   "GRBM_GUI_ACTIVE GRBM_COUNT"
+  "FETCH_SIZE"      # KB; on gfx950 x2 for wide coalesced reads (MI355X_MICROARCH.md "HBM")
+  "WRITE_SIZE"      # KB
 )
+first=${2:-1}; last=${3:-${#groups[@]}}
 i=0
 for g in "${groups[@]}"; do
   i=$((i + 1))
+  if [ $i -lt $first ] || [ $i -gt $last ]; then continue; fi
   rocprofv3 --pmc $g -d "$out/g$i" -o run --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > "$out/g$i.log" 2>&1 || echo "group $i failed (see $out/g$i.log)"
   echo "group $i done"
 done
