@@ -167,9 +167,12 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     const uint32_t tiles = ((width + 15) / 16) * ((height + 15) / 16);
     c->numBinsMax = tiles * 4u;
     if (c->numBinsMax < 64u) c->numBinsMax = 64u;            // room for rtggx_trace_rays batches on tiny frames
-    RT_HIP(hipMalloc(&c->rayQueue, (size_t)c->numBinsMax * 128 * 64));
-    RT_HIP(hipMalloc(&c->hitQueue, (size_t)c->numBinsMax * 128 * 16));
-    RT_HIP(hipMalloc(&c->binCount, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCount, 0, (size_t)c->numBinsMax * 4));
+    for (int i = 0; i < 2; ++i) {
+      RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * 128 * 64));
+      RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * 128 * 16));
+      RT_HIP(hipMalloc(&c->binCountBuf[i], (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCountBuf[i], 0, (size_t)c->numBinsMax * 4));
+    }
+    c->selectSet(0);
     RT_HIP(hipMalloc(&c->dEnvMipOffset, 16 * 4)); RT_HIP(hipMemset(c->dEnvMipOffset, 0, 16 * 4));
     RT_HIP(hipMalloc(&c->dummyRecord, 128)); RT_HIP(hipMemset(c->dummyRecord, 0, 128));
   }
@@ -205,7 +208,8 @@ void rtggx_destroy(rtggx_context* c) {
   for (int i = 0; i < 2; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
-  hipFree(c->rayQueue); hipFree(c->hitQueue); hipFree(c->binCount); hipFree(c->stackOverflow); hipFree(c->dummyRecord);
+  for (int i = 0; i < 2; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
+  hipFree(c->stackOverflow); hipFree(c->dummyRecord);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
@@ -324,12 +328,14 @@ int rtggx_ray_trace(rtggx_context* c) {
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[3], c->streamAS);
-  const int r = launchRayTrace(c, c->slots[c->slot], c->streamAS);
-  if (c->timing) hipEventRecord(c->tev[14], c->streamAS);
-  // the denoiser (main stream) consumes this frame's G-buffer and traced images
+  int r = launchRayTrace(c, c->slots[c->slot], c->streamAS);
+  // stream B runs ahead with ray generation and traversal; shading and the denoiser consume the bins, the G-buffer
+  // and the traced images on the main stream
   RT_HIP(hipEventRecord(c->evRT, c->streamAS));
   RT_HIP(hipStreamWaitEvent(c->streamMain, c->evRT, 0));
-  return r;
+  if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain);
+  if (c->timing) hipEventRecord(c->tev[14], c->streamMain);
+  return r ? r : markSetRead(c);
 }
 
 int rtggx_denoise(rtggx_context* c, int useSharedMem) {

@@ -412,12 +412,21 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[12], s);
   if (ring) hipEventRecord(c->kevEnd[c->kevCount++], s);
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
+  uint32_t rb, re;
+  passRows(fp, ROWS_GBUFFER, rb, re);
+  if (re <= rb) return 0;
+  const uint32_t numTiles = ((fp.W + 15) / 16) * ((re - rb + 15) / 16);
   ShadeArgs S;
   S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitRec*)c->hitQueue; S.binCount = c->binCount;
-  S.verts0 = G.verts0; S.idx0 = G.idx0; S.verts1 = G.verts1; S.idx1 = G.idx1;
-  S.env = G.env; S.envMipOffset = G.envMipOffset; S.envSize = G.envSize; S.envMips = G.envMips; S.sh = c->sh;
+  S.verts0 = c->mesh[0].verts; S.idx0 = c->mesh[0].indices; S.verts1 = c->mesh[1].verts; S.idx1 = c->mesh[1].indices;
+  S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;
   S.reflOut = c->rtRefl; S.diffOut = c->rtDiff;
-  hipLaunchKernelGGL(shadeKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, S);
+  hipLaunchKernelGGL(shadeKernel, dim3(numTiles), dim3(256), 0, s, c->dParams + c->slot, S);
   RT_HIP(hipGetLastError());
   return 0;
 }

@@ -83,8 +83,11 @@ struct rtggx_context {
   uint32_t *normalBuf[2] = {nullptr, nullptr}, *velocityBuf[2] = {nullptr, nullptr}, *rtReflBuf[2] = {nullptr, nullptr}, *rtDiffBuf[2] = {nullptr, nullptr};
   uint16_t* roughMetalBuf[2] = {nullptr, nullptr};
   uint32_t setIndex = 0;
+  void *rayQueueBuf[2] = {nullptr, nullptr}, *hitQueueBuf[2] = {nullptr, nullptr};   // ray bins: written on stream B, shaded on the main stream
+  uint32_t* binCountBuf[2] = {nullptr, nullptr};
   void selectSet(uint32_t i) {
     setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
+    rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
   }
   uint2 *tss[2] = {nullptr, nullptr}, *fltRfl = nullptr, *fltDff = nullptr;
   uint32_t frameParity = 0;
@@ -149,7 +152,8 @@ int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s);
 int uploadScene(rtggx_context* c, hipStream_t s);
 int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s);
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
-int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s);
+int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s);   // ray generation + traversal
+int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s);      // hit / miss shading of the traced bins
 int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s);
 int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s);
 int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s);
