@@ -409,7 +409,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   if (c->timing) hipEventRecord(c->tev[11], s);
   const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size();
   if (ring) hipEventRecord(c->kevBegin[c->kevCount], s);
-  { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true); if (r) return r; }
+  { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true, tilesX, tilesY); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[12], s);
   if (ring) hipEventRecord(c->kevEnd[c->kevCount++], s);
   RT_HIP(hipGetLastError());
@@ -456,7 +456,7 @@ int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays,
   const uint32_t numBins = (((n + RT_BIN - 1u) / RT_BIN) + 3u) & ~3u;   // whole tiles of four bins
   RT_HIP(hipMemsetAsync(c->binCount, 0, (size_t)numBins * 4, s));
   hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, c->binCount);
-  { const int r = launchTrace(c, fp, s, numBins, false); if (r) return r; }
+  { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u); if (r) return r; }
   hipLaunchKernelGGL(exportTestHits, dim3((n + 255) / 256), dim3(256), 0, s, (const HitRec*)c->hitQueue, n, dOut);
   RT_HIP(hipGetLastError());
   return 0;

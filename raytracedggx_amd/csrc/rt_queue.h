@@ -24,6 +24,6 @@ struct __attribute__((aligned(16))) HitRec { float t, b1, b2; uint32_t id; /* (i
 
 // Persistent traversal of the rays in bins [0, numBins) (trace.hip).  countRays: add the rays of rows
 // [fp.rowBegin, fp.rowEnd) to the per-frame counters.
-int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays);
+int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY);
 
 }  // namespace rt

@@ -41,6 +41,7 @@ struct TraceArgs {
   unsigned long long* runTotals;   // 256 running totals (rtggx_ray_total)
   uint32_t countRowBegin, countRowEnd, width;
   size_t spillStride;
+  uint32_t tilesX, tilesY;   // tile grid of the frame (4 bins per 16x16 tile); tilesX == 0: bins are a plain list (rtggx_trace_rays)
 };
 
 struct LaneRay {
@@ -126,7 +127,19 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   __shared__ uint32_t victimMem[256];              // scratch: the lanes offering work, compacted
   const FrameParams& fp = *fpp;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t bin = blockIdx.x * 4u + wave;
+  // Workgroup -> tile.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2; handing every
+  // XCD whole super-tiles of 8x8 tiles (128x128 pixels), dealt round-robin over the screen, keeps the part of the tree
+  // an L2 needs at any one time small without tying an XCD to one (cheap or expensive) region of the screen.
+  uint32_t tile = blockIdx.x;
+  if (A.tilesX != 0u) {
+    const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+    const uint32_t super = (local >> 6) * 8u + xcd, inSuper = local & 63u;
+    const uint32_t superX = (A.tilesX + 7u) >> 3;
+    const uint32_t tx = (super % superX) * 8u + (inSuper & 7u), ty = (super / superX) * 8u + (inSuper >> 3);
+    if (tx >= A.tilesX || ty >= A.tilesY) return;
+    tile = ty * A.tilesX + tx;
+  }
+  const uint32_t bin = tile * 4u + wave;
   if (bin >= A.numBins) return;
   const uint32_t count = min(A.binCount[bin], RT_BIN);
   if (count == 0u) return;
@@ -336,7 +349,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
 __global__ void stampKernel(uint32_t* totals) { *reinterpret_cast<unsigned long long*>(totals + 1020) = wall_clock64(); }
 #endif
 
-int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays) {
+int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY) {
   TraceArgs T;
   if (numBins == 0) return 0;
   if (numBins > c->numBinsMax) { setError("launchTrace: %u bins exceed the %u allocated", numBins, c->numBinsMax); return -1; }
@@ -364,7 +377,10 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
 #ifdef RT_TRACE_STATS
   hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounter32);
 #endif
-  hipLaunchKernelGGL(traceKernel, dim3((numBins + 3u) / 4u), dim3(256), 0, s, c->dParams + c->slot, T);
+  T.tilesX = tilesX; T.tilesY = tilesY;
+  const uint32_t superTiles = ((tilesX + 7u) / 8u) * ((tilesY + 7u) / 8u);
+  const uint32_t grid = tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (numBins + 3u) / 4u;
+  hipLaunchKernelGGL(traceKernel, dim3(grid), dim3(256), 0, s, c->dParams + c->slot, T);
   RT_HIP(hipGetLastError());
   return 0;
 }

@@ -18,5 +18,7 @@ for f in range(3):
         f, rays, c[0] / rays, c[1] / rays, c[2], c[2] / waves, (c[0] + c[1]) / max(c[2] * 64.0, 1), c[3], c[4], c[8], c[9], a.context.timings()["ray_trace_kernel"]))
     print("   wave lifetime: mean %.0f cycles, max %.0f cycles; most iterations in one wave %d; cycles per iteration %.0f" % (
         c[5] * 1024 / waves, c[6] * 16, c[7], c[5] * 1024 / max(c[2], 1)))
+    longest = max((int(raw[k, 11]), int(raw[k, 10])) for k in range(16))
+    print("   the wave with the most iterations (%d) did %d lane steps: lane utilisation %.2f" % (longest[0], longest[1], longest[1] / max(longest[0] * 64.0, 1)))
     print("   wave starts per 8 us:", " ".join(str(int(v)) for v in allc[288:320]))
     print("   wave ends   per 8 us:", " ".join(str(int(v)) for v in allc[256:288]))
