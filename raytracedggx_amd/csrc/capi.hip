@@ -134,8 +134,14 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   rtggx_context* c = new rtggx_context();
   c->device = device; c->W = width; c->H = height; c->rowBegin = 0; c->rowEnd = height;
   const size_t n = (size_t)width * height;
-  RT_HIP(hipStreamCreateWithFlags(&c->ownMain, hipStreamNonBlocking));
-  RT_HIP(hipStreamCreateWithFlags(&c->streamAS, hipStreamNonBlocking));
+  // Stream B carries the frame's critical chain (visibility -> ray generation -> traversal): it gets the high
+  // priority, so that the shading/denoise kernels of the previous frame on the main stream fill the gaps it leaves
+  // rather than compete with it.
+  int prioLeast = 0, prioGreatest = 0;
+  RT_HIP(hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
+  if (getenv("RTGGX_NO_PRIORITY")) prioGreatest = prioLeast;
+  RT_HIP(hipStreamCreateWithPriority(&c->ownMain, hipStreamNonBlocking, prioLeast));
+  RT_HIP(hipStreamCreateWithPriority(&c->streamAS, hipStreamNonBlocking, prioGreatest));
   c->streamMain = c->ownMain;
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evFrameStart, hipEventDisableTiming));
