@@ -1,4 +1,5 @@
-for e in X=1 RTGGX_NO_PRIORITY=1 X=2 RTGGX_NO_PRIORITY=1; do env $e timeout -k 10 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $e <<'PY'
+timeout -k 10 400 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -n 3 gpurun_out/t.log
+for e in X=1 X=2; do env $e timeout -k 10 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $e <<'PY'
 import json,sys
 for l in open("gpurun_out/sw.log"):
     if l.startswith("{"):

@@ -162,7 +162,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
   RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
   c->largeCapacity = 1u << 16;
-  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 40)); RT_HIP(hipMalloc(&c->largeCount, 4));
+  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 4));
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
   RT_HIP(hipMalloc(&c->rayCounter32, 1024 * 4)); RT_HIP(hipMemset(c->rayCounter32, 0, 1024 * 4));   // [0..255] rays; [256..] RT_TRACE_STATS
   {

@@ -18,7 +18,7 @@
 
 namespace rt {
 
-struct LargeTri { int32_t X[3], Y[3]; float z[3]; uint32_t word; };
+struct LargeTri { int32_t X[3], Y[3]; float z[3]; uint32_t word; double invA; uint32_t tl, pad; };   // 56 B; set-up done once, by rasterSmall
 
 struct RVert { long long X, Y; float z; bool ok; };
 
@@ -49,11 +49,13 @@ __global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begi
 }
 
 // Fragment test + depth for one pixel; returns the key or ~0 when not covered.
-RT_DEV unsigned long long fragmentKey(long long PX, long long PY, const long long X[3], const long long Y[3],
+// Snapped coordinates are below 2^30 in magnitude (rasterVertex), pixel centres below 2^23: every difference fits 32
+// bits, every product is one 32x32->64 multiply-add.
+RT_DEV unsigned long long fragmentKey(int32_t PX, int32_t PY, const int32_t X[3], const int32_t Y[3],
                                       bool tl0, bool tl1, bool tl2, double invA, double z0, double dz1, double dz2, uint32_t word) {
-  const long long w0 = (X[2] - X[1]) * (PY - Y[1]) - (Y[2] - Y[1]) * (PX - X[1]);
-  const long long w1 = (X[0] - X[2]) * (PY - Y[2]) - (Y[0] - Y[2]) * (PX - X[2]);
-  const long long w2 = (X[1] - X[0]) * (PY - Y[0]) - (Y[1] - Y[0]) * (PX - X[0]);
+  const long long w0 = (long long)(X[2] - X[1]) * (long long)(PY - Y[1]) - (long long)(Y[2] - Y[1]) * (long long)(PX - X[1]);
+  const long long w1 = (long long)(X[0] - X[2]) * (long long)(PY - Y[2]) - (long long)(Y[0] - Y[2]) * (long long)(PX - X[2]);
+  const long long w2 = (long long)(X[1] - X[0]) * (long long)(PY - Y[0]) - (long long)(Y[1] - Y[0]) * (long long)(PX - X[0]);
   if (w0 < 0 || w1 < 0 || w2 < 0) return ~0ull;
   if ((w0 == 0 && !tl0) || (w1 == 0 && !tl1) || (w2 == 0 && !tl2)) return ~0ull;
   const double l1 = (double)w1 * invA, l2 = (double)w2 * invA;
@@ -118,14 +120,15 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict
           if (slot < largeCap) {
             LargeTri lt;
             for (int k = 0; k < 3; ++k) { lt.X[k] = (int32_t)X[k]; lt.Y[k] = (int32_t)Y[k]; lt.z[k] = z[k]; }
-            lt.word = word;
+            lt.word = word; lt.invA = invA; lt.tl = (tl0 ? 1u : 0u) | (tl1 ? 2u : 0u) | (tl2 ? 4u : 0u); lt.pad = 0u;
             large[slot] = lt;
           } else {
             // queue full (more than 65536 big triangles): rasterise it right here -- correct, slow
             const double z0 = (double)z[0], dz1 = (double)z[1] - z0, dz2 = (double)z[2] - z0;
+            const int32_t X32[3] = {(int32_t)X[0], (int32_t)X[1], (int32_t)X[2]}, Y32[3] = {(int32_t)Y[0], (int32_t)Y[1], (int32_t)Y[2]};
             for (long long py = py0; py <= py1; ++py)
               for (long long px = px0; px <= px1; ++px) {
-                const unsigned long long key = fragmentKey(px * 256 + 128, py * 256 + 128, X, Y, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
+                const unsigned long long key = fragmentKey((int32_t)px * 256 + 128, (int32_t)py * 256 + 128, X32, Y32, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
                 if (key == ~0ull) continue;
                 unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
                 if (key < *dst) atomicMin(dst, key);
@@ -157,8 +160,8 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict
     const TriSetup& S = setup[lo];
     const uint32_t q = w - prefix[lo], bw = S.bwTl & 0xFFFFu;
     const uint32_t ry = (q * S.magic) >> 24, rx = q - ry * bw;       // q / bw exactly: q < 1024, bw <= 1024
-    const long long px = S.px0 + (long long)rx, py = S.py0 + (long long)ry;
-    const long long X[3] = {S.X[0], S.X[1], S.X[2]}, Y[3] = {S.Y[0], S.Y[1], S.Y[2]};
+    const int32_t px = S.px0 + (int32_t)rx, py = S.py0 + (int32_t)ry;
+    const int32_t X[3] = {S.X[0], S.X[1], S.X[2]}, Y[3] = {S.Y[0], S.Y[1], S.Y[2]};
     const double z0 = (double)S.z[0], dz1 = (double)S.z[1] - z0, dz2 = (double)S.z[2] - z0;
     const unsigned long long key = fragmentKey(px * 256 + 128, py * 256 + 128, X, Y, (S.bwTl >> 16) & 1u, (S.bwTl >> 17) & 1u, (S.bwTl >> 18) & 1u,
                                                S.invA, z0, dz1, dz2, S.word);
@@ -174,22 +177,17 @@ __global__ void __launch_bounds__(256) rasterLarge(const FrameParams* __restrict
   const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63);
   const uint32_t py = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
   const uint32_t n = min(*largeCount, largeCap);
-  const long long tileX0 = (long long)(blockIdx.x * 64) * 256 + 128, tileX1 = tileX0 + 63 * 256;
-  const long long tileY0 = (long long)(rowBegin + blockIdx.y * 4) * 256 + 128, tileY1 = tileY0 + 3 * 256;
-  const long long PX = (long long)px * 256 + 128, PY = (long long)py * 256 + 128;
+  const int32_t tileX0 = (int32_t)(blockIdx.x * 64) * 256 + 128, tileX1 = tileX0 + 63 * 256;
+  const int32_t tileY0 = (int32_t)(rowBegin + blockIdx.y * 4) * 256 + 128, tileY1 = tileY0 + 3 * 256;
+  const int32_t PX = (int32_t)px * 256 + 128, PY = (int32_t)py * 256 + 128;
   unsigned long long best = ~0ull;
   for (uint32_t i = 0; i < n; ++i) {
     const LargeTri lt = large[i];
-    long long X[3], Y[3];
-    for (int k = 0; k < 3; ++k) { X[k] = lt.X[k]; Y[k] = lt.Y[k]; }
-    const long long minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
-    const long long minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
+    const int32_t minX = min(lt.X[0], min(lt.X[1], lt.X[2])), maxX = max(lt.X[0], max(lt.X[1], lt.X[2]));
+    const int32_t minY = min(lt.Y[0], min(lt.Y[1], lt.Y[2])), maxY = max(lt.Y[0], max(lt.Y[1], lt.Y[2]));
     if (maxX < tileX0 || minX > tileX1 || maxY < tileY0 || minY > tileY1) continue;   // uniform per workgroup
-    const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
-    const bool tl0 = isTopLeft(X[1], Y[1], X[2], Y[2]), tl1 = isTopLeft(X[2], Y[2], X[0], Y[0]), tl2 = isTopLeft(X[0], Y[0], X[1], Y[1]);
-    const double invA = 1.0 / (double)area2;
     const double z0 = (double)lt.z[0], dz1 = (double)lt.z[1] - z0, dz2 = (double)lt.z[2] - z0;
-    const unsigned long long key = fragmentKey(PX, PY, X, Y, tl0, tl1, tl2, invA, z0, dz1, dz2, lt.word);
+    const unsigned long long key = fragmentKey(PX, PY, lt.X, lt.Y, lt.tl & 1u, (lt.tl >> 1) & 1u, (lt.tl >> 2) & 1u, lt.invA, z0, dz1, dz2, lt.word);
     best = key < best ? key : best;
   }
   if (px < fp.W && py < rowEnd && best != ~0ull) {
