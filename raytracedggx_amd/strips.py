@@ -63,9 +63,11 @@ def run_exchange(dist, plan, buffers):
 
 class StripRenderer:
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
-                 transport=None):
+                 transport=None, torch_buffers=None):
         """dist: torch.distributed (one process per GPU).  transport: instead of dist, a callable
-        transport(renderer, plan) that carries out the plan some other way (tests drive several strips from one process)."""
+        transport(renderer, plan) that carries out the plan some other way (tests drive several strips from one process).
+        torch_buffers: wrap the exchanged targets as torch tensors and render on torch's current stream (default: only
+        when dist is used); with a transport it lets a test move the rows with torch copies on that stream."""
         self.W, self.H, self.rank, self.world, self.dist, self.transport = width, height, rank, world, dist, transport
         args = ["-mesh", mesh_path] + ([str(x) for x in pos_scale] if pos_scale else []) + \
                ["-env", env_path, "-width", width, "-height", height, "-device", device] + list(extra_args)
@@ -76,11 +78,15 @@ class StripRenderer:
             if self.e - self.b < HISTORY_APRON:
                 raise ValueError("strips of %d rows are thinner than the %d-row history apron" % (self.e - self.b, HISTORY_APRON))
             self.context.set_strip(self.b, self.e)
-            if transport is None:
+            if transport is None or torch_buffers:
                 import torch
                 self.torch = torch
-                # run the HIP passes on torch's current stream so that RCCL ops and kernels are ordered by the stream
-                self.context.set_stream(torch.cuda.current_stream().cuda_stream)
+                # The main-stream passes (shade, denoise, tone map) run on a torch stream of our own, and the RCCL ops
+                # are issued with that stream current: kernels and transfers are then ordered by the stream.  (Not
+                # torch's default stream: on ROCm that is the null stream, whose handle is 0 -- "no stream" to
+                # rtggx_set_stream -- and the library's own streams do not synchronise with it.)
+                self.stream = torch.cuda.Stream(device=device)
+                self.context.set_stream(self.stream.cuda_stream)
                 self._tss = [self._wrap(capi.BUF_TSS0, "<u8"), self._wrap(capi.BUF_TSS1, "<u8")]
                 self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
         self._last = None
@@ -105,7 +111,12 @@ class StripRenderer:
         if self.transport is not None:
             self.transport(self, plan)
         else:
-            run_exchange(self.dist, plan, {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer})
+            with self.torch.cuda.stream(self.stream):
+                run_exchange(self.dist, plan, self.exchange_buffers())
+
+    def exchange_buffers(self):
+        """The torch views of the two exchanged targets (this frame's temporal result, the back buffer)."""
+        return {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer}
 
     # -- statistics --------------------------------------------------------------------------------------
     def rays_traced_since_reset(self):

@@ -341,3 +341,45 @@ def test_two_strips_with_history_exchange_equal_one_frame(built):
         full.close()
         for s in strips:
             s.close()
+
+
+def test_strips_through_torch_views_on_torch_stream(built):
+    """The multi-GPU code path minus RCCL: the exchanged targets wrapped as torch tensors (zero-copy views of the
+    library's device buffers), all passes on torch's current stream, rows moved with torch copies on that stream --
+    against the single-context frame.  Checks the views alias the right memory and that stream ordering holds."""
+    import torch
+    from raytracedggx_amd import capi
+    from raytracedggx_amd.strips import StripRenderer
+    W, H = 480, 272
+    mesh, env = assets.path("bunny.obj"), assets.path("rnl_cross.dds")
+    strips = []
+
+    def transport(r, plan):
+        mine = r.exchange_buffers()
+        with torch.cuda.stream(r.stream):
+            for op, name, r0, r1, peer in plan:
+                if op == "recv":
+                    r.stream.wait_stream(strips[peer].stream)       # what RCCL's send/recv pairing does across processes
+                    mine[name][r0:r1].copy_(strips[peer].exchange_buffers()[name][r0:r1], non_blocking=True)
+
+    full = StripRenderer(W, H, mesh, env, extra_args=("-sharedmem",))
+    strips += [StripRenderer(W, H, mesh, env, rank=r, world=2, transport=transport, torch_buffers=True, extra_args=("-sharedmem",)) for r in range(2)]
+    try:
+        for f in range(3):
+            full.frame()
+            for s in strips:
+                s.render()
+            for s in strips:
+                s.exchange()
+            for s in strips:                                         # a peer may not start its next frame (and overwrite
+                for t in strips:                                     # rows being copied) before the copies are done
+                    s.stream.wait_stream(t.stream)
+            torch.cuda.synchronize(); full.context.sync()
+            assert strips[0].exchange_buffers()["backbuffer"].data_ptr() == strips[0].context.buffer_ptr(capi.BUF_BACKBUFFER)
+            np.testing.assert_array_equal(strips[0].exchange_buffers()["backbuffer"].cpu().numpy().view(np.uint32),
+                                          full.context.readback(capi.BUF_BACKBUFFER), err_msg="frame %d" % f)
+            np.testing.assert_array_equal(strips[0].context.readback(capi.BUF_BACKBUFFER), full.context.readback(capi.BUF_BACKBUFFER))
+    finally:
+        full.close()
+        for s in strips:
+            s.close()
