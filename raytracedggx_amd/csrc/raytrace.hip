@@ -6,25 +6,23 @@
 //                  visibility buffer (getPrimarySurface :277-333), GGX / uniform-sphere sampling
 //                  (:92-162, :394-406), BRDF weight (:459-480).  Pixels whose ray is degenerate
 //                  (background, NoL <= 0) are finished here (missMain :620-625 / zero); every real
-//                  ray is appended, by wave ballot + one atomic per wave, to one of 8 queues
-//                  (indexed by the XCD the workgroup runs on).
-//   traceKernel    TraceRay :183-198: persistent wavefronts.  A lane owns one ray at a time; when
-//                  >= 16 lanes of a wave are idle they are refilled together from the queue of the
-//                  wave's own XCD (then from the others: work stealing), found with __ballot and
-//                  one returning atomic per refill.  Two-level software BVH: the ray is carried
-//                  into each instance's object space (TLAS = two world->object matrices) and walks
-//                  the 64-byte-node binary LBVH with a per-lane stack in LDS ([entry][lane] layout:
-//                  conflict-free ds_read/ds_write_b32), nearer child first.  Ray/triangle:
-//                  watertight test (Woop, Benthin, Wald 2013), no culling, TMin < t < TMax, ties to
-//                  the lower (instance, primitive).
+//                  ray is compacted, by wave ballot, into the bin of the wave's own 8x8-pixel sub-tile
+//                  (rt_queue.h: no atomics).
+//   traceKernel    TraceRay :183-198 (trace.hip): one wave per bin over a two-level software BVH -- the ray
+//                  is carried into each instance's object space (TLAS = two world->object matrices) and
+//                  walks the 4-wide collapse of the Morton-ordered PLOC tree with a per-lane stack in LDS,
+//                  nearer child first, lanes sharing work inside the wave.  Ray/triangle: watertight test
+//                  (Woop, Benthin, Wald 2013), no culling, TMin < t < TMax, ties to the lower
+//                  (instance, primitive).
 //   shadeKernel    closestHitReflection :571-590, closestHitDiffuse :593-614, missMain :620-625 and
 //                  the tail of computeReflection / computeDiffuse, with Material.hlsli,
 //                  BRDFModels.hlsli, SHIrradianceTypeless.hlsli:16-37; writes RayTracingOut0/1.
 //
+// rayGenKernel and traceKernel run on stream B, shadeKernel on the main stream one frame behind (capi.hip).
 // Roofline: HBM by decree of the metric (no MFMA work exists here).  Algorithmic bytes:
 // rayGen 18 B/pixel (+64 B per queued ray); trace 64 B ray + 16 B hit per ray + the scene arrays
-// once; shade 64+16 B in, 4 B out per ray.  The BVH (<= 10 MB) is L2/MALL resident, so traversal is
-// latency / issue bound, not HBM bound (DESIGN.md "Roofline").
+// once; shade 64+16 B in, 4 B out per ray.  The BVH (<= 14 MB) is L2/MALL resident, so traversal is
+// bound by L1 request rate, issue and latency, not by HBM (DESIGN.md "Roofline").
 #include "rt_queue.h"
 
 namespace rt {
@@ -431,7 +429,7 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   return 0;
 }
 
-// ---- test entry: closest-hit queries for an explicit ray list (through the same persistent kernel) ----------
+// ---- test entry: closest-hit queries for an explicit ray list (through the same trace kernel) ---------------
 __global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec* q0, uint32_t* binCount) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i % RT_BIN == 0 && i < n) binCount[i / RT_BIN] = n - i < RT_BIN ? n - i : RT_BIN;   // bins are filled densely, in order

@@ -2,9 +2,10 @@
 //
 // No atomics anywhere on this path: every wave of rayGenKernel owns one BIN of RT_BIN ray slots (its 8x8 pixel
 // sub-tile, at most one reflection and one diffuse ray per pixel), compacts its rays into the front of the bin
-// with __ballot/popcount and records how many there are.  The trace kernel's waves own fixed, interleaved sets
-// of bins, so no queue head is ever contended (device-scope atomics on a shared head word cost ~11 ns each at
-// the memory side and serialised the first versions of this pass: profiles/r01_b).
+// with __ballot/popcount and records how many there are.  Each wave of the trace kernel owns one bin, so no
+// queue head is ever contended (device-scope atomics on a shared head word cost ~11 ns each at the memory side
+// and serialised the first, work-queue versions of this pass).  The bins exist twice (rtggx_context.h): stream B
+// fills and traces set i while the main stream still shades set i^1.
 #pragma once
 #include "rtggx_context.h"
 
@@ -22,8 +23,8 @@ struct __attribute__((aligned(16))) RayRec {
 // 16-byte hit record
 struct __attribute__((aligned(16))) HitRec { float t, b1, b2; uint32_t id; /* (inst<<24)|prim, ~0 = miss */ };
 
-// Persistent traversal of the rays in bins [0, numBins) (trace.hip).  countRays: add the rays of rows
-// [fp.rowBegin, fp.rowEnd) to the per-frame counters.
+// Traversal of the rays in bins [0, numBins) (trace.hip).  countRays: add the rays of rows [fp.rowBegin, fp.rowEnd)
+// to the per-frame counters.  tilesX x tilesY: the tile grid the bins come from (4 bins per tile), 0 for a plain list.
 int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY);
 
 }  // namespace rt

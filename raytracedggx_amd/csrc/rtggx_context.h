@@ -6,8 +6,11 @@
 //   normal     u32   R10G10B10A2_UNORM      roughMetal u16 R8G8_UNORM     velocity u32 R16G16_FLOAT
 //   rtRefl/rtDiff u32 R11G11B10_FLOAT       tss[2], fltRfl, fltDff u64 R16G16B16A16_FLOAT
 //   backbuffer u32   R8G8B8A8_UNORM
-// Scene: per mesh 24-byte vertices, u32 indices, 64-byte BVH nodes, 64-byte leaf triangles;
-// environment as RGBA16F mip-major (6 faces per mip); 9 float3 SH coefficients.
+// visDepth, normal, roughMetal, velocity, rtRefl, rtDiff and the ray bins exist twice ("input sets"): stream B
+// (visibility, ray generation, traversal) fills one set while the main stream (shading, denoise, tone map) still
+// reads the other.
+// Scene: per mesh 24-byte vertices, u32 indices, 64-byte binary BVH nodes, their 128-byte 4-wide collapse,
+// 64-byte leaf triangles; environment as RGBA16F mip-major (6 faces per mip); 9 float3 SH coefficients.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
