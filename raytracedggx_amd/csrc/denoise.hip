@@ -28,6 +28,11 @@ namespace rt {
 #define RT_VBH 16
 #endif
 
+// The denoiser's outputs are floating-point images judged to 1e-3 relative L2 (DESIGN.md "parity bar"), and with both
+// streams busy the frame is bound by VALU issue: in the spatial filters and the tone map, IEEE divisions (10-12
+// instructions each) become multiplications by a constant or by v_rcp_f32 (1 ulp).  Not in the temporal pass: see tssTM.
+RT_DEV float rcpFast(float x) { return __builtin_amdgcn_rcpf(x); }
+
 struct GTexel { float nx, ny, nz, nw, rough, metal, depth; };
 
 RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restrict__ roughMetal, const unsigned long long* __restrict__ visDepth,
@@ -36,17 +41,17 @@ RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restr
   if (x < 0 || y < 0 || x >= W || y >= H) { g.nx = g.ny = g.nz = -1.0f; g.nw = 0.0f; g.rough = 0.0f; g.metal = 0.0f; g.depth = 0.0f; return g; }
   const size_t i = (size_t)y * W + x;
   const uint32_t n = normal[i];
-  g.nx = ((float)(n & 1023u) / 1023.0f) * 2.0f - 1.0f;
-  g.ny = ((float)((n >> 10) & 1023u) / 1023.0f) * 2.0f - 1.0f;
-  g.nz = ((float)((n >> 20) & 1023u) / 1023.0f) * 2.0f - 1.0f;
-  g.nw = (float)(n >> 30) / 3.0f;
+  g.nx = (float)(n & 1023u) * (2.0f / 1023.0f) - 1.0f;
+  g.ny = (float)((n >> 10) & 1023u) * (2.0f / 1023.0f) - 1.0f;
+  g.nz = (float)((n >> 20) & 1023u) * (2.0f / 1023.0f) - 1.0f;
+  g.nw = (float)(n >> 30) * (1.0f / 3.0f);
   const uint32_t rm = roughMetal[i];
-  g.rough = (float)(rm & 0xFFu) / 255.0f; g.metal = (float)(rm >> 8) / 255.0f;
-  g.depth = (float)(uint32_t)(visDepth[i] >> 32) / 16777215.0f;
+  g.rough = (float)(rm & 0xFFu) * (1.0f / 255.0f); g.metal = (rm >> 8) == 255u ? 1.0f : (float)(rm >> 8) * (1.0f / 255.0f);
+  g.depth = (float)(uint32_t)(visDepth[i] >> 32) * (1.0f / 16777215.0f);
   return g;
 }
-RT_DEV f3 TM3(f3 c) { const float l = 1.0f + ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f); return mk3(c.x / l, c.y / l, c.z / l); }     // FilterCommon.hlsli:14-19
-RT_DEV f3 ITM3(f3 c) { const float l = 1.0f - ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f); return mk3(c.x / l, c.y / l, c.z / l); }    // :24-27
+RT_DEV f3 TM3(f3 c) { const float r = rcpFast(1.0f + ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f)); return mk3(c.x * r, c.y * r, c.z * r); }     // FilterCommon.hlsli:14-19
+RT_DEV f3 ITM3(f3 c) { const float r = rcpFast(1.0f - ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f)); return mk3(c.x * r, c.y * r, c.z * r); }    // :24-27
 struct Targets {
   const uint32_t* normal; const uint16_t* roughMetal; const unsigned long long* visDepth; const uint32_t* velocity;
   const uint32_t* rtRefl; const uint32_t* rtDiff;
@@ -76,14 +81,15 @@ template <bool DIFFUSE>
 RT_DEV Centre makeCentre(float nx, float ny, float nz, float depth, float rough, int W, int H) {
   Centre c; c.nx = nx; c.ny = ny; c.nz = nz; c.depth = depth; c.rough = rough;
   const int br = DIFFUSE ? 0 : (int)clampf(0.1f * rough * (float)W, 0.0f, (float)H * 0.05f);   // FilterCommon.hlsli:49-52
-  const float sigma = (float)(br + 1) / 3.0f;
-  c.gaussK = (-0.5f * RT_LOG2E) / (sigma * sigma);
+  const float sigma = (float)(br + 1) * (1.0f / 3.0f);
+  c.gaussK = (-0.5f * RT_LOG2E) * rcpFast(sigma * sigma);
   c.depthK = depth * (4.0f * RT_LOG2E);
   return c;
 }
 template <int MODE>
 RT_DEV void storeFiltered(const Targets& T, size_t pix, float mx, float my, float mz, float wsum) {
-  f3 mu = mk3(mx / wsum, my / wsum, mz / wsum);
+  const float rw = rcpFast(wsum);
+  f3 mu = mk3(mx * rw, my * rw, mz * rw);
   if (MODE == 0 || MODE == 2) T.scratch[pix] = packRGBA16F(mu.x, mu.y, mu.z, 0.0f);
   if (MODE == 1) { mu = ITM3(mu); const uint2 v = packRGBA16F(mu.x, mu.y, mu.z, 1.0f); T.fltRfl[pix] = v; T.fltDff[pix] = v; }
   if (MODE == 3) {
@@ -205,6 +211,9 @@ RT_DEV f3 yCoCgToRGB(f3 c) {   // :90-101
   const float y = c.x * 0.25f, co = c.y * 0.25f, cg = c.z * 0.25f;
   return mk3(y + co - cg, y + cg, y - co - cg);
 }
+// The temporal pass keeps IEEE division and square root: its neighbourhood variance m2/9 - mu^2 is pure rounding noise
+// in flat regions, sqrt turns that noise into the clamp window (times gamma <= 32), and only identical arithmetic on
+// both sides keeps the window -- and with it the clamped history -- comparable with the oracle's.
 RT_DEV f3 tssTM(f3 hdr) { const f3 c = rgbToYCoCg(hdr); const float d = 4.0f + c.x; return mk3(c.x / d, c.y / d, c.z / d); }   // :106-114
 RT_DEV f3 tssITM(f3 col) { const float k = 4.0f / (1.0f - col.x); return yCoCgToRGB(mk3(col.x * k, col.y * k, col.z * k)); }   // :119-128
 RT_DEV f2 loadVel(const uint32_t* __restrict__ vel, int x, int y, int W, int H) {
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
     const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * 4 - 1;
     for (int t = threadIdx.x; t < 6 * 66; t += 256) {
       const f4 c = loadRGBA16(T.scratch, ox + t % 66, oy + t / 66, W, H);
-      tile[t / 66][t % 66] = make_float4(c.x / (c.x + 0.5f), c.y / (c.y + 0.5f), c.z / (c.z + 0.5f), c.w);
+      tile[t / 66][t % 66] = make_float4(c.x * rcpFast(c.x + 0.5f), c.y * rcpFast(c.y + 0.5f), c.z * rcpFast(c.z + 0.5f), c.w);
     }
   }
   __syncthreads();
