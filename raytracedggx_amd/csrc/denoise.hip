@@ -213,9 +213,11 @@ RT_DEV f3 yCoCgToRGB(f3 c) {   // :90-101
 }
 // The temporal pass keeps IEEE division and square root: its neighbourhood variance m2/9 - mu^2 is pure rounding noise
 // in flat regions, sqrt turns that noise into the clamp window (times gamma <= 32), and only identical arithmetic on
-// both sides keeps the window -- and with it the clamped history -- comparable with the oracle's.
+// both sides keeps the window -- and with it the clamped history -- comparable with the oracle's.  The smooth terms
+// around it (reprojection uv, blend factors, the inverse tone map) do use v_rcp_f32.
 RT_DEV f3 tssTM(f3 hdr) { const f3 c = rgbToYCoCg(hdr); const float d = 4.0f + c.x; return mk3(c.x / d, c.y / d, c.z / d); }   // :106-114
-RT_DEV f3 tssITM(f3 col) { const float k = 4.0f / (1.0f - col.x); return yCoCgToRGB(mk3(col.x * k, col.y * k, col.z * k)); }   // :119-128
+RT_DEV f3 tssITM(f3 col) { const float k = 4.0f * rcpFast(1.0f - col.x); return yCoCgToRGB(mk3(col.x * k, col.y * k, col.z * k)); }   // :119-128 (smooth: v_rcp)
+RT_DEV f3 tssTMSmooth(f3 hdr) { const f3 c = rgbToYCoCg(hdr); const float r = rcpFast(4.0f + c.x); return mk3(c.x * r, c.y * r, c.z * r); }   // for the reprojected history, which does not enter the variance
 RT_DEV f2 loadVel(const uint32_t* __restrict__ vel, int x, int y, int W, int H) {
   f2 v; v.x = 0.0f; v.y = 0.0f;
   if (x < 0 || y < 0 || x >= W || y >= H) return v;
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= T.W || y >= T.rowEnd) return;
   const float Wf = (float)W, Hf = (float)H;
-  const float uvx = ((float)x + 0.5f) / Wf, uvy = ((float)y + 0.5f) / Hf;
+  const float uvx = ((float)x + 0.5f) * rcpFast(Wf), uvy = ((float)y + 0.5f) * rcpFast(Hf);
   const float4 cur = tile[ly][lx];
   const f3 currentTM = mk3(cur.x, cur.y, cur.z);
   f4 current; current.x = current.y = current.z = 0.0f; current.w = cur.w;     // only the alpha of the raw value is used below
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   float historyBlur = 1.0f - history.w;
   historyBlur = fmaxf(historyBlur, curHistoryBlur);
   history.w = history.w * 15.0f + 1.0f;
-  float gamma = current.w <= 0.0f ? 1.0f : clampf(8.0f / historyBlur, 1.0f, 32.0f);
+  float gamma = current.w <= 0.0f ? 1.0f : clampf(8.0f * rcpFast(historyBlur), 1.0f, 32.0f);
   // NeighborMinMax :166-236
   float fl[4] = {currentTM.x, currentTM.y, currentTM.z, current.w};
   float nmin[4], nmax[4];
@@ -312,23 +314,23 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   }
   curHistoryBlur = saturatef(curHistoryBlur);   // :290-291
   historyBlur = saturatef(historyBlur);
-  const f3 hTM = tssTM(mk3(history.x, history.y, history.z));   // :294-299
+  const f3 hTM = tssTMSmooth(mk3(history.x, history.y, history.z));   // :294-299
   float historyTM[3] = {fminf(fmaxf(hTM.x, nmin[0]), nmax[0]), fminf(fmaxf(hTM.y, nmin[1]), nmax[1]), fminf(fmaxf(hTM.z, nmin[2]), nmax[2])};
   const float contrast = nmax[3] - nmin[3];
   const float lumContrastFactor = 32.0f * 4.0f;   // :303-308
   float addAlias = historyBlur * 0.5f + 0.25f;
-  addAlias = saturatef(addAlias + 1.0f / (1.0f + contrast * lumContrastFactor));
+  addAlias = saturatef(addAlias + rcpFast(1.0f + contrast * lumContrastFactor));
   const float ctm[3] = {currentTM.x, currentTM.y, currentTM.z};
   for (int k = 0; k < 3; ++k) fl[k] = lerpf(fl[k], ctm[k], addAlias);   // :311
   const float lumHist = historyTM[0];   // :314-325
   const float distToClamp = fminf(fabsf(nmin[3] - lumHist), fabsf(nmax[3] - lumHist));
-  const float historyAmt = fminf(1.0f / history.w + historyBlur / 8.0f, 1.0f);
-  float blend = 0.25f / lerpf(8.0f, distToClamp + contrast, historyAmt);
+  const float historyAmt = fminf(rcpFast(history.w) + historyBlur * 0.125f, 1.0f);
+  float blend = 0.25f * rcpFast(lerpf(8.0f, distToClamp + contrast, historyAmt));
   blend = fminf(blend, 0.25f);
   blend = fl[3] > 0.0f ? blend : 1.0f;
   f3 result = tssITM(mk3(lerpf(historyTM[0], fl[0], blend), lerpf(historyTM[1], fl[1], blend), lerpf(historyTM[2], fl[2], blend)));   // :327-329
   if (isnan(result.x) || isnan(result.y) || isnan(result.z)) result = tssITM(mk3(fl[0], fl[1], fl[2]));
-  const float hw = fminf(history.w / 15.0f, 1.0f - curHistoryBlur);
+  const float hw = fminf(history.w * (1.0f / 15.0f), 1.0f - curHistoryBlur);
   T.scratch[(size_t)y * W + x] = packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
 }
 
