@@ -64,7 +64,11 @@ struct Targets {
 // Weight of one tap (SpatialFilter.hlsli:57-75, FilterCommon.hlsli:34-42,59-71) given the centre's constants.
 //   reflection: [nw > 0] * Gaussian(i, blurRadius) * pow(max(N.Nc, 0), 512) * exp(-|dc - d| dc 4) * (1 - smoothstep(0, .5, |r - rc|))
 //   diffuse:    pow(max(N.Nc, 0), 32) * exp(-|dc - d| dc 4)
-// Texels that do not take part (nw = 0; diffuse: metal = 1) are staged with a zero normal: their weight is 0.
+// The diffuse loops SKIP texels that do not take part (nw = 0 or metal = 1; CSSpatial_H_Diff.hlsl:35): those are staged
+// with a zero normal and colour.  The reflection weight instead MULTIPLIES by the nw flag (SpatialFilter.hlsli:60):
+// an out-of-range texel reads as zeros, i.e. normal (-1,-1,-1), and for a centre normal with nx+ny+nz < -1.19 the
+// 512th power overflows, 0 x inf = NaN, and the pixel (then its column) turns NaN -- in the reference, hence here:
+// reflection texels are staged as they are, with the flag in the sign bit of the roughness word.
 struct Centre { float nx, ny, nz, depth, rough, gaussK /* -0.5 log2(e) / sigma^2 */, depthK /* dc 4 log2(e) */; };
 template <bool DIFFUSE>
 RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, float depth, float rough) {
@@ -74,8 +78,9 @@ RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, flo
   if (DIFFUSE) return p * __builtin_amdgcn_exp2f(-dd);
   p *= p; p *= p; p *= p; p *= p;                          // ^512
   const float e = __builtin_fmaf(c.gaussK, (float)(i * i), -dd);
-  const float t = saturatef(fabsf(rough - c.rough) * 2.0f);
-  return (p * __builtin_amdgcn_exp2f(e)) * (1.0f - t * t * (3.0f - 2.0f * t));
+  const float t = saturatef(fabsf(fabsf(rough) - c.rough) * 2.0f);
+  const float flag = (__float_as_uint(rough) >> 31) ? 0.0f : 1.0f;          // sign bit set: norm.w <= 0
+  return ((p * __builtin_amdgcn_exp2f(e)) * (1.0f - t * t * (3.0f - 2.0f * t))) * flag;
 }
 template <bool DIFFUSE>
 RT_DEV Centre makeCentre(float nx, float ny, float nz, float depth, float rough, int W, int H) {
@@ -127,11 +132,11 @@ __global__ void __launch_bounds__(256) spatialDirectKernel(Targets T) {
   float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
   for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
     const int tx = vertical ? x : x + i, ty = vertical ? y + i : y;
-    if (tx < 0 || ty < 0 || tx >= T.W || ty >= T.H) continue;       // zero texel: weight 0
-    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);
-    if (g.nw <= 0.0f || (diffuse && g.metal >= 1.0f)) continue;
-    const f3 src = tapColour<MODE>(T, (size_t)ty * T.W + tx);
-    const float w = tapWeight<diffuse>(c, i, g.nx, g.ny, g.nz, g.depth, g.rough);
+    const bool inside = tx >= 0 && ty >= 0 && tx < T.W && ty < T.H;
+    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);     // zeros outside: normal -1, flag 0
+    if (diffuse && (g.nw <= 0.0f || g.metal >= 1.0f)) continue;
+    const f3 src = inside ? tapColour<MODE>(T, (size_t)ty * T.W + tx) : mk3(0.0f, 0.0f, 0.0f);
+    const float w = tapWeight<diffuse>(c, i, g.nx, g.ny, g.nz, g.depth, g.nw > 0.0f ? g.rough : __uint_as_float(__float_as_uint(g.rough) | 0x80000000u));
     mx = __builtin_fmaf(src.x, w, mx); my = __builtin_fmaf(src.y, w, my); mz = __builtin_fmaf(src.z, w, mz);
     wsum += w;
   }
@@ -172,13 +177,18 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
   for (int t = threadIdx.x; t < N; t += 256) {
     const int tx = ox + t % TW, ty = oy + t / TW;
     float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (tx >= 0 && ty >= 0 && tx < T.W && ty < T.H) {
-      const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);
-      v[3] = g.depth; v[4] = g.rough;
-      if (g.nw > 0.0f && !(diffuse && g.metal >= 1.0f)) {
+    const bool inside = tx >= 0 && ty >= 0 && tx < T.W && ty < T.H;
+    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);       // zeros outside
+    v[3] = g.depth; v[4] = g.rough;
+    if (diffuse) {
+      if (g.nw > 0.0f && g.metal < 1.0f) {
         const f3 src = tapColour<MODE>(T, (size_t)ty * T.W + tx);
         v[0] = g.nx; v[1] = g.ny; v[2] = g.nz; v[5] = src.x; v[6] = src.y; v[7] = src.z;
       }
+    } else {
+      v[0] = g.nx; v[1] = g.ny; v[2] = g.nz;
+      if (g.nw <= 0.0f) v[4] = __uint_as_float(__float_as_uint(g.rough) | 0x80000000u);
+      if (inside) { const f3 src = tapColour<MODE>(T, (size_t)ty * T.W + tx); v[5] = src.x; v[6] = src.y; v[7] = src.z; }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) sm[q][t] = v[q];
