@@ -412,3 +412,40 @@ def test_strips_through_torch_views_on_torch_stream(built):
         full.close()
         for s in strips:
             s.close()
+
+
+def test_c_abi_error_behaviour(built):
+    """Misuse is reported through the return code + rtggx_last_error(), never by crashing or by silently doing nothing:
+    calls out of order, bad arguments, short buffers (INTEGRATION.md "Error behaviour")."""
+    import ctypes as C
+    from raytracedggx_amd import capi
+    L = capi.load()
+    with pytest.raises(capi.RtggxError, match="bad arguments"):
+        capi.Context(0, 16)
+    ctx = capi.Context(64, 48)
+    try:
+        for call, what in ((ctx.render_visibility, "no frame constants"), (ctx.update_as, "rtggx_update_frame has not been called"),
+                           (ctx.denoise, "no frame constants"), (ctx.tone_map, "no frame constants"), (ctx.timings, "timing not enabled")):
+            with pytest.raises(capi.RtggxError, match=what):
+                call()
+        with pytest.raises(capi.RtggxError, match="bad rows"):
+            ctx.set_strip(10, 49)
+        with pytest.raises(capi.RtggxError, match="out of range"):
+            ctx.set_mesh(1, np.zeros((3, 6), np.float32), np.array([0, 1, 3], np.uint32))
+        with pytest.raises(capi.RtggxError, match="bad arguments"):
+            ctx.set_mesh(2, np.zeros((3, 6), np.float32), np.array([0, 1, 2], np.uint32))
+        ctx.update_frame(np.zeros(768, np.uint8))
+        with pytest.raises(capi.RtggxError, match="rtggx_build_as has not been called"):
+            ctx.ray_trace()
+        small = np.zeros(16, np.uint32)
+        assert L.rtggx_readback(ctx.h, capi.BUF_NORMAL, small.ctypes.data_as(C.c_void_p), small.nbytes) == -1
+        assert b"needs" in L.rtggx_last_error()
+        with pytest.raises(capi.RtggxError, match="not writable"):
+            ctx.upload(capi.BUF_TLAS, np.zeros((2, 4, 4), np.float32))
+        assert L.rtggx_sync(None) == -1 and b"null context" in L.rtggx_last_error()
+        # and the context is still usable afterwards
+        ctx.set_mesh(1, np.array([[-1, 0, 0, 0, 0, 1], [1, 0, 0, 0, 0, 1], [0, 2, 0, 0, 0, 1]], np.float32), np.array([0, 1, 2], np.uint32))
+        ctx.build_as(); ctx.sync()
+        assert ctx.bvh_root(1) == -1 and ctx.buffer_size(capi.BUF_BVH_TRIS1) == 64     # one triangle: the root is the leaf ~0
+    finally:
+        ctx.close()
