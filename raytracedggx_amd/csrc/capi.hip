@@ -144,7 +144,6 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipStreamCreateWithPriority(&c->streamAS, hipStreamNonBlocking, prioGreatest));
   c->streamMain = c->ownMain;
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
-  RT_HIP(hipEventCreateWithFlags(&c->evFrameStart, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
@@ -220,7 +219,7 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
-  hipEventDestroy(c->evAS); hipEventDestroy(c->evFrameStart); hipEventDestroy(c->evRT); hipEventDestroy(c->evSetRead[0]); hipEventDestroy(c->evSetRead[1]);
+  hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); hipEventDestroy(c->evSetRead[0]); hipEventDestroy(c->evSetRead[1]);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS);
   delete c;
 }

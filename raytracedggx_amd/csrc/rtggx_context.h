@@ -65,7 +65,7 @@ struct rtggx_context {
   uint32_t W = 0, H = 0;
   uint32_t rowBegin = 0, rowEnd = 0;
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
-  hipEvent_t evAS = nullptr, evFrameStart = nullptr;
+  hipEvent_t evAS = nullptr;      // constants uploaded (stream B -> main)
   hipEvent_t evRT = nullptr, evSetRead[2] = {nullptr, nullptr};   // ray trace done (stream B -> main); last reader of input set i done (main -> stream B)
   bool setReadRecorded[2] = {false, false};
   bool externalStream = false;

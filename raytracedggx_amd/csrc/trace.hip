@@ -27,7 +27,7 @@
 
 namespace rt {
 
-#define RT_STACK 24          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: see tests/trace_stats_probe.py)
+#define RT_STACK 24          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: see tools/probes/trace_stats_probe.py)
 
 struct TraceArgs {
   const float4* nodes0; const float4* tris0;   // 128-byte 4-wide nodes (8 x float4), 64-byte leaf triangles (4 x float4)

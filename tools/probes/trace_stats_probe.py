@@ -1,7 +1,7 @@
 """Manual probe: per-frame counters of a -DRT_TRACE_STATS build of librtggx
 (make -C raytracedggx_amd EXTRA=-DRT_TRACE_STATS after removing _build/trace.o)."""
 import sys
-sys.path.insert(0, __file__.rsplit("/tests/", 1)[0]); sys.path.insert(0, __file__.rsplit("/", 1)[0])
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0]); sys.path.insert(0, __file__.rsplit("/tools/", 1)[0] + "/tests")
 import assets
 from raytracedggx_amd import app
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
