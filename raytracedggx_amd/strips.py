@@ -53,10 +53,15 @@ def exchange_plan(height, rank, world, apron=HISTORY_APRON):
     return ops
 
 
-def run_exchange(dist, plan, buffers):
-    """Issue `plan` over torch.distributed as one batch (RCCL group launch on GPU tensors; plain isend/irecv on gloo).
-    buffers: {"history": tensor[H, W], "backbuffer": tensor[H, W]}."""
-    ops = [dist.P2POp(dist.isend if op == "send" else dist.irecv, buffers[name][r0:r1], peer) for op, name, r0, r1, peer in plan]
+def make_ops(dist, plan, buffers):
+    """The P2P operations of `plan` over `buffers` = {"history": tensor[H, W], "backbuffer": tensor[H, W]} (row slices
+    are views: the list can be built once and reused every frame)."""
+    return [dist.P2POp(dist.isend if op == "send" else dist.irecv, buffers[name][r0:r1], peer) for op, name, r0, r1, peer in plan]
+
+
+def run_exchange(dist, plan, buffers, ops=None):
+    """Issue `plan` over torch.distributed as one batch (RCCL group launch on GPU tensors; plain isend/irecv on gloo)."""
+    ops = make_ops(dist, plan, buffers) if ops is None else ops
     for w in dist.batch_isend_irecv(ops) if ops else []:
         w.wait()                       # on GPU tensors a stream-side wait only: the host does not block
 
@@ -90,6 +95,7 @@ class StripRenderer:
                 self._tss = [self._wrap(capi.BUF_TSS0, "<u8"), self._wrap(capi.BUF_TSS1, "<u8")]
                 self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
         self._last = None
+        self._ops = [None, None]
 
     def _wrap(self, bid, typestr):
         t = self.torch.as_tensor(_DeviceArray(self.context.buffer_ptr(bid), (self.H, self.W), typestr), device="cuda")
@@ -107,12 +113,14 @@ class StripRenderer:
     def exchange(self):
         if self.world == 1:
             return
-        plan = exchange_plan(self.H, self.rank, self.world)
         if self.transport is not None:
-            self.transport(self, plan)
-        else:
-            with self.torch.cuda.stream(self.stream):
-                run_exchange(self.dist, plan, self.exchange_buffers())
+            self.transport(self, exchange_plan(self.H, self.rank, self.world))
+            return
+        parity = self.context.frame_parity()
+        if self._ops[parity] is None:          # built once per history target: the per-frame host cost is the batch call alone
+            self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world), self.exchange_buffers())
+        with self.torch.cuda.stream(self.stream):
+            run_exchange(self.dist, None, None, ops=self._ops[parity])
 
     def exchange_buffers(self):
         """The torch views of the two exchanged targets (this frame's temporal result, the back buffer)."""

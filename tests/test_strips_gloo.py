@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from raytracedggx_amd.strips import HISTORY_APRON, exchange_plan, run_exchange, strip_rows
+from raytracedggx_amd.strips import HISTORY_APRON, exchange_plan, make_ops, run_exchange, strip_rows
 
 H, W = 120, 16
 
@@ -26,12 +26,14 @@ def _worker(rank, world, port, results):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         b, e = strip_rows(H, rank, world)
-        for frame in range(3):                                   # several frames: the matching must not drift
-            history = torch.full((H, W), -1, dtype=torch.int64)   # rows this rank did not produce are garbage
-            back = torch.full((H, W), -1, dtype=torch.int32)
+        # as in StripRenderer: persistent targets, the operation list built once and reissued every frame
+        history = torch.empty((H, W), dtype=torch.int64); back = torch.empty((H, W), dtype=torch.int32)
+        ops = make_ops(dist, exchange_plan(H, rank, world), {"history": history, "backbuffer": back})
+        for frame in range(4):                                   # several frames: the matching must not drift
+            history.fill_(-1); back.fill_(-1)                     # rows this rank did not produce are garbage
             history[b:e] = _truth((b, e)) + frame
             back[b:e] = (_truth((b, e)) + frame + 7).to(torch.int32)
-            run_exchange(dist, exchange_plan(H, rank, world), {"history": history, "backbuffer": back})
+            run_exchange(dist, None, None, ops=ops)
             lo, hi = max(b - HISTORY_APRON, 0), min(e + HISTORY_APRON, H)
             assert torch.equal(history[lo:hi], _truth((lo, hi)) + frame), "rank %d frame %d: history apron" % (rank, frame)
             assert (history[:lo] == -1).all() and (history[hi:] == -1).all(), "nothing beyond the apron is touched"
