@@ -1,4 +1,4 @@
-for f in gpurun_in/lib_slp.so gpurun_in/lib_noslp.so gpurun_in/lib_slp.so gpurun_in/lib_noslp.so; do cp $f raytracedggx_amd/librtggx.so; timeout -k 10 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $f <<'PY'
+for f in gpurun_in/lib_a_default.so gpurun_in/lib_b_noslp_rt_dn.so gpurun_in/lib_a_default.so gpurun_in/lib_b_noslp_rt_dn.so gpurun_in/lib_a_default.so gpurun_in/lib_b_noslp_rt_dn.so; do cp $f raytracedggx_amd/librtggx.so; timeout -k 10 120 python bench.py --steps 128 --warmup 32 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $f <<'PY'
 import json,sys
 for l in open("gpurun_out/sw.log"):
     if l.startswith("{"):
