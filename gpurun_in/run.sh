@@ -1,4 +1,5 @@
-for f in gpurun_in/lib_a_default.so gpurun_in/lib_b_noslp_rt_dn.so gpurun_in/lib_a_default.so gpurun_in/lib_b_noslp_rt_dn.so gpurun_in/lib_a_default.so gpurun_in/lib_b_noslp_rt_dn.so; do cp $f raytracedggx_amd/librtggx.so; timeout -k 10 120 python bench.py --steps 128 --warmup 32 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $f <<'PY'
+timeout -k 10 400 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -n 3 gpurun_out/t.log
+for e in X=1 X=2; do env $e timeout -k 10 120 python bench.py --steps 128 --warmup 32 --no-cpu-baseline > gpurun_out/sw.log 2>&1; python - $e <<'PY'
 import json,sys
 for l in open("gpurun_out/sw.log"):
     if l.startswith("{"):

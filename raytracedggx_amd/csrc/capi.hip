@@ -174,7 +174,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     if (c->numBinsMax < 64u) c->numBinsMax = 64u;            // room for rtggx_trace_rays batches on tiny frames
     for (int i = 0; i < 2; ++i) {
       RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * 128 * 64));
-      RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * 128 * 16));
+      RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * 128 * 8));
       RT_HIP(hipMalloc(&c->binCountBuf[i], (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCountBuf[i], 0, (size_t)c->numBinsMax * 4));
     }
     c->selectSet(0);

@@ -24,6 +24,7 @@
 // once; shade 64+16 B in, 4 B out per ray.  The BVH (<= 14 MB) is L2/MALL resident, so traversal is
 // bound by L1 request rate, issue and latency, not by HBM (DESIGN.md "Roofline").
 #include "rt_queue.h"
+#include "rt_traverse.h"
 
 namespace rt {
 
@@ -201,7 +202,7 @@ struct GenArgs {
   const float* verts0; const uint32_t* idx0; const float* verts1; const uint32_t* idx1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* cosSin;
-  RayRec* rays; uint32_t* binCount;
+  RayRec* rays; HitKey* hits; uint32_t* binCount;
   uint32_t* frameRays;      // 256 per-frame ray counters, zeroed here, added to by the trace kernel
   uint32_t tilesX, numTiles, rowBegin, rowEnd;
 };
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
     if (visibility > 0) {
       --visibility;
       hit = true; inst = visibility >> 24; prim = visibility & 0xFFFFFFu;
+      asm volatile("" : "+v"(prim));      // see shadeKernel: the mask must survive the array indexing by inst below
       const Tri3 v = getVertices(inst ? A.verts1 : A.verts0, inst ? A.idx1 : A.idx0, prim);
       const M4 wvp = cbLoad4x4(fp.g.WorldViewProjs[inst]);
       f4 p[3];
@@ -315,8 +317,9 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
   const unsigned long long maskR = __ballot(wantRefl), maskD = __ballot(wantDiff), below = (1ull << lane) - 1ull;
   const uint32_t nR = (uint32_t)__popcll(maskR);
   RayRec* dst = A.rays + (size_t)bin * RT_BIN;
-  if (wantRefl) dst[__popcll(maskR & below)] = rr;
-  if (wantDiff) dst[nR + (uint32_t)__popcll(maskD & below)] = rd;
+  HitKey* keys = A.hits + (size_t)bin * RT_BIN;      // every ray starts as a miss at TMax
+  if (wantRefl) { const uint32_t k = (uint32_t)__popcll(maskR & below); dst[k] = rr; keys[k] = hitKey(rr.tmax, 0xFFFFFFFFu); }
+  if (wantDiff) { const uint32_t k = nR + (uint32_t)__popcll(maskD & below); dst[k] = rd; keys[k] = hitKey(rd.tmax, 0xFFFFFFFFu); }
   if (lane == 0) A.binCount[bin] = nR + (uint32_t)__popcll(maskD);
 }
 
@@ -324,7 +327,7 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
 // Kernel 3: hit / miss shading
 // =========================================================================================================
 struct ShadeArgs {
-  const RayRec* rays; const HitRec* hits; const uint32_t* binCount;
+  const RayRec* rays; const HitKey* hits; const uint32_t* binCount;
   const float* verts0; const uint32_t* idx0; const float* verts1; const uint32_t* idx1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* sh;
@@ -354,23 +357,30 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict
   for (uint32_t i = threadIdx.x & 63u; i < count; i += 64u) {
     const size_t slot = (size_t)bin * RT_BIN + i;
     const float4* rp = reinterpret_cast<const float4*>(A.rays + slot);
-    const float4 rb = rp[1], rw = rp[3];
+    const float4 ra = rp[0], rb = rp[1], rw = rp[3];
     const uint4 rc = reinterpret_cast<const uint4*>(A.rays + slot)[2];
-    const HitRec h = A.hits[slot];
+    const uint32_t hitId = hitKeyId(A.hits[slot]);
     const f3 dir = mk3(rb.x, rb.y, rb.z);
     const bool diffuseGroup = (rc.z & 1u) != 0u;
     const uint32_t srcInst = rc.y >> 24;
     f3 col;
-    if (h.id == 0xFFFFFFFFu) col = environment(env, dir, 0.0f);   // missMain :620-625
+    if (hitId == 0xFFFFFFFFu) col = environment(env, dir, 0.0f);   // missMain :620-625
     else {
       // payload preset = color * metallic of the surface the ray left (:456); closestHitReflection returns it untouched when <= 0 (:573)
       const float m = fp.mat.RoughMetals[srcInst][1];
       const f3 preset = mk3(fp.mat.BaseColors[srcInst][0] * m, fp.mat.BaseColors[srcInst][1] * m, fp.mat.BaseColors[srcInst][2] * m);
       if (!diffuseGroup && preset.x <= 0.0f && preset.y <= 0.0f && preset.z <= 0.0f) col = preset;
       else {
-        const uint32_t hInst = h.id >> 24, hPrim = h.id & 0xFFFFFFu;
+        const uint32_t hInst = hitId >> 24;
+        uint32_t hPrim = hitId & 0xFFFFFFu;
+        // hipcc 7.2 drops this mask when the same id also indexes a two-element array (it then addresses the triangle
+        // with the whole id: a fault for every hit on instance 1): keep it behind a barrier, and select instead of index
+        asm volatile("" : "+v"(hPrim));
         const Tri3 v = getVertices(hInst ? A.verts1 : A.verts0, hInst ? A.idx1 : A.idx0, hPrim);
-        const Attrib a = interpAttrib(v, h.b1, h.b2);
+        // the hit attributes (barycentrics) of the recorded triangle: the traversal's own test, repeated
+        float ht, hb1 = 0.0f, hb2 = 0.0f;
+        woopTestVerts(toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, hInst ? fp.invWorld[1] : fp.invWorld[0]), v.pos[0], v.pos[1], v.pos[2], ht, hb1, hb2);
+        const Attrib a = interpAttrib(v, hb1, hb2);
         const f3 N = normalize3(mulDir(a.Nrm, cbLoad3x3(hInst ? fp.g.WorldIT1 : fp.g.WorldITs0)));
         const f2 rm = getRoughMetal(fp.mat, hInst, a.UV);
         f3 color = mk3(fp.mat.BaseColors[hInst][0], fp.mat.BaseColors[hInst][1], fp.mat.BaseColors[hInst][2]);
@@ -401,7 +411,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   G.roughMetalPrev = c->roughMetalBuf[c->setIndex ^ 1u]; G.diffPrev = c->rtDiffBuf[c->setIndex ^ 1u];
   G.verts0 = c->mesh[0].verts; G.idx0 = c->mesh[0].indices; G.verts1 = c->mesh[1].verts; G.idx1 = c->mesh[1].indices;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
-  G.rays = (RayRec*)c->rayQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;
+  G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;
   G.tilesX = tilesX; G.numTiles = tilesX * tilesY; G.rowBegin = rb; G.rowEnd = re;
   hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, G);
   if (c->timing) hipEventRecord(c->tev[11], s);
@@ -420,7 +430,7 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   if (re <= rb) return 0;
   const uint32_t numTiles = ((fp.W + 15) / 16) * ((re - rb + 15) / 16);
   ShadeArgs S;
-  S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitRec*)c->hitQueue; S.binCount = c->binCount;
+  S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitKey*)c->hitQueue; S.binCount = c->binCount;
   S.verts0 = c->mesh[0].verts; S.idx0 = c->mesh[0].indices; S.verts1 = c->mesh[1].verts; S.idx1 = c->mesh[1].indices;
   S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;
   S.reflOut = c->rtRefl; S.diffOut = c->rtDiff;
@@ -430,7 +440,7 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
 }
 
 // ---- test entry: closest-hit queries for an explicit ray list (through the same trace kernel) ---------------
-__global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec* q0, uint32_t* binCount) {
+__global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec* q0, HitKey* keys, uint32_t* binCount) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i % RT_BIN == 0 && i < n) binCount[i / RT_BIN] = n - i < RT_BIN ? n - i : RT_BIN;   // bins are filled densely, in order
   if (i >= n) return;
@@ -439,23 +449,38 @@ __global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec
   rr.ox = r[0]; rr.oy = r[1]; rr.oz = r[2]; rr.tmin = r[6]; rr.dx = r[3]; rr.dy = r[4]; rr.dz = r[5]; rr.tmax = r[7];
   rr.pixel = 0u; rr.skip = 0xFFFFFFFFu; rr.flags = 0u; rr.pad = 0u; rr.wx = rr.wy = rr.wz = rr.wpad = 0.0f;
   q0[i] = rr;
+  keys[i] = hitKey(rr.tmax, 0xFFFFFFFFu);
 }
-__global__ void exportTestHits(const HitRec* __restrict__ hits, uint32_t n, float* __restrict__ out) {
+__global__ void exportTestHits(const FrameParams* __restrict__ fpp, const RayRec* __restrict__ rays, const HitKey* __restrict__ hits, uint32_t n,
+                               const float* __restrict__ verts0, const uint32_t* __restrict__ idx0, const float* __restrict__ verts1, const uint32_t* __restrict__ idx1,
+                               float* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const HitRec h = hits[i];
+  const HitKey k = hits[i];
+  const uint32_t id = hitKeyId(k);
   float* o = out + 6 * (size_t)i;
-  const bool valid = h.id != 0xFFFFFFFFu;
-  o[0] = h.t; o[1] = u2f(valid ? h.id >> 24 : 0u); o[2] = u2f(valid ? h.id & 0xFFFFFFu : 0u); o[3] = h.b1; o[4] = h.b2; o[5] = valid ? 1.0f : 0.0f;
+  const bool valid = id != 0xFFFFFFFFu;
+  float t = hitKeyT(k), b1 = 0.0f, b2 = 0.0f;
+  if (valid) {
+    const RayRec rr = rays[i];
+    const uint32_t inst = id >> 24;
+    uint32_t prim = id & 0xFFFFFFu;
+    // (same compiler hazard as in shadeKernel: keep the mask behind a barrier)
+    asm volatile("" : "+v"(prim));
+    const Tri3 v = getVertices(inst ? verts1 : verts0, inst ? idx1 : idx0, prim);
+    woopTestVerts(toObject(rr.ox, rr.oy, rr.oz, rr.dx, rr.dy, rr.dz, inst ? fpp->invWorld[1] : fpp->invWorld[0]), v.pos[0], v.pos[1], v.pos[2], t, b1, b2);
+  }
+  o[0] = t; o[1] = u2f(valid ? id >> 24 : 0u); o[2] = u2f(valid ? id & 0xFFFFFFu : 0u); o[3] = b1; o[4] = b2; o[5] = valid ? 1.0f : 0.0f;
 }
 int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s) {
   if (!n) return 0;
   if (n > c->numBinsMax * RT_BIN) { setError("rtggx_trace_rays: at most %u rays per launch", c->numBinsMax * RT_BIN); return -1; }
   const uint32_t numBins = (((n + RT_BIN - 1u) / RT_BIN) + 3u) & ~3u;   // whole tiles of four bins
   RT_HIP(hipMemsetAsync(c->binCount, 0, (size_t)numBins * 4, s));
-  hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, c->binCount);
+  hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, (HitKey*)c->hitQueue, c->binCount);
   { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u); if (r) return r; }
-  hipLaunchKernelGGL(exportTestHits, dim3((n + 255) / 256), dim3(256), 0, s, (const HitRec*)c->hitQueue, n, dOut);
+  hipLaunchKernelGGL(exportTestHits, dim3((n + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, (const RayRec*)c->rayQueue, (const HitKey*)c->hitQueue, n,
+                     c->mesh[0].verts, c->mesh[0].indices, c->mesh[1].verts, c->mesh[1].indices, dOut);
   RT_HIP(hipGetLastError());
   return 0;
 }

@@ -1,4 +1,4 @@
-// Ray / hit records exchanged between the three kernels of the ray-tracing pass (raytrace.hip, trace.hip).
+// Ray records / hit keys exchanged between the three kernels of the ray-tracing pass (raytrace.hip, trace.hip).
 //
 // No atomics anywhere on this path: every wave of rayGenKernel owns one BIN of RT_BIN ray slots (its 8x8 pixel
 // sub-tile, at most one reflection and one diffuse ray per pixel), compacts its rays into the front of the bin
@@ -11,7 +11,7 @@
 
 namespace rt {
 
-#define RT_BIN 128u          // ray slots per bin = 2 rays x 64 pixels
+#define RT_BIN 128u          // ray slots per bin = 2 rays x 64 pixels (64-byte ray record + 8-byte hit key per slot)
 
 // 64-byte ray record
 struct __attribute__((aligned(16))) RayRec {
@@ -20,8 +20,14 @@ struct __attribute__((aligned(16))) RayRec {
   uint32_t pixel, skip /* (inst<<24)|prim the ray starts on, ~0 none */, flags /* bit0: diffuse hit group */, pad;
   float wx, wy, wz, wpad;   // BRDF weight applied to the returned radiance
 };
-// 16-byte hit record
-struct __attribute__((aligned(16))) HitRec { float t, b1, b2; uint32_t id; /* (inst<<24)|prim, ~0 = miss */ };
+// 8-byte hit key of a ray slot: (bits of t << 32) | id, id = (inst<<24)|prim, ~0 = miss.  t > 0, so keys order like
+// (t, id): the closest-hit rule (smaller t, ties to the smaller id) is a 64-bit unsigned min, and every job that
+// walks part of a ray's tree merges what it found with one fire-and-forget atomicMin.  rayGenKernel initialises the
+// key to (TMax, miss); barycentrics are re-derived from (ray, triangle) by whoever needs them (rt_traverse.h).
+typedef unsigned long long HitKey;
+RT_HD HitKey hitKey(float t, uint32_t id) { union { float f; uint32_t u; } c; c.f = t; return ((HitKey)c.u << 32) | id; }
+RT_HD float hitKeyT(HitKey k) { union { float f; uint32_t u; } c; c.u = (uint32_t)(k >> 32); return c.f; }
+RT_HD uint32_t hitKeyId(HitKey k) { return (uint32_t)k; }
 
 // Traversal of the rays in bins [0, numBins) (trace.hip).  countRays: add the rays of rows [fp.rowBegin, fp.rowEnd)
 // to the per-frame counters.  tilesX x tilesY: the tile grid the bins come from (4 bins per tile), 0 for a plain list.

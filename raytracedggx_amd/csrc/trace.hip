@@ -24,6 +24,7 @@
 // order in which boxes are visited, so the 4-wide collapse, the work sharing and the postponed triangle tests
 // leave every hit record bit-identical to the oracle's binary-tree walk (tests/test_gpu_parity.py).
 #include "rt_queue.h"
+#include "rt_traverse.h"
 
 namespace rt {
 
@@ -34,7 +35,7 @@ struct TraceArgs {
   const float4* nodes1; const float4* tris1;
   int32_t root0, root1;
   uint32_t haveMesh0, haveMesh1;
-  const RayRec* rays; HitRec* hits;
+  const RayRec* rays; HitKey* hits;
   const uint32_t* binCount; uint32_t numBins;
   int32_t* overflow;        // [entry][numBinsMax * RT_BIN] spill area for stacks deeper than RT_STACK
   uint32_t* rayTotals;       // 256 per-frame partial counters (+ RT_TRACE_STATS words from 256)
@@ -44,65 +45,6 @@ struct TraceArgs {
   uint32_t tilesX, tilesY;   // tile grid of the frame (4 bins per 16x16 tile); tilesX == 0: bins are a plain list (rtggx_trace_rays)
 };
 
-struct LaneRay {
-  float ox, oy, oz, ix, iy, iz;     // object-space origin, reciprocal direction
-  float Sx, Sy, Sz;                 // Woop shear
-  int kx, ky, kz;
-};
-
-RT_DEV float pick3(float a, float b, float c, int k) { return k == 0 ? a : (k == 1 ? b : c); }
-
-RT_DEV LaneRay toObject(float wox, float woy, float woz, float wdx, float wdy, float wdz, const float* __restrict__ inv) {
-  LaneRay r;
-  r.ox = ((wox * inv[0] + woy * inv[4]) + woz * inv[8]) + inv[12];
-  r.oy = ((wox * inv[1] + woy * inv[5]) + woz * inv[9]) + inv[13];
-  r.oz = ((wox * inv[2] + woy * inv[6]) + woz * inv[10]) + inv[14];
-  const float dx = (wdx * inv[0] + wdy * inv[4]) + wdz * inv[8];
-  const float dy = (wdx * inv[1] + wdy * inv[5]) + wdz * inv[9];
-  const float dz = (wdx * inv[2] + wdy * inv[6]) + wdz * inv[10];
-  r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
-  const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-  r.kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-  r.kx = (r.kz + 1) % 3; r.ky = (r.kx + 1) % 3;
-  const float dkz = pick3(dx, dy, dz, r.kz);
-  if (dkz < 0.0f) { const int t = r.kx; r.kx = r.ky; r.ky = t; }
-  r.Sx = pick3(dx, dy, dz, r.kx) / dkz; r.Sy = pick3(dx, dy, dz, r.ky) / dkz; r.Sz = 1.0f / dkz;
-  return r;
-}
-
-RT_DEV bool woopTest(const LaneRay& r, const float4 t0, const float4 t1, const float4 t2, float& t, float& b1, float& b2) {
-  // t0 = v0.xyz v1.x | t1 = v1.yz v2.xy | t2 = v2.z pad pad pad
-  const float Ax0 = t0.x - r.ox, Ay0 = t0.y - r.oy, Az0 = t0.z - r.oz;
-  const float Bx0 = t0.w - r.ox, By0 = t1.x - r.oy, Bz0 = t1.y - r.oz;
-  const float Cx0 = t1.z - r.ox, Cy0 = t1.w - r.oy, Cz0 = t2.x - r.oz;
-  const float Akz = pick3(Ax0, Ay0, Az0, r.kz), Bkz = pick3(Bx0, By0, Bz0, r.kz), Ckz = pick3(Cx0, Cy0, Cz0, r.kz);
-  const float Ax = pick3(Ax0, Ay0, Az0, r.kx) - r.Sx * Akz, Ay = pick3(Ax0, Ay0, Az0, r.ky) - r.Sy * Akz;
-  const float Bx = pick3(Bx0, By0, Bz0, r.kx) - r.Sx * Bkz, By = pick3(Bx0, By0, Bz0, r.ky) - r.Sy * Bkz;
-  const float Cx = pick3(Cx0, Cy0, Cz0, r.kx) - r.Sx * Ckz, Cy = pick3(Cx0, Cy0, Cz0, r.ky) - r.Sy * Ckz;
-  float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
-  if (U == 0.0f || V == 0.0f || W == 0.0f) {
-    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
-    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
-    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
-  }
-  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
-  const float det = (U + V) + W;
-  if (det == 0.0f) return false;
-  const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
-  const float T = (U * Az + V * Bz) + W * Cz;
-  const float rdet = 1.0f / det;
-  t = T * rdet; b1 = V * rdet; b2 = W * rdet;
-  return true;
-}
-
-RT_DEV void slabTest(const LaneRay& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float tmin, float tmax, float& tn, float& tf) {
-  const float x1 = (mnx - r.ox) * r.ix, x2 = (mxx - r.ox) * r.ix;
-  const float y1 = (mny - r.oy) * r.iy, y2 = (mxy - r.oy) * r.iy;
-  const float z1 = (mnz - r.oz) * r.iz, z2 = (mxz - r.oz) * r.iz;
-  tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fmaxf(fminf(z1, z2), tmin));
-  tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fminf(fmaxf(z1, z2), tmax));
-}
-
 // Wave w of the grid traces the rays of bin w, 64 at a time (a second round only where a sub-tile has more than 64
 // rays, i.e. diffuse rays besides the reflection rays).
 //
@@ -110,20 +52,16 @@ RT_DEV void slabTest(const LaneRay& r, float mnx, float mny, float mnz, float mx
 // wave runs at 44% lane utilisation and the kernel ends with a long tail of waves in which one lane chases one ray
 // at ~2000 cycles per dependent step.  So a lane is not tied to its ray: the unit of work is a JOB -- a subtree of
 // one ray -- and in every step in which at least half of the lanes have no job, those lanes take the BOTTOM stack
-// entry (the farthest, largest pending subtree) of lanes that have one.  The helper copies the ray and the victim's best hit so far, walks the subtree
-// with its own stack and merges what it finds into the ray's record in LDS: key = (t bits << 32) | id, combined
-// with a 64-bit min, which is exactly the closest-hit rule (smaller t, then smaller id) whatever the order in
-// which the subtrees finish.  pending[] counts the helpers of a ray; its hit record is written when the primary
-// job has ended and pending is 0.
+// entry (the farthest, largest pending subtree) of lanes that have one.  The helper copies the ray and the victim's
+// best hit so far, walks the subtree with its own stack and merges what it finds into the ray's hit key (rt_queue.h)
+// with a 64-bit atomic min, which is exactly the closest-hit rule (smaller t, then smaller id) whatever the order in
+// which the subtrees finish.  Nobody waits for anybody: the kernel boundary is the only join.
 // Tuned on the 1080p bunny frame (tools/sweep: kernel 0.26 ms without sharing, 0.19 ms with these):
 #define RT_STEAL_MIN_IDLE 32u    // share work once half of the lanes have none
 #define RT_STEAL_ROUNDS 2        // entries a lane can give away per step
 #define RT_LEAF_BATCH 8u         // lanes standing on a leaf that make a triangle-test phase worthwhile
 __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
   __shared__ int32_t stackMem[RT_STACK * 256];
-  __shared__ unsigned long long keyMem[256];       // per ray (owner lane): best (t, id) over all its jobs
-  __shared__ float2 baryMem[256];                  // barycentrics of that hit
-  __shared__ uint32_t pendingMem[256];             // helpers still walking subtrees of the ray
   __shared__ uint32_t victimMem[256];              // scratch: the lanes offering work, compacted
   const FrameParams& fp = *fpp;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -145,8 +83,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   if (count == 0u) return;
   int32_t* const stackBase = stackMem + wave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
   int32_t* const stack = stackBase + lane;
-  unsigned long long* const key = keyMem + wave * 64; float2* const bary = baryMem + wave * 64;
-  uint32_t* const pending = pendingMem + wave * 64; uint32_t* const victims = victimMem + wave * 64;
+  uint32_t* const victims = victimMem + wave * 64;
   const size_t spillStride = A.spillStride;
   int32_t* const spill = A.overflow + bin * RT_BIN + lane;                               // entry e at spill[e * spillStride]
   const unsigned long long laneLt = (1ull << lane) - 1ull;
@@ -157,14 +94,14 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
 #endif
   for (uint32_t base = 0; base < count; base += 64u) {
   const uint32_t slot = bin * RT_BIN + base + lane;
-  bool hasRay = base + lane < count;                 // my slot holds a ray whose hit record is not written yet
+  const bool hasRay = base + lane < count;
 
   // ---- the ray: world space -> the object spaces of both instances --------------------------------------------
   const float4* rp = reinterpret_cast<const float4*>(A.rays + (hasRay ? slot : bin * RT_BIN));
   const float4 ra = rp[0], rb = rp[1];
   const uint4 rc = reinterpret_cast<const uint4*>(rp)[2];
   float tmin = ra.w;
-  float bestT = rb.w, bestB1 = 0.0f, bestB2 = 0.0f;
+  float bestT = rb.w;
   uint32_t bestId = 0xFFFFFFFFu;
   uint32_t skip = rc.y;
   uint32_t inst = A.haveMesh0 ? 0u : 1u;
@@ -176,18 +113,12 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
     const uint32_t row = rc.x / A.width;
     if (hasRay && row >= A.countRowBegin && row < A.countRowEnd) ++nRays;
   }
-  if (hasRay && (!(bestT > tmin) || (inst == 1u && A.haveMesh1 == 0u))) {   // degenerate interval / empty scene: a miss
-    HitRec h; h.t = bestT; h.b1 = 0.0f; h.b2 = 0.0f; h.id = 0xFFFFFFFFu; A.hits[slot] = h;
-    hasRay = false;
-  }
-  // job state: the primary job of my own ray
-  bool job = hasRay, helper = false, primaryDone = !hasRay;
-  uint32_t owner = lane;
-  key[lane] = ((unsigned long long)__float_as_uint(bestT) << 32) | 0xFFFFFFFFull;
-  pending[lane] = 0u;
+  // job state: the primary job of my own ray (none for a degenerate interval or an empty scene: the key stays a miss)
+  bool job = hasRay && bestT > tmin && !(inst == 1u && A.haveMesh1 == 0u), helper = false;
+  uint32_t owner = slot;                             // the ray slot whose key this job's hits go to
 
   // ---- traversal -----------------------------------------------------------------------------------------------
-  while (__ballot(job || hasRay)) {
+  while (__ballot(job)) {
     // -- idle lanes take over pending subtrees
     if ((uint32_t)__popcll(__ballot(!job)) >= RT_STEAL_MIN_IDLE) {
       for (int round = 0; round < RT_STEAL_ROUNDS; ++round) {
@@ -205,16 +136,15 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
         const float v_ix = __shfl(r.ix, (int)v), v_iy = __shfl(r.iy, (int)v), v_iz = __shfl(r.iz, (int)v);
         const float v_Sx = __shfl(r.Sx, (int)v), v_Sy = __shfl(r.Sy, (int)v), v_Sz = __shfl(r.Sz, (int)v);
         const int v_kx = __shfl(r.kx, (int)v), v_ky = __shfl(r.ky, (int)v), v_kz = __shfl(r.kz, (int)v);
-        const float v_tmin = __shfl(tmin, (int)v), v_bestT = __shfl(bestT, (int)v), v_b1 = __shfl(bestB1, (int)v), v_b2 = __shfl(bestB2, (int)v);
+        const float v_tmin = __shfl(tmin, (int)v), v_bestT = __shfl(bestT, (int)v);
         const uint32_t v_bestId = (uint32_t)__shfl((int)bestId, (int)v), v_skip = (uint32_t)__shfl((int)skip, (int)v);
         const uint32_t v_inst = (uint32_t)__shfl((int)inst, (int)v), v_owner = (uint32_t)__shfl((int)owner, (int)v);
         if (thief) {
           cur = stackBase[vsb * 64 + (int)v];
           r.ox = v_ox; r.oy = v_oy; r.oz = v_oz; r.ix = v_ix; r.iy = v_iy; r.iz = v_iz; r.Sx = v_Sx; r.Sy = v_Sy; r.Sz = v_Sz;
           r.kx = v_kx; r.ky = v_ky; r.kz = v_kz;
-          tmin = v_tmin; bestT = v_bestT; bestB1 = v_b1; bestB2 = v_b2; bestId = v_bestId; skip = v_skip; inst = v_inst; owner = v_owner;
+          tmin = v_tmin; bestT = v_bestT; bestId = v_bestId; skip = v_skip; inst = v_inst; owner = v_owner;
           sp = sb = 0; job = true; helper = true;
-          atomicAdd(&pending[owner], 1u);
 #ifdef RT_TRACE_STATS
           ++stSteal;
 #endif
@@ -292,7 +222,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
             if (woopTest(r, q0, q1, q2, t, b1, b2) && t > tmin) {
               const bool closer = t < bestT;
               const bool tie = bestId != 0xFFFFFFFFu && t == bestT && id < bestId;
-              if (closer || tie) { bestT = t; bestId = id; bestB1 = b1; bestB2 = b2; }
+              if (closer || tie) { bestT = t; bestId = id; }
             }
           }
           popOrFinish();
@@ -302,23 +232,11 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
         }
       }
     }
-    // -- finished jobs merge their best hit into the ray's record; complete rays are written out
-    if (__ballot(finished)) {
-      const unsigned long long mine = ((unsigned long long)__float_as_uint(bestT) << 32) | bestId;
-      if (finished) atomicMin(&key[owner], mine);
-      if (finished) {
-        if (bestId != 0xFFFFFFFFu && key[owner] == mine) bary[owner] = make_float2(bestB1, bestB2);
-        if (helper) atomicSub(&pending[owner], 1u); else primaryDone = true;
-        helper = false; owner = lane;
-      }
-    }
-    if (hasRay && primaryDone && pending[lane] == 0u) {
-      const unsigned long long k = key[lane];
-      HitRec h; h.t = __uint_as_float((uint32_t)(k >> 32)); h.id = (uint32_t)k;
-      const float2 bb = h.id != 0xFFFFFFFFu ? bary[lane] : make_float2(0.0f, 0.0f);
-      h.b1 = bb.x; h.b2 = bb.y;
-      A.hits[slot] = h;
-      hasRay = false;
+    // -- a finished job merges its best hit into the ray's key (a helper that found nothing closer than what it started
+    //    with repeats its victim's candidate: harmless)
+    if (finished) {
+      if (bestId != 0xFFFFFFFFu) atomicMin(&A.hits[owner], hitKey(bestT, bestId));
+      helper = false;
     }
   }
   }   // base
@@ -360,7 +278,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.nodes1 = (const float4*)(have1 && c->mesh[1].nodes4 ? (const void*)c->mesh[1].nodes4 : c->dummyRecord);
   T.tris1 = (const float4*)(have1 ? (const void*)c->mesh[1].tris : c->dummyRecord);
   T.root0 = c->mesh[0].root; T.root1 = c->mesh[1].root; T.haveMesh0 = have0; T.haveMesh1 = have1;
-  T.rays = (const RayRec*)c->rayQueue; T.hits = (HitRec*)c->hitQueue;
+  T.rays = (const RayRec*)c->rayQueue; T.hits = (HitKey*)c->hitQueue;
   T.binCount = c->binCount; T.numBins = numBins;
   // stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get
   // (a 4-wide node leaves at most 3 entries behind, and there is one per two levels of the binary tree)

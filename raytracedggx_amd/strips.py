@@ -138,9 +138,9 @@ class StripRenderer:
 
     def trace_kernel_algorithmic_bytes(self, rays_per_launch):
         """DESIGN.md "Roofline": what one launch of traceKernel has to move if every byte moved once -- a 64-byte ray
-        record in and a 16-byte hit record out per ray, plus the acceleration structure once (the 4-wide nodes in use
+        record in and an 8-byte hit key out per ray, plus the acceleration structure once (the 4-wide nodes in use
         and the leaf triangles of both instances)."""
-        return 80 * rays_per_launch + self.bvh_bytes()
+        return 72 * rays_per_launch + self.bvh_bytes()
 
     def bvh_bytes(self):
         if not hasattr(self, "_bvh_bytes"):
