@@ -57,9 +57,15 @@ struct TraceArgs {
 // with a 64-bit atomic min, which is exactly the closest-hit rule (smaller t, then smaller id) whatever the order in
 // which the subtrees finish.  Nobody waits for anybody: the kernel boundary is the only join.
 // Tuned on the 1080p bunny frame (tools/sweep: kernel 0.26 ms without sharing, 0.19 ms with these):
+#ifndef RT_STEAL_MIN_IDLE
 #define RT_STEAL_MIN_IDLE 32u    // share work once half of the lanes have none
+#endif
+#ifndef RT_STEAL_ROUNDS
 #define RT_STEAL_ROUNDS 2        // entries a lane can give away per step
+#endif
+#ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 8u         // lanes standing on a leaf that make a triangle-test phase worthwhile
+#endif
 __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
   __shared__ int32_t stackMem[RT_STACK * 256];
   __shared__ uint32_t victimMem[256];              // scratch: the lanes offering work, compacted
