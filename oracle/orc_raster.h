@@ -10,8 +10,11 @@
 // to 1.0, depth clip to [0,1].  Choices where the spec leaves latitude:
 //   * z is interpolated with barycentrics from the snapped integer edge functions, in double;
 //   * D24 = floor(z * (2^24-1) + 0.5);
-//   * triangles with a vertex at w <= 0 or snapped coordinates beyond +-2^30 are dropped
-//     (no near-plane / guard-band clipping yet -- not reached by any BASELINE config).
+//   * near plane: a triangle with vertices on both sides of z_clip = 0 is clipped (Sutherland-Hodgman, one plane,
+//     new vertices by fp32 interpolation in clip space from the inside vertex towards the outside one, z set to 0)
+//     into one or two triangles that share the primitive id; the far plane needs no geometry (z <= 1 per pixel);
+//   * a (sub-)triangle with a vertex at w <= 0 or snapped coordinates beyond +-2^30 is dropped (no guard-band
+//     clipping: not reached by any BASELINE config).
 // Equal depth keeps the earlier fragment (LESS): lower instance first, then lower primitive.
 #pragma once
 #include "orc_scene.h"
@@ -20,10 +23,15 @@ namespace orc {
 
 struct RasterVert { int64_t X, Y; float z; bool ok; };
 
-static inline RasterVert raster_vertex(const float* pos, const M4& wvp, const float bias[2], uint32_t W, uint32_t H) {
+// clip-space position of a vertex (VSVisibility.hlsl:26-32)
+static inline float4 clip_vertex(const float* pos, const M4& wvp, const float bias[2]) {
   float4 p = mul_point(f3(pos[0], pos[1], pos[2]), wvp);
   p.x += bias[0] * p.w;
   p.y += bias[1] * p.w;
+  return p;
+}
+// viewport transform + snapping to 8 sub-pixel bits
+static inline RasterVert raster_vertex(const float4& p, uint32_t W, uint32_t H) {
   RasterVert r{0, 0, 0.0f, false};
   if (!(p.w > 0.0f)) return r;
   const float nx = p.x / p.w, ny = p.y / p.w;
@@ -34,6 +42,23 @@ static inline RasterVert raster_vertex(const float* pos, const M4& wvp, const fl
   if (!(std::fabs(fx) < 1073741824.0f) || !(std::fabs(fy) < 1073741824.0f)) return r;
   r.X = (int64_t)fx; r.Y = (int64_t)fy; r.ok = true;
   return r;
+}
+// Near-plane clip of one triangle: writes 0, 3 or 4 vertices (a convex polygon in the input's winding) and returns
+// the count.  A vertex with z >= 0 is inside.
+static inline int clip_near(const float4 in[3], float4 out[4]) {
+  int n = 0;
+  for (int k = 0; k < 3; ++k) {
+    const float4& a = in[k]; const float4& b = in[(k + 1) % 3];
+    const bool ia = a.z >= 0.0f, ib = b.z >= 0.0f;
+    if (ia) out[n++] = a;
+    if (ia != ib) {
+      const float4& p = ia ? a : b; const float4& q = ia ? b : a;       // from the inside vertex to the outside one
+      const float t = p.z / (p.z - q.z);
+      float4 c; c.x = p.x + (q.x - p.x) * t; c.y = p.y + (q.y - p.y) * t; c.z = 0.0f; c.w = p.w + (q.w - p.w) * t;
+      out[n++] = c;
+    }
+  }
+  return n;
 }
 
 static inline bool is_top_left(int64_t ax, int64_t ay, int64_t bx, int64_t by) {
@@ -52,10 +77,15 @@ static inline void render_visibility(Ctx& c) {
     const float* bias = c.fc.po[inst].ProjBias;
     const uint32_t ntri = (uint32_t)(m.idx.size() / 3);
     for (uint32_t prim = 0; prim < ntri; ++prim) {
+      float4 cp[3], poly[4];
+      for (int k = 0; k < 3; ++k) cp[k] = clip_vertex(&m.verts[6 * (size_t)m.idx[3 * prim + k]], wvp, bias);
+      const bool allIn = cp[0].z >= 0.0f && cp[1].z >= 0.0f && cp[2].z >= 0.0f;
+      int nv = 3;
+      if (allIn) { poly[0] = cp[0]; poly[1] = cp[1]; poly[2] = cp[2]; } else nv = clip_near(cp, poly);
+      for (int sub = 0; sub + 2 < nv; ++sub) {          // fan: (0,1,2), (0,2,3)
       RasterVert v[3];
-      bool ok = true;
-      for (int k = 0; k < 3; ++k) { v[k] = raster_vertex(&m.verts[6 * (size_t)m.idx[3 * prim + k]], wvp, bias, W, H); ok = ok && v[k].ok; }
-      if (!ok) continue;
+      v[0] = raster_vertex(poly[0], W, H); v[1] = raster_vertex(poly[sub + 1], W, H); v[2] = raster_vertex(poly[sub + 2], W, H);
+      if (!(v[0].ok && v[1].ok && v[2].ok)) continue;
       const int64_t area2 = (v[1].X - v[0].X) * (v[2].Y - v[0].Y) - (v[1].Y - v[0].Y) * (v[2].X - v[0].X);
       if (area2 <= 0) continue;                                         // back-facing or degenerate
       int64_t minX = std::min(v[0].X, std::min(v[1].X, v[2].X)), maxX = std::max(v[0].X, std::max(v[1].X, v[2].X));
@@ -87,6 +117,7 @@ static inline void render_visibility(Ctx& c) {
         uint64_t& dst = key[(size_t)py * W + (size_t)px];
         if (k < dst) dst = k;
       }
+      }   // sub
     }
   }
   c.vis.resize((size_t)W * H); c.depth.resize((size_t)W * H);

@@ -22,10 +22,15 @@ struct LargeTri { int32_t X[3], Y[3]; float z[3]; uint32_t word; double invA; ui
 
 struct RVert { long long X, Y; float z; bool ok; };
 
-RT_DEV RVert rasterVertex(const float* __restrict__ pos, const M4& wvp, float bx, float by, uint32_t W, uint32_t H) {
+// clip-space position of a vertex (VSVisibility.hlsl:26-32)
+RT_DEV f4 clipVertex(const float* __restrict__ pos, const M4& wvp, float bx, float by) {
   f4 p = mulPoint(mk3(pos[0], pos[1], pos[2]), wvp);
   p.x += bx * p.w;
   p.y += by * p.w;
+  return p;
+}
+// viewport transform + snapping to 8 sub-pixel bits
+RT_DEV RVert rasterVertex(f4 p, uint32_t W, uint32_t H) {
   RVert r; r.X = 0; r.Y = 0; r.z = 0.0f; r.ok = false;
   if (!(p.w > 0.0f)) return r;
   const float nx = p.x / p.w, ny = p.y / p.w;
@@ -36,6 +41,25 @@ RT_DEV RVert rasterVertex(const float* __restrict__ pos, const M4& wvp, float bx
   if (!(fabsf(fx) < 1073741824.0f) || !(fabsf(fy) < 1073741824.0f)) return r;
   r.X = (long long)fx; r.Y = (long long)fy; r.ok = true;
   return r;
+}
+// Near-plane clip of one triangle (D3D clips to 0 <= z; the far side is a per-pixel z <= 1 test): 0, 3 or 4 vertices of a
+// convex polygon in the input's winding.  New vertices are interpolated in clip space, fp32, from the inside vertex
+// towards the outside one, and sit exactly on the plane (z = 0).
+RT_DEV int clipNear(const f4 in[3], f4 out[4]) {
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const f4 a = in[k], b = in[(k + 1) % 3];
+    const bool ia = a.z >= 0.0f, ib = b.z >= 0.0f;
+    if (ia) out[n++] = a;
+    if (ia != ib) {
+      const f4 p = ia ? a : b, q = ia ? b : a;
+      const float t = p.z / (p.z - q.z);
+      f4 c; c.x = p.x + (q.x - p.x) * t; c.y = p.y + (q.y - p.y) * t; c.z = 0.0f; c.w = p.w + (q.w - p.w) * t;
+      out[n++] = c;
+    }
+  }
+  return n;
 }
 RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
   const long long dx = bx - ax, dy = by - ay;
@@ -94,58 +118,65 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict
     const uint32_t* idx = inst ? i1 : i0;
     const M4 wvp = cbLoad4x4(fp.po[inst].WorldViewProj);
     const float bx = fp.po[inst].ProjBias[0], by = fp.po[inst].ProjBias[1];
-    long long X[3], Y[3]; float z[3];
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const RVert r = rasterVertex(verts + 6 * (size_t)idx[3 * (size_t)prim + k], wvp, bx, by, fp.W, fp.H);
-      X[k] = r.X; Y[k] = r.Y; z[k] = r.z; ok = ok && r.ok;
-    }
-    const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
-    if (ok && area2 > 0) {
+    const uint32_t word = ((inst << 24) | prim) + 1u;
+    // One (sub-)triangle in clip space: project, snap, cull, box; small boxes are parked for phase 2 (at most one per
+    // lane: sub-triangles of a clipped triangle always go to the tile pass), big ones queued for rasterLarge.
+    auto emit = [&](f4 c0, f4 c1, f4 c2, bool toTilePass) {
+      const RVert r0 = rasterVertex(c0, fp.W, fp.H), r1 = rasterVertex(c1, fp.W, fp.H), r2 = rasterVertex(c2, fp.W, fp.H);
+      if (!(r0.ok && r1.ok && r2.ok)) return;
+      const long long X[3] = {r0.X, r1.X, r2.X}, Y[3] = {r0.Y, r1.Y, r2.Y}; const float z[3] = {r0.z, r1.z, r2.z};
+      const long long area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+      if (area2 <= 0) return;
       const long long minX = min(X[0], min(X[1], X[2])), maxX = max(X[0], max(X[1], X[2]));
       const long long minY = min(Y[0], min(Y[1], Y[2])), maxY = max(Y[0], max(Y[1], Y[2]));
       long long px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
       long long py0 = (minY - 128 + 255) >> 8, py1 = (maxY - 128) >> 8;
       px0 = max(px0, 0ll); py0 = max(py0, (long long)rowBegin);
       px1 = min(px1, (long long)fp.W - 1); py1 = min(py1, (long long)rowEnd - 1);
-      if (px0 <= px1 && py0 <= py1) {
-        const uint32_t word = ((inst << 24) | prim) + 1u;
-        const long long area = (px1 - px0 + 1) * (py1 - py0 + 1);
-        const bool tl0 = isTopLeft(X[1], Y[1], X[2], Y[2]), tl1 = isTopLeft(X[2], Y[2], X[0], Y[0]), tl2 = isTopLeft(X[0], Y[0], X[1], Y[1]);
-        const double invA = 1.0 / (double)area2;
-        bool here = area <= RT_SMALL_BOX;
-        if (!here) {
-          const uint32_t slot = atomicAdd(largeCount, 1u);
-          if (slot < largeCap) {
-            LargeTri lt;
-            for (int k = 0; k < 3; ++k) { lt.X[k] = (int32_t)X[k]; lt.Y[k] = (int32_t)Y[k]; lt.z[k] = z[k]; }
-            lt.word = word; lt.invA = invA; lt.tl = (tl0 ? 1u : 0u) | (tl1 ? 2u : 0u) | (tl2 ? 4u : 0u); lt.pad = 0u;
-            large[slot] = lt;
-          } else {
-            // queue full (more than 65536 big triangles): rasterise it right here -- correct, slow
-            const double z0 = (double)z[0], dz1 = (double)z[1] - z0, dz2 = (double)z[2] - z0;
-            const int32_t X32[3] = {(int32_t)X[0], (int32_t)X[1], (int32_t)X[2]}, Y32[3] = {(int32_t)Y[0], (int32_t)Y[1], (int32_t)Y[2]};
-            for (long long py = py0; py <= py1; ++py)
-              for (long long px = px0; px <= px1; ++px) {
-                const unsigned long long key = fragmentKey((int32_t)px * 256 + 128, (int32_t)py * 256 + 128, X32, Y32, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
-                if (key == ~0ull) continue;
-                unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
-                if (key < *dst) atomicMin(dst, key);
-              }
-          }
+      if (px0 > px1 || py0 > py1) return;
+      const long long area = (px1 - px0 + 1) * (py1 - py0 + 1);
+      const bool tl0 = isTopLeft(X[1], Y[1], X[2], Y[2]), tl1 = isTopLeft(X[2], Y[2], X[0], Y[0]), tl2 = isTopLeft(X[0], Y[0], X[1], Y[1]);
+      const double invA = 1.0 / (double)area2;
+      if (toTilePass || area > RT_SMALL_BOX) {
+        const uint32_t slot = atomicAdd(largeCount, 1u);
+        if (slot < largeCap) {
+          LargeTri lt;
+          for (int k = 0; k < 3; ++k) { lt.X[k] = (int32_t)X[k]; lt.Y[k] = (int32_t)Y[k]; lt.z[k] = z[k]; }
+          lt.word = word; lt.invA = invA; lt.tl = (tl0 ? 1u : 0u) | (tl1 ? 2u : 0u) | (tl2 ? 4u : 0u); lt.pad = 0u;
+          large[slot] = lt;
         } else {
-          TriSetup ts;
-          for (int k = 0; k < 3; ++k) { ts.X[k] = (int32_t)X[k]; ts.Y[k] = (int32_t)Y[k]; ts.z[k] = z[k]; }
-          ts.word = word; ts.px0 = (int32_t)px0; ts.py0 = (int32_t)py0;
-          const uint32_t bw = (uint32_t)(px1 - px0 + 1);
-          ts.bwTl = bw | (tl0 ? 1u << 16 : 0u) | (tl1 ? 1u << 17 : 0u) | (tl2 ? 1u << 18 : 0u);
-          ts.magic = ((1u << 24) + bw - 1u) / bw;
-          ts.invA = invA;
-          setup[lane] = ts;
-          cnt = (uint32_t)area;
+          // queue full (more than 65536 big triangles): rasterise it right here -- correct, slow
+          const double z0 = (double)z[0], dz1 = (double)z[1] - z0, dz2 = (double)z[2] - z0;
+          const int32_t X32[3] = {(int32_t)X[0], (int32_t)X[1], (int32_t)X[2]}, Y32[3] = {(int32_t)Y[0], (int32_t)Y[1], (int32_t)Y[2]};
+          for (long long py = py0; py <= py1; ++py)
+            for (long long px = px0; px <= px1; ++px) {
+              const unsigned long long key = fragmentKey((int32_t)px * 256 + 128, (int32_t)py * 256 + 128, X32, Y32, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
+              if (key == ~0ull) continue;
+              unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
+              if (key < *dst) atomicMin(dst, key);
+            }
         }
+      } else {
+        TriSetup ts;
+        for (int k = 0; k < 3; ++k) { ts.X[k] = (int32_t)X[k]; ts.Y[k] = (int32_t)Y[k]; ts.z[k] = z[k]; }
+        ts.word = word; ts.px0 = (int32_t)px0; ts.py0 = (int32_t)py0;
+        const uint32_t bw = (uint32_t)(px1 - px0 + 1);
+        ts.bwTl = bw | (tl0 ? 1u << 16 : 0u) | (tl1 ? 1u << 17 : 0u) | (tl2 ? 1u << 18 : 0u);
+        ts.magic = ((1u << 24) + bw - 1u) / bw;
+        ts.invA = invA;
+        setup[lane] = ts;
+        cnt = (uint32_t)area;
       }
+    };
+    f4 cp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cp[k] = clipVertex(verts + 6 * (size_t)idx[3 * (size_t)prim + k], wvp, bx, by);
+    if (cp[0].z >= 0.0f && cp[1].z >= 0.0f && cp[2].z >= 0.0f) emit(cp[0], cp[1], cp[2], false);
+    else {                                            // crosses (or is behind) the near plane: rare
+      f4 poly[4];
+      const int nv = clipNear(cp, poly);
+      if (nv >= 3) emit(poly[0], poly[1], poly[2], true);
+      if (nv == 4) emit(poly[0], poly[2], poly[3], true);
     }
   }
   // exclusive prefix sum of the candidate counts over the wave

@@ -161,6 +161,21 @@ def test_model_off_screen_and_behind_camera(built):
         p.close()
 
 
+def test_model_crossing_the_near_plane(built):
+    """The model stands right beside the camera and reaches behind it: triangles cross z_clip = 0 and w = 0 and are clipped against the
+    near plane (one or two sub-triangles with the primitive's id) instead of being dropped -- same words as the oracle."""
+    p = Pair(320, 180, pos_scale=(14.8, 4.5, -19.9, 1.0), shared_mem=True)     # just to the right of the eye, reaching behind it
+    try:
+        p.frame(); p.check_frame("model around the camera")
+        vis = p.ctx.readback(p.capi.BUF_VISIBILITY)
+        depth = p.ctx.readback(p.capi.BUF_DEPTH)
+        model = vis >= 0x01000001
+        assert model.mean() > 0.05, "the model covers part of the frame"
+        assert (depth[model] < 16777215 // 2).any(), "with fragments close to the near plane"
+    finally:
+        p.close()
+
+
 def _bvh_check(nodes_u32, tris_u32, root, num_tris):
     nodes = nodes_u32.view(np.float32).reshape(-1, 16)
     left, right = nodes_u32[:, 12].view(np.int32), nodes_u32[:, 13].view(np.int32)
