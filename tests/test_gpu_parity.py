@@ -487,3 +487,29 @@ def test_environment_upload_formats(built):
             ctx.set_env(28, size, mips, dds32)           # DXGI_FORMAT_R8G8B8A8_UNORM
     finally:
         ctx.close()
+
+
+def test_context_lifecycle_and_mode_changes(built):
+    """Contexts can be created and destroyed repeatedly, and the per-frame switches of the sample (the [V] shared-memory
+    toggle, metallic changes) can flip between frames without disturbing parity."""
+    import torch
+    free0 = None
+    for cycle in range(7):
+        p = Pair(160, 96)
+        p.frame()
+        p.close()
+        if cycle == 0:                      # the first context also loads the code objects and warms the runtime's pools
+            torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 32 << 20, "device memory is returned on destroy"
+    p = Pair(320, 180)
+    try:
+        for f, (shared, metal) in enumerate(((False, (1.0, 1.0)), (True, (0.25, 0.5)), (False, (0.25, 0.5)), (True, (1.0, 0.0)))):
+            if shared != getattr(p, "_shared", False):
+                p.app.OnKeyUp(ord("V"))                 # the sample's shared-memory toggle
+            p._shared = shared
+            for mesh, m in enumerate(metal):
+                p.ctx.set_metallic(mesh, m); p.o.set_metallic(mesh, m)
+            p.frame(); p.check_frame("mode change frame %d" % f)
+    finally:
+        p.close()
