@@ -124,8 +124,10 @@ void rtggx_destroy(rtggx_context* ctx);
  * filters need) are not touched.  Default: the whole frame. */
 int  rtggx_set_strip(rtggx_context* ctx, uint32_t row_begin, uint32_t row_end);
 
-/* Run every pass on an externally owned hipStream_t (e.g. torch's current stream). NULL restores
- * the context's own streams. */
+/* Make an externally owned hipStream_t the context's MAIN stream: shading, denoise and tone map run on it, and
+ * every result the caller may read (traced images, filtered images, back buffer) is produced in its order.  The
+ * visibility pass, ray generation and traversal keep running ahead on the context's internal stream B, joined
+ * to the main stream by events.  NULL (also the handle of the null stream) restores the context's own stream. */
 int  rtggx_set_stream(rtggx_context* ctx, void* hip_stream);
 
 /* Vertex = {float3 Pos; float3 Nrm} (24 bytes), 32-bit indices, triangle list. */
