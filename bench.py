@@ -101,11 +101,12 @@ def main():
         # HBM bytes per launch from hardware counters: collected in separate rocprofv3 --pmc runs of this same workload
         # (tools/pmc.sh), committed under profiles/; null for other workloads
         traffic, traffic_source = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc_traffic.json")
-        if os.path.exists(tpath) and (W, H, args.mesh, world) == (1920, 1080, "bunny.obj", 1):
-            with open(tpath) as f:
-                traffic = json.load(f)["kernels"]["rt::traceKernel"]["traffic_bytes"]
-            traffic_source = "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+        if tfiles and (W, H, args.mesh, world) == (1920, 1080, "bunny.obj", 1):
+            with open(tfiles[-1]) as f:
+                traffic = json.load(f)["kernels"].get("rt::traceKernel", {}).get("traffic_bytes")
+            traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)" % os.path.basename(tfiles[-1])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
         out = {
             "metric": "Mrays/s + ms/frame, bunny 1920x1080 1spp+denoise, 1/2/4/8 GPUs",

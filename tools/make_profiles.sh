@@ -1,0 +1,40 @@
+#!/bin/bash
+# Regenerates the judged summaries under profiles/ for one tag (run on the GPU box through gpurun, from the repo root):
+#   tools/make_profiles.sh r01_h
+# 1. the default bench line                          -> profiles/<tag>_bench.json
+# 2. rocprofv3 --kernel-trace --stats of the same    -> profiles/<tag>_kernel_stats.csv
+# 3. counter passes (tools/pmc.sh groups 1,2,10,11)  -> profiles/<tag>_pmc_report.txt, profiles/<tag>_pmc_traffic.json
+# Raw rocprofv3 output goes to gpurun_out/profiles_<tag>/ (scratch).  On the GPU box only gpurun_out/ travels back: run
+#   tools/make_profiles.sh <tag> --summaries-only
+# afterwards in the repo to rebuild profiles/<tag>_* from the raw files that came back.
+set -e
+tag=${1:?tag}
+export TMPDIR=/tmp
+out=gpurun_out/profiles_$tag
+mkdir -p "$out" profiles
+if [ "$2" != "--summaries-only" ]; then
+python3 bench.py > "$out/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o run --output-format csv -- python3 bench.py --no-cpu-baseline > "$out/trace.log" 2>&1
+tools/pmc.sh "$out/pmc" 1 2 > /dev/null
+tools/pmc.sh "$out/pmc" 10 11 > /dev/null
+fi
+grep '^{' "$out/bench.log" | tail -n 1 > "profiles/${tag}_bench.json"
+cp "$out/trace/run_kernel_stats.csv" "profiles/${tag}_kernel_stats.csv"
+python3 tools/pmc_report.py "$out/pmc" > "profiles/${tag}_pmc_report.txt"
+python3 - "$tag" <<'EOF'
+import json, re, sys
+tag = sys.argv[1]
+txt = open("profiles/%s_pmc_report.txt" % tag).read()
+out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `python3 bench.py --steps 4 --warmup 2` (tools/pmc.sh groups 10, 11), per dispatch averages",
+       "correction": "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): FETCH_SIZE is in KB and counts 128-byte requests as 64 on gfx950 (MI355X_MICROARCH.md 'HBM'); uncalibrated for narrow gathers",
+       "workload": "bunny 1920x1080, all-metal, shared-memory denoiser", "kernels": {}}
+for block in re.split(r"\n(?=\S)", txt):
+    name = block.split("\n")[0].strip()
+    vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([0-9.]+) per dispatch", block, re.M)}
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and name.startswith(("rt::", "void rt::")):
+        out["kernels"][name] = {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+                                "traffic_bytes": int(1024 * (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]))}
+json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
+print("trace kernel traffic:", out["kernels"].get("rt::traceKernel"))
+EOF
+echo "profiles/${tag}_* written"
