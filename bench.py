@@ -6,8 +6,10 @@
   N GPUs   : the SAME 1920x1080 frame sharded by row strips, one process per GPU (torchrun), history-apron
              exchange over RCCL + frame gather on rank 0 ("scaling": "strong")
   value    : non-degenerate rays traced by all ranks in the K timed frames / max-over-ranks wall time
-  roofline : the dominant kernel (rayGenKernel: fused raygen + BVH traversal + shading), algorithmic bytes per launch
-             (DESIGN.md "Roofline") / its average duration from HIP events recorded on the launching stream
+  roofline : the dominant kernel (rt::traceKernel: BVH traversal of the binned rays), algorithmic bytes per launch
+             (DESIGN.md "Roofline accounting") / its average duration from HIP events recorded on the launching stream
+             (stream B); `traffic` = HBM-side bytes per launch from the newest profiles/*_pmc_traffic.json;
+             `roofline.frame` = SURVEY 8(d)'s whole-frame bytes / frame time
   cpu_baseline : the scalar C++ oracle re-tracing the SAME BVH arrays on the host cores, bounded sample (rank 0, N=1 only)
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080 --mesh bunny.obj]
