@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mesh", default="bunny.obj")
+    ap.add_argument("--metallic", type=float, nargs=2, default=None, help="metallic of ground and model (default: the sample's 1 1 = no diffuse rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     args = ap.parse_args()
@@ -60,7 +61,8 @@ def main():
 
     W, H = args.width, args.height
     r = StripRenderer(W, H, assets.path(args.mesh), assets.path("rnl_cross.dds"), rank=rank, world=world, device=local_rank,
-                      dist=dist if world > 1 else None, extra_args=("-sharedmem",))
+                      dist=dist if world > 1 else None,
+                      extra_args=("-sharedmem",) + (("-metallic", args.metallic[0], args.metallic[1]) if args.metallic else ()))
     ctx = r.context
 
     def barrier():
@@ -98,7 +100,7 @@ def main():
         rows = r.strip_rows_with_apron()
         rays_per_launch = own_rays / max(args.steps, 1)     # rays of this rank's strip (apron rays of a strip are not counted)
         alg_bytes = r.trace_kernel_algorithmic_bytes(rays_per_launch)
-        frame_bytes = r.frame_algorithmic_bytes(rows)
+        frame_bytes = r.frame_algorithmic_bytes(rows, metallic_lt_1=bool(args.metallic) and min(args.metallic) < 1.0)
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         # HBM bytes per launch from hardware counters: collected in separate rocprofv3 --pmc runs of this same workload
         # (tools/pmc.sh), committed under profiles/; null for other workloads
@@ -116,7 +118,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: %s + rnl_cross env, %dx%d, 1spp GGX reflection + full denoise chain (refl H,V; diff H,V, shared-memory variant; temporal; tone map), "
-                                   "all-metal default materials, dt=1/60" % (args.mesh, W, H),
+                                   "%s, dt=1/60" % (args.mesh, W, H, "metallic %g %g" % tuple(args.metallic) if args.metallic else "all-metal default materials"),
                        "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
@@ -145,6 +147,8 @@ def cpu_baseline(r, args, W, H):
     v, i, _ = O.obj_import(assets.path(args.mesh))
     o.set_mesh(1, v, i)
     o.set_env_dds(assets.path("rnl_cross.dds"))
+    if args.metallic:
+        o.set_metallic(0, args.metallic[0]); o.set_metallic(1, args.metallic[1])
     for slot, (bn, bt) in enumerate(((capi.BUF_BVH_NODES0, capi.BUF_BVH_TRIS0), (capi.BUF_BVH_NODES1, capi.BUF_BVH_TRIS1))):
         o.set_bvh(slot, r.context.readback(bn), r.context.readback(bt), r.context.bvh_root(slot))
     o.transform_sh()
