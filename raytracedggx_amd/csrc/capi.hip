@@ -163,7 +163,8 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   c->largeCapacity = 1u << 16;
   RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 4));
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
-  RT_HIP(hipMalloc(&c->rayCounter32, 1024 * 4)); RT_HIP(hipMemset(c->rayCounter32, 0, 1024 * 4));   // [0..255] rays; [256..] RT_TRACE_STATS
+  RT_HIP(hipMalloc(&c->rayCounter32, 1024 * 4)); RT_HIP(hipMemset(c->rayCounter32, 0, 1024 * 4));
+  RT_HIP(hipHostMalloc(&c->hostRayCounters, 256 * 4)); RT_HIP(hipEventCreateWithFlags(&c->evRayCounters, hipEventDisableTiming));   // [0..255] rays; [256..] RT_TRACE_STATS
   {
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, device));
@@ -215,7 +216,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < 2; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
   hipFree(c->stackOverflow); hipFree(c->dummyRecord);
-  hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32);
+  hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);

@@ -112,6 +112,9 @@ struct rtggx_context {
   uint32_t numCUs = 256;
 
   // counters
+  uint32_t* hostRayCounters = nullptr;  // pinned copy of rayCounter32[0..255], refreshed asynchronously after every trace launch
+  hipEvent_t evRayCounters = nullptr; bool rayCountersInFlight = false; uint32_t traceLaunches = 0;
+  uint32_t lastFrameRays = 0xFFFFFFFFu; // rays of the most recent frame whose counters have arrived (unknown: assume a full machine)
   uint32_t* rayCounter32 = nullptr;     // 256 per-frame partial counts written by the trace kernel
   unsigned long long* rayCounter = nullptr;   // [0..255] last frame, [256..511] running total
 
