@@ -42,7 +42,7 @@ struct TraceArgs {
   unsigned long long* runTotals;   // 256 running totals (rtggx_ray_total)
   uint32_t countRowBegin, countRowEnd, width;
   size_t spillStride;
-  uint32_t sliceShift;       // 0, 1, 2: a wave starts with 64, 32, 16 rays of its bin (1, 2, 4 waves per bin; the other lanes start as helpers)
+  uint32_t sliceShift;       // 0..3: a wave starts with 64, 32, 16, 8 rays of its bin (1, 2, 4, 8 waves per bin; the other lanes start as helpers)
   uint32_t tilesX, tilesY;   // tile grid of the frame (4 bins per 16x16 tile); tilesX == 0: bins are a plain list (rtggx_trace_rays)
 };
 
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   // XCD whole super-tiles of 8x8 tiles (128x128 pixels), dealt round-robin over the screen, keeps the part of the tree
   // an L2 needs at any one time small without tying an XCD to one (cheap or expensive) region of the screen.
   // On a small frame or a thin strip the bins are too few to fill the chip, and the kernel lasts as long as its most
-  // expensive bin (~70 dependent steps): such launches split every bin over 2 or 4 waves (sliceShift), whose spare
+  // expensive bin (~70 dependent steps): such launches split every bin over 2, 4 or 8 waves (sliceShift), whose spare
   // lanes start as helpers of the wave's own rays.
   const uint32_t slices = 1u << A.sliceShift, raysPerWave = 64u >> A.sliceShift;
   const uint32_t blk = blockIdx.x >> A.sliceShift, sub = blockIdx.x & (slices - 1u);
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   int32_t* const stack = stackBase + lane;
   uint32_t* const victims = victimMem + wave * 64;
   const size_t spillStride = A.spillStride;
-  int32_t* const spill = A.overflow + (size_t)bin * 256u + slice * 64u + lane;            // entry e at spill[e * spillStride] (256 lanes per bin: 4 waves)
+  int32_t* const spill = A.overflow + (size_t)bin * 512u + slice * 64u + lane;            // entry e at spill[e * spillStride] (512 lanes per bin: up to 8 waves)
   const unsigned long long laneLt = (1ull << lane) - 1ull;
   uint32_t nRays = 0;
 #ifdef RT_TRACE_STATS
@@ -300,16 +300,16 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
     RT_HIP(hipStreamSynchronize(s));
     if (c->stackOverflow) { RT_HIP(hipFree(c->stackOverflow)); c->stackOverflow = nullptr; }
     c->spillEntries = deepest - RT_STACK;
-    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)c->spillEntries * c->numBinsMax * 256 * 4));
+    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)c->spillEntries * c->numBinsMax * 512 * 4));
   }
   T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32; T.runTotals = c->rayCounter + 256;
-  T.spillStride = (size_t)c->numBinsMax * 256;
+  T.spillStride = (size_t)c->numBinsMax * 512;
   T.countRowBegin = countRays ? fp.rowBegin : 0u; T.countRowEnd = countRays ? fp.rowEnd : 0u; T.width = fp.W;
 #ifdef RT_TRACE_STATS
   hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounter32);
 #endif
   T.tilesX = tilesX; T.tilesY = tilesY;
-  // How many waves per bin: one when the rays fill the chip (~5000 wave slots x 64 lanes); two or four when they do not
+  // How many waves per bin: one when the rays fill the chip (~5000 wave slots x 64 lanes); 2, 4 or 8 when they do not
   // (small frames, thin strips of a multi-GPU frame).  The ray count is last frame's, copied back asynchronously.
   if (countRays && c->rayCountersInFlight && hipEventQuery(c->evRayCounters) == hipSuccess) {
     uint32_t sum = 0; for (int i = 0; i < 256; ++i) sum += c->hostRayCounters[i];
@@ -317,7 +317,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   }
   static const int forcedShift = getenv("RTGGX_SLICE_SHIFT") ? atoi(getenv("RTGGX_SLICE_SHIFT")) : -1;
   const uint32_t raysGuess = countRays ? c->lastFrameRays : numBins * 40u;
-  T.sliceShift = forcedShift >= 0 ? (uint32_t)forcedShift : (raysGuess < 60000u ? 2u : raysGuess < 110000u ? 1u : 0u);
+  T.sliceShift = forcedShift >= 0 ? (uint32_t)forcedShift : (raysGuess < 25000u ? 3u : raysGuess < 60000u ? 2u : raysGuess < 110000u ? 1u : 0u);
   const uint32_t superTiles = ((tilesX + 7u) / 8u) * ((tilesY + 7u) / 8u);
   const uint32_t grid = (tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (numBins + 3u) / 4u) << T.sliceShift;
   hipLaunchKernelGGL(traceKernel, dim3(grid), dim3(256), 0, s, c->dParams + c->slot, T);
