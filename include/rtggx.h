@@ -161,10 +161,11 @@ int  rtggx_ray_total(rtggx_context* ctx, uint64_t* rays, int reset);
 int  rtggx_debug_counters(rtggx_context* ctx, uint32_t* out, uint32_t n, int reset);
 int  rtggx_get_timings(rtggx_context* ctx, RtggxTimings* out);
 /* mode 0 off, 1 every pass (rtggx_get_timings), 2 only the ray-trace kernel: one HIP event pair per frame,
- * recorded on the launching stream right around the kernel, kept for up to RTGGX_KERNEL_RING frames. */
+ * recorded on the launching stream right around the kernel, kept for up to RTGGX_KERNEL_RING frames; 3 like 2 for
+ * every 8th frame only (an event pair costs the launching stream ~6 us per frame). */
 #define RTGGX_KERNEL_RING 4096
 int  rtggx_enable_timing(rtggx_context* ctx, int mode);
-/* Durations (ms) of the ray-trace kernel launches recorded in mode 2 since the last call; synchronises. */
+/* Durations (ms) of the ray-trace kernel launches recorded in mode 2 or 3 since the last call; synchronises. */
 int  rtggx_kernel_times(rtggx_context* ctx, float* ms, uint32_t capacity, uint32_t* count);
 
 /* Size in bytes of a buffer / synchronous copy into caller memory / raw device pointer. */

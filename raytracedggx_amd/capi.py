@@ -182,7 +182,7 @@ class Context:
         return out
 
     def enable_timing(self, mode=1):
-        """0 off, 1 every pass (timings()), 2 ray-trace kernel ring (kernel_times())."""
+        """0 off, 1 every pass (timings()), 2 ray-trace kernel ring (kernel_times()), 3 the same for every 8th frame."""
         self._check(self.L.rtggx_enable_timing(self.h, int(mode)))
 
     def kernel_times(self):

@@ -403,7 +403,7 @@ int rtggx_ray_total(rtggx_context* c, uint64_t* rays, int reset) {
 int rtggx_enable_timing(rtggx_context* c, int mode) {
   RT_CHECK_CTX(c);
   c->timing = mode == 1; c->timingsPending = false;
-  c->kernelRing = mode == 2; c->kevCount = 0;
+  c->kernelRing = mode == 2 || mode == 3; c->kevCount = 0; c->ringStride = mode == 3 ? 8u : 1u; c->ringTick = 0;
   if (c->kernelRing && c->kevBegin.empty()) {
     c->kevBegin.resize(RTGGX_KERNEL_RING); c->kevEnd.resize(RTGGX_KERNEL_RING);
     for (uint32_t i = 0; i < RTGGX_KERNEL_RING; ++i) { RT_HIP(hipEventCreate(&c->kevBegin[i])); RT_HIP(hipEventCreate(&c->kevEnd[i])); }

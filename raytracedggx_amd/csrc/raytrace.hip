@@ -415,7 +415,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   G.tilesX = tilesX; G.numTiles = tilesX * tilesY; G.rowBegin = rb; G.rowEnd = re;
   hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, G);
   if (c->timing) hipEventRecord(c->tev[11], s);
-  const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size();
+  const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size() && (c->ringTick++ % c->ringStride) == 0u;
   if (ring) hipEventRecord(c->kevBegin[c->kevCount], s);
   { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true, tilesX, tilesY); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[12], s);

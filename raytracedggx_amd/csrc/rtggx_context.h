@@ -130,7 +130,8 @@ struct rtggx_context {
 
   // timing
   bool timing = false;        // all per-pass events (rtggx_get_timings)
-  bool kernelRing = false;    // only the ray-trace kernel, one event pair per frame in a ring (rtggx_kernel_times)
+  bool kernelRing = false;    // only the ray-trace kernel, one event pair per sampled frame in a ring (rtggx_kernel_times)
+  uint32_t ringStride = 1, ringTick = 0;   // every ringStride-th frame is sampled
   std::vector<hipEvent_t> kevBegin, kevEnd;
   uint32_t kevCount = 0;
   hipEvent_t tev[16];
