@@ -300,10 +300,15 @@ int rtggx_update_as(rtggx_context* c) {
   }
   memcpy(fp.invWorld, c->invWorld, sizeof fp.invWorld);
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
-  if (c->timing) hipEventRecord(c->tev[0], c->streamAS);
-  const int r = uploadParamsStreamB(c);
-  if (r) return r;
-  if (c->timing) hipEventRecord(c->tev[1], c->streamAS);
+  // The constants (with the refreshed TLAS) ride to the device with the first kernel of the visibility pass, which
+  // follows on stream B (rtggx_render_visibility); a caller that traces without a visibility pass gets them through
+  // ensureParams.  In timing mode they are uploaded here, so that the pass has a duration of its own.
+  if (c->timing) {
+    hipEventRecord(c->tev[0], c->streamAS);
+    const int r = uploadParamsStreamB(c);
+    if (r) return r;
+    hipEventRecord(c->tev[1], c->streamAS);
+  }
   return 0;
 }
 
@@ -315,7 +320,6 @@ int rtggx_transform_sh(rtggx_context* c) {
 int rtggx_render_visibility(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
-  { const int r = ensureParams(c); if (r) return r; }
   if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamAS); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
   // Stream B renders into the other input set, so the pass overlaps whatever the main stream still has queued from
   // the previous frame (the sample overlaps its two queues in the same spirit, RayTracedGGX.cpp:302-353).

@@ -66,8 +66,16 @@ RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
   return (dy == 0 && dx > 0) || dy < 0;
 }
 
-__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount) {
+// First kernel of the pass: clears the target, empties the large-triangle list and -- when the frame's constants have
+// not been uploaded yet -- copies them (912 bytes, passed by value) into their device slot for the kernels that follow.
+__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount,
+                              FrameParams src, FrameParams* __restrict__ dst) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *largeCount = 0;      // the large-triangle list of rasterSmall starts empty
+  if (blockIdx.x == 0 && dst) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4; i += blockDim.x) d[i] = s[i];
+  }
   const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < end) vd[i] = 0x00FFFFFF00000000ull;
 }
@@ -241,7 +249,9 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   passRows(fp, ROWS_GBUFFER, rb, re);
   const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
-  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount);
+  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount,
+                     fp, c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot);
+  c->slotUploaded = true;
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
   if (nt) {
     hipLaunchKernelGGL(rasterSmall, dim3((nt + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->mesh[0].verts, c->mesh[0].indices, c->mesh[0].numTris,
