@@ -159,6 +159,12 @@ int  rtggx_ray_total(rtggx_context* ctx, uint64_t* rays, int reset);
 /* Diagnostic counters (non-zero only in builds with -DRT_TRACE_STATS): [0] lane node steps, [1] lane leaf steps,
  * [2] wave iterations, [3] refills of the trace kernel since the last reset. */
 int  rtggx_debug_counters(rtggx_context* ctx, uint32_t* out, uint32_t n, int reset);
+/* Tuning / test hook of the trace kernel's adaptive split (bins that were expensive in the previous frame are traced by
+ * 2, 4 or 8 waves): work_per_wave = lane-steps of traversal per wave above which a bin is split further (0: never),
+ * max_shift = log2 of the most waves per bin (0..3), capacity = room in the split list, in waves (-1: sized from the
+ * demand of earlier frames, the default).  *last_demand (may be NULL) receives the number of list entries the most recent
+ * frame asked for; synchronises.  Results do not depend on any of this: hits merge with a 64-bit atomic min. */
+int  rtggx_debug_trace_split(rtggx_context* ctx, uint32_t work_per_wave, uint32_t max_shift, int capacity, uint32_t* last_demand);
 int  rtggx_get_timings(rtggx_context* ctx, RtggxTimings* out);
 /* mode 0 off, 1 every pass (rtggx_get_timings), 2 only the ray-trace kernel: one HIP event pair per frame,
  * recorded on the launching stream right around the kernel, kept for up to RTGGX_KERNEL_RING frames; 3 like 2 for

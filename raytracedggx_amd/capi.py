@@ -28,7 +28,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
-           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters"]
+           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split"]
 
 
 class Timings(C.Structure):
@@ -174,6 +174,13 @@ class Context:
         n = C.c_uint64()
         self._check(self.L.rtggx_ray_total(self.h, C.byref(n), 1 if reset else 0))
         return int(n.value)
+
+    def debug_trace_split(self, work_per_wave, max_shift, capacity=-1):
+        """Sets the adaptive-split parameters of the trace kernel; returns the split-list entries the last frame asked for."""
+        d = C.c_uint32()
+        self.L.rtggx_debug_trace_split.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        self._check(self.L.rtggx_debug_trace_split(self.h, work_per_wave, max_shift, capacity, C.byref(d)))
+        return int(d.value)
 
     def debug_counters(self, n=8, reset=True):
         out = np.zeros(n, np.uint32)

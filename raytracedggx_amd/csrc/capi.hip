@@ -7,6 +7,7 @@
 #include <cmath>
 #include <vector>
 #include "rtggx_context.h"
+#include "rt_queue.h"
 
 namespace rt {
 static thread_local char g_err[512] = "";
@@ -161,10 +162,10 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
   RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
   c->largeCapacity = 1u << 16;
-  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 4));
+  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 8));
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
   RT_HIP(hipMalloc(&c->rayCounter32, 1024 * 4)); RT_HIP(hipMemset(c->rayCounter32, 0, 1024 * 4));
-  RT_HIP(hipHostMalloc(&c->hostRayCounters, 256 * 4)); RT_HIP(hipEventCreateWithFlags(&c->evRayCounters, hipEventDisableTiming));   // [0..255] rays; [256..] RT_TRACE_STATS
+  RT_HIP(hipHostMalloc(&c->hostRayCounters, 257 * 4)); c->hostRayCounters[256] = 0; RT_HIP(hipEventCreateWithFlags(&c->evRayCounters, hipEventDisableTiming));   // [0..255] rays; [256..] RT_TRACE_STATS
   {
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, device));
@@ -179,6 +180,11 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
       RT_HIP(hipMalloc(&c->binCountBuf[i], (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCountBuf[i], 0, (size_t)c->numBinsMax * 4));
     }
     c->selectSet(0);
+    RT_HIP(hipMalloc(&c->binWork, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binWork, 0, (size_t)c->numBinsMax * 4));
+    RT_HIP(hipMalloc(&c->splitList, (size_t)RT_SPLIT_CAP * 4));
+    c->splitWork = getenv("RTGGX_SPLIT_WORK") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_WORK")) : RT_SPLIT_WORK;
+    c->splitMaxShift = getenv("RTGGX_SPLIT_MAX_SHIFT") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_MAX_SHIFT")) : RT_SPLIT_MAX_SHIFT;
+    if (c->splitMaxShift > 3u) c->splitMaxShift = 3u;
     RT_HIP(hipMalloc(&c->dEnvMipOffset, 16 * 4)); RT_HIP(hipMemset(c->dEnvMipOffset, 0, 16 * 4));
     RT_HIP(hipMalloc(&c->dummyRecord, 128)); RT_HIP(hipMemset(c->dummyRecord, 0, 128));
   }
@@ -215,6 +221,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < 2; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
+  hipFree(c->binWork); hipFree(c->splitList);
   hipFree(c->stackOverflow); hipFree(c->dummyRecord);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
@@ -388,6 +395,17 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
   RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
   RT_HIP(hipMemcpy(out, c->rayCounter32 + 256, (size_t)n * 4, hipMemcpyDeviceToHost));
   if (reset) RT_HIP(hipMemset(c->rayCounter32 + 256, 0, 768 * 4));
+  return 0;
+}
+
+int rtggx_debug_trace_split(rtggx_context* c, uint32_t workPerWave, uint32_t maxShift, int capacity, uint32_t* lastDemand) {
+  RT_CHECK_CTX(c);
+  if (maxShift > 3u) { setError("rtggx_debug_trace_split: max_shift %u > 3", maxShift); return -1; }
+  if (capacity > (int)RT_SPLIT_CAP) { setError("rtggx_debug_trace_split: capacity %d > %u", capacity, RT_SPLIT_CAP); return -1; }
+  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  if (lastDemand) RT_HIP(hipMemcpy(lastDemand, c->largeCount + 1, 4, hipMemcpyDeviceToHost));
+  c->splitWork = workPerWave; c->splitMaxShift = maxShift;
+  c->splitCapForced = capacity < 0 ? 0xFFFFFFFFu : ((uint32_t)capacity / 32u) * 32u;
   return 0;
 }
 

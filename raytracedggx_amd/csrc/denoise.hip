@@ -221,11 +221,15 @@ RT_DEV f3 yCoCgToRGB(f3 c) {   // :90-101
   const float y = c.x * 0.25f, co = c.y * 0.25f, cg = c.z * 0.25f;
   return mk3(y + co - cg, y + cg, y - co - cg);
 }
-// The temporal pass keeps IEEE division and square root: its neighbourhood variance m2/9 - mu^2 is pure rounding noise
-// in flat regions, sqrt turns that noise into the clamp window (times gamma <= 32), and only identical arithmetic on
-// both sides keeps the window -- and with it the clamped history -- comparable with the oracle's.  The smooth terms
-// around it (reprojection uv, blend factors, the inverse tone map) do use v_rcp_f32.
-RT_DEV f3 tssTM(f3 hdr) { const f3 c = rgbToYCoCg(hdr); const float d = 4.0f + c.x; return mk3(c.x / d, c.y / d, c.z / d); }   // :106-114
+// The temporal pass keeps correctly rounded division and square root: its neighbourhood variance m2/9 - mu^2 is pure
+// rounding noise in flat regions, sqrt turns that noise into the clamp window (times gamma <= 32), and only identical
+// arithmetic on both sides keeps the window -- and with it the clamped history -- comparable with the oracle's.  They are
+// the short exact sequences of rtggx_device.h (divBy9, div3Shared, sqrtRN), not the compiler's full-range expansions.
+// The smooth terms around it (reprojection uv, blend factors, the inverse tone map) do use v_rcp_f32.
+RT_DEV f3 tssTM(f3 hdr) {   // :106-114; three IEEE quotients that share the refinement of 1/d (rtggx_device.h)
+  const f3 c = rgbToYCoCg(hdr); const float d = 4.0f + c.x;
+  f3 q; div3Shared(c.x, c.y, c.z, d, q.x, q.y, q.z); return q;
+}
 RT_DEV f3 tssITM(f3 col) { const float k = 4.0f * rcpFast(1.0f - col.x); return yCoCgToRGB(mk3(col.x * k, col.y * k, col.z * k)); }   // :119-128 (smooth: v_rcp)
 RT_DEV f3 tssTMSmooth(f3 hdr) { const f3 c = rgbToYCoCg(hdr); const float r = rcpFast(4.0f + c.x); return mk3(c.x * r, c.y * r, c.z * r); }   // for the reprojected history, which does not enter the variance
 RT_DEV f2 loadVel(const uint32_t* __restrict__ vel, int x, int y, int W, int H) {
@@ -244,13 +248,22 @@ RT_DEV f4 loadRGBA16(const uint2* __restrict__ b, int x, int y, int W, int H) {
 // pixels and a one-texel apron: each texel is unpacked and tone-mapped (three divisions) once instead of nine times.
 __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   __shared__ float4 tile[6][66];
+  __shared__ uint32_t velRaw[6][66];      // the velocity texels of the same window (zero outside the frame) ...
+  __shared__ float velSq[6][66];          // ... and their squared lengths: VelocityMax compares five of them per pixel
   const int W = T.W, H = T.H;
   {
     const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * 4 - 1;
     for (int t = threadIdx.x; t < 6 * 66; t += 256) {
-      const f4 raw = loadRGBA16(T.fltDff, ox + t % 66, oy + t / 66, W, H);
+      const int tx = ox + t % 66, ty = oy + t / 66;
+      const bool inside = tx >= 0 && ty >= 0 && tx < W && ty < H;
+      const size_t ti = inside ? (size_t)ty * W + tx : 0;
+      const f4 raw = inside ? unpackRGBA16F(T.fltDff[ti]) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+      const uint32_t vr = inside ? T.velocity[ti] : 0u;
       const f3 tm = tssTM(mk3(raw.x, raw.y, raw.z));
       tile[t / 66][t % 66] = make_float4(tm.x, tm.y, tm.z, raw.w);
+      const float vx = f16ToF32(vr & 0xFFFFu), vy = f16ToF32(vr >> 16);
+      velRaw[t / 66][t % 66] = vr;
+      velSq[t / 66][t % 66] = vx * vx + vy * vy;
     }
   }
   __syncthreads();
@@ -264,13 +277,17 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   const f3 currentTM = mk3(cur.x, cur.y, cur.z);
   f4 current; current.x = current.y = current.z = 0.0f; current.w = cur.w;     // only the alpha of the raw value is used below
   // VelocityMax :133-161
-  f2 vmax = loadVel(T.velocity, x, y, W, H);
-  float speedSq = vmax.x * vmax.x + vmax.y * vmax.y;
   const int ox[8] = {-1, 1, 0, 0, -1, 1, 1, -1}, oy[8] = {0, 0, -1, 1, -1, -1, 1, 1};   // g_texOffsets :48-52
-  for (int i = 4; i < 8; ++i) {
-    const f2 nb = loadVel(T.velocity, x + ox[i], y + oy[i], W, H);
-    const float sq = nb.x * nb.x + nb.y * nb.y;
-    if (sq > speedSq) { vmax = nb; speedSq = sq; }
+  f2 vmax;
+  {
+    float speedSq = velSq[ly][lx];
+    uint32_t raw = velRaw[ly][lx];
+    for (int i = 4; i < 8; ++i) {
+      const float sq = velSq[ly + oy[i]][lx + ox[i]];
+      const uint32_t r = velRaw[ly + oy[i]][lx + ox[i]];
+      if (sq > speedSq) { raw = r; speedSq = sq; }
+    }
+    vmax.x = f16ToF32(raw & 0xFFFFu); vmax.y = f16ToF32(raw >> 16);
   }
   // history: bilinear, clamped addressing :259-260
   f4 history;
@@ -307,15 +324,15 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
       const float4 t = tile[ly + oy[i]][lx + ox[i]];
       const float nb[4] = {t.x, t.y, t.z, t.w};
       const float wgt = i < 4 ? 0.5f : 0.25f;
-      for (int k = 0; k < 4; ++k) fl[k] += nb[k] * wgt;
+      for (int k = 0; k < 4; ++k) fl[k] = __builtin_fmaf(nb[k], wgt, fl[k]);     // wgt is a power of two: the product is exact, fused or not
       for (int k = 0; k < 3; ++k) { mu[k] += nb[k]; m2[k] += nb[k] * nb[k]; }
     }
     for (int k = 0; k < 4; ++k) fl[k] /= 4.0f;
     gamma = fabsf(alpha - fl[3]) < 1.0f / 255.0f ? gamma : 1.0f;
     float sigma[3];
     for (int k = 0; k < 3; ++k) {
-      mu[k] /= 9.0f;
-      sigma[k] = sqrtf(fabsf(m2[k] / 9.0f - mu[k] * mu[k]));
+      mu[k] = divBy9(mu[k]);
+      sigma[k] = sqrtRN(fabsf(divBy9(m2[k]) - mu[k] * mu[k]));
       const float gs = gamma * sigma[k];
       nmin[k] = fminf(mu[k] - gs, fl[k]);
       nmax[k] = fmaxf(mu[k] + gs, fl[k]);

@@ -205,6 +205,8 @@ struct GenArgs {
   RayRec* rays; HitKey* hits; uint32_t* binCount;
   uint32_t* frameRays;      // 256 per-frame ray counters, zeroed here, added to by the trace kernel
   uint32_t tilesX, numTiles, rowBegin, rowEnd;
+  // adaptive split (trace.hip): null / 0 when off
+  uint32_t* binWork; uint32_t* splitList; uint32_t* splitCount; uint32_t splitWork, frontWork, splitMaxShift, splitCap;
 };
 
 __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restrict__ fpp, GenArgs A) {
@@ -320,7 +322,37 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
   HitKey* keys = A.hits + (size_t)bin * RT_BIN;      // every ray starts as a miss at TMax
   if (wantRefl) { const uint32_t k = (uint32_t)__popcll(maskR & below); dst[k] = rr; keys[k] = hitKey(rr.tmax, 0xFFFFFFFFu); }
   if (wantDiff) { const uint32_t k = nR + (uint32_t)__popcll(maskD & below); dst[k] = rd; keys[k] = hitKey(rd.tmax, 0xFFFFFFFFu); }
-  if (lane == 0) A.binCount[bin] = nR + (uint32_t)__popcll(maskD);
+  const uint32_t nRaysInBin = nR + (uint32_t)__popcll(maskD);
+  if (A.binWork == nullptr) {
+    if (lane == 0) A.binCount[bin] = nRaysInBin;
+    return;
+  }
+  // Adaptive split (trace.hip).  What this bin's rays cost in the previous frame decides whether it goes on the split
+  // list -- whose bins the trace kernel starts first -- and how many waves trace it: one per `splitWork` lane-steps, up
+  // to 2^splitMaxShift.  One atomic per workgroup allocates the entries of its four bins; the count keeps running past
+  // the list's capacity (the host sizes the next launches from it).
+  __shared__ uint32_t want[4], listBase;
+  uint32_t shift = 0u, n = 0u;
+  if (lane == 0) {
+    const uint32_t w = A.binWork[bin];
+    A.binWork[bin] = 0u;
+    while (shift < A.splitMaxShift && (w >> shift) > A.splitWork) ++shift;
+    n = (shift || w > A.frontWork) ? 1u << shift : 0u;
+    want[wave] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { const uint32_t total = want[0] + want[1] + want[2] + want[3]; listBase = total ? atomicAdd(A.splitCount, total) : 0u; }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t base = listBase, mark = 0u;
+    for (uint32_t k = 0; k < wave; ++k) base += want[k];
+    if (n) {
+      const bool fits = base + n <= A.splitCap;
+      for (uint32_t k = 0; k < n && base + k < A.splitCap; ++k) A.splitList[base + k] = fits ? ((shift << 28) | (k << 24) | bin) : 0xFFFFFFFFu;
+      mark = fits ? (shift << 1) | 1u : 0u;
+    }
+    A.binCount[bin] = nRaysInBin | (mark << 8);     // rays in the bin | bit 8: on the split list | bits 9..: log2(its waves)
+  }
 }
 
 // =========================================================================================================
@@ -353,7 +385,7 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict
   const EnvRef env{A.env, A.envSize, A.envMips, A.envMipOffset};
   // workgroup b shades the four bins its rayGen namesake filled: wave w <-> bin 4b + w
   const uint32_t bin = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const uint32_t count = min(A.binCount[bin], RT_BIN);
+  const uint32_t count = min(A.binCount[bin] & 0xFFu, RT_BIN);
   for (uint32_t i = threadIdx.x & 63u; i < count; i += 64u) {
     const size_t slot = (size_t)bin * RT_BIN + i;
     const float4* rp = reinterpret_cast<const float4*>(A.rays + slot);
@@ -413,11 +445,21 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
   G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;
   G.tilesX = tilesX; G.numTiles = tilesX * tilesY; G.rowBegin = rb; G.rowEnd = re;
+  const uint32_t splitWork = c->splitWork, splitMaxShift = c->splitMaxShift;
+  const uint32_t sliceShift = chooseSliceShift(c, true, G.numTiles * 4u);
+  const bool adaptive = splitWork != 0u && sliceShift == 0u;
+  // the split list is sized from the demand of an earlier frame (copied back asynchronously, like the ray counters)
+  const uint32_t splitCap = !adaptive ? 0u : c->splitCapForced != 0xFFFFFFFFu ? c->splitCapForced
+                          : c->splitDemand == 0u ? 0u : ((c->splitDemand + c->splitDemand / 8u + 64u + 31u) / 32u) * 32u;
+  G.binWork = adaptive ? c->binWork : nullptr; G.splitList = c->splitList; G.splitCount = c->largeCount + 1;
+  static const uint32_t frontWork = getenv("RTGGX_SPLIT_FRONT") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_FRONT")) : RT_SPLIT_FRONT;
+  G.frontWork = frontWork < splitWork ? frontWork : splitWork;
+  G.splitWork = splitWork; G.splitMaxShift = splitMaxShift < 3u ? splitMaxShift : 3u; G.splitCap = splitCap < RT_SPLIT_CAP ? splitCap : RT_SPLIT_CAP;
   hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, G);
   if (c->timing) hipEventRecord(c->tev[11], s);
   const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size() && (c->ringTick++ % c->ringStride) == 0u;
   if (ring) hipEventRecord(c->kevBegin[c->kevCount], s);
-  { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true, tilesX, tilesY); if (r) return r; }
+  { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true, tilesX, tilesY, sliceShift, adaptive ? (int)G.splitCap : -1); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[12], s);
   if (ring) hipEventRecord(c->kevEnd[c->kevCount++], s);
   RT_HIP(hipGetLastError());
@@ -478,7 +520,7 @@ int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays,
   const uint32_t numBins = (((n + RT_BIN - 1u) / RT_BIN) + 3u) & ~3u;   // whole tiles of four bins
   RT_HIP(hipMemsetAsync(c->binCount, 0, (size_t)numBins * 4, s));
   hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, (HitKey*)c->hitQueue, c->binCount);
-  { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u); if (r) return r; }
+  { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u, chooseSliceShift(c, false, numBins), -1); if (r) return r; }
   hipLaunchKernelGGL(exportTestHits, dim3((n + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, (const RayRec*)c->rayQueue, (const HitKey*)c->hitQueue, n,
                      c->mesh[0].verts, c->mesh[0].indices, c->mesh[1].verts, c->mesh[1].indices, dOut);
   RT_HIP(hipGetLastError());

@@ -13,6 +13,19 @@ namespace rt {
 
 #define RT_BIN 128u          // ray slots per bin = 2 rays x 64 pixels (64-byte ray record + 8-byte hit key per slot)
 
+// Adaptive split of the trace launch (trace.hip): what a bin cost in the previous frame, in lane-steps, decides where and
+// how it is traced in this one.  Tuned on the 1080p bunny frame (mean bin: ~700 lane-steps, 14 steps of a wave):
+#define RT_SPLIT_CAP 16384u  // entries of the split list
+#ifndef RT_SPLIT_FRONT
+#define RT_SPLIT_FRONT 1000u // above this a bin goes on the list: the launch starts with the listed bins
+#endif
+#ifndef RT_SPLIT_WORK
+#define RT_SPLIT_WORK 2400u  // above this (per wave) a listed bin gets twice the waves ...
+#endif
+#ifndef RT_SPLIT_MAX_SHIFT
+#define RT_SPLIT_MAX_SHIFT 1u   // ... up to 2^this
+#endif
+
 // 64-byte ray record
 struct __attribute__((aligned(16))) RayRec {
   float ox, oy, oz, tmin;
@@ -31,6 +44,10 @@ RT_HD uint32_t hitKeyId(HitKey k) { return (uint32_t)k; }
 
 // Traversal of the rays in bins [0, numBins) (trace.hip).  countRays: add the rays of rows [fp.rowBegin, fp.rowEnd)
 // to the per-frame counters.  tilesX x tilesY: the tile grid the bins come from (4 bins per tile), 0 for a plain list.
-int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY);
+// sliceShift: waves per bin for the whole launch (chooseSliceShift).  splitCap >= 0 (with sliceShift 0): adaptive split --
+// the bins rayGenKernel marked (bits 8.. of binCount, c->splitList with room for splitCap waves) are traced by several
+// waves, and the kernel records what each bin cost (c->binWork) for the next frame's decision; -1: off.
+uint32_t chooseSliceShift(rtggx_context* c, bool countRays, uint32_t numBins);
+int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY, uint32_t sliceShift, int splitCap);
 
 }  // namespace rt

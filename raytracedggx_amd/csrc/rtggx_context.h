@@ -97,7 +97,13 @@ struct rtggx_context {
 
   // visibility scratch
   void* largeTris = nullptr;     // LargeTri records
-  uint32_t* largeCount = nullptr;
+  uint32_t* largeCount = nullptr;       // [0] entries of largeTris, [1] entries of splitList (both zeroed by clearVisDepth)
+  // Bins whose traversal was expensive in the previous frame are traced by 2, 4 or 8 waves (trace.hip "adaptive split"):
+  uint32_t* binWork = nullptr;          // [numBinsMax] lane-steps the trace kernel spent on the bin (read and zeroed by rayGenKernel)
+  uint32_t* splitList = nullptr;        // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a split bin
+  uint32_t splitDemand = 0;             // entries the most recent frame whose count has arrived wanted (hostRayCounters[256])
+  uint32_t splitCapForced = 0xFFFFFFFFu;   // rtggx_debug_trace_split: fixed capacity instead of the demand-driven one
+  uint32_t splitWork = 0, splitMaxShift = 0;   // set at creation (RT_SPLIT_WORK, or RTGGX_SPLIT_WORK / RTGGX_SPLIT_MAX_SHIFT)
   uint32_t largeCapacity = 0;
 
   // ray bins of the trace pass (rt_queue.h): numBinsMax bins of 128 64-byte ray records + 16-byte hit records

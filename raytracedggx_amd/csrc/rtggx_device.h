@@ -36,6 +36,36 @@ RT_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
 RT_HD f3 lerp3(f3 a, f3 b, float t) { return a + t * (b - a); }
 RT_HD f3 reflect3(f3 i, f3 n) { const float k = 2.0f * dot3(i, n); return i - k * n; }
 RT_DEV float smoothstepf(float a, float b, float x) { const float t = saturatef((x - a) / (b - a)); return t * t * (3.0f - 2.0f * t); }
+
+// ---- correctly rounded division / square root in fewer instructions -------------------------------
+// `a / b` and sqrtf() expand to 10-16 instructions because they also cover operands near the ends of the exponent range
+// (v_div_scale / v_div_fixup, the 2^32 pre-scaling of sqrt).  Where the operands cannot be there (|x| in [1e-30, 1e30] or
+// zero) the core of the same sequences returns the same round-to-nearest result; tools/microbench/exactmath.hip checks
+// that exhaustively (x/9, sqrt) and on 4e9 random triples (div3Shared) against the compiler's expansion on the GPU.
+RT_DEV float divBy9(float x) {              // q = RN(x * RN(1/9)), one residual correction (Markstein); -0 comes back as +0
+  const float r9 = 0.111111112f;            // RN(1/9) = 0x3DE38E39
+  const float q = x * r9;
+  return __builtin_fmaf(__builtin_fmaf(-9.0f, q, x), r9, q);
+}
+RT_DEV void div3Shared(float n0, float n1, float n2, float d, float& q0, float& q1, float& q2) {   // n0/d, n1/d, n2/d
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float y = __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);       // 1/d refined once, shared
+  auto quotient = [&](float n) {
+    const float a = n * y;
+    const float b = __builtin_fmaf(__builtin_fmaf(-d, a, n), y, a);
+    return __builtin_fmaf(__builtin_fmaf(-d, b, n), y, b);
+  };
+  q0 = quotient(n0); q1 = quotient(n1); q2 = quotient(n2);
+}
+RT_DEV float sqrtRN(float x) {              // v_sqrt_f32 (1 ulp), then pick among s-1ulp, s, s+1ulp by the sign of the residuals
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
+  float r = rdn <= 0.0f ? dn : s;
+  r = rup > 0.0f ? up : r;
+  return r;
+}
+
 RT_DEV uint32_t ftou(float x) { if (!(x > 0.0f)) return 0u; if (x >= 4294967296.0f) return 0xFFFFFFFFu; return (uint32_t)x; }
 
 // Row-vector matrix, row-major: v' = v * M.

@@ -44,6 +44,9 @@ struct TraceArgs {
   size_t spillStride;
   uint32_t sliceShift;       // 0..3: a wave starts with 64, 32, 16, 8 rays of its bin (1, 2, 4, 8 waves per bin; the other lanes start as helpers)
   uint32_t tilesX, tilesY;   // tile grid of the frame (4 bins per 16x16 tile); tilesX == 0: bins are a plain list (rtggx_trace_rays)
+  // adaptive split: the first splitBlocks workgroups take their (bin, slice) from the split list; a bin marked as split
+  // (binCount bits 8..) is left to them.  binWork: lane-steps spent per bin, for the next frame's decision; null when off.
+  const uint32_t* splitList; const uint32_t* splitCount; uint32_t* binWork; uint32_t splitBlocks;
 };
 
 // Wave w of the grid traces the rays of bin w, 64 at a time (a second round only where a sub-tile has more than 64
@@ -78,20 +81,38 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   // On a small frame or a thin strip the bins are too few to fill the chip, and the kernel lasts as long as its most
   // expensive bin (~70 dependent steps): such launches split every bin over 2, 4 or 8 waves (sliceShift), whose spare
   // lanes start as helpers of the wave's own rays.
-  const uint32_t slices = 1u << A.sliceShift, raysPerWave = 64u >> A.sliceShift;
-  const uint32_t blk = blockIdx.x >> A.sliceShift, sub = blockIdx.x & (slices - 1u);
-  uint32_t tile = blk;
-  if (A.tilesX != 0u) {
-    const uint32_t xcd = blk & 7u, local = blk >> 3;
-    const uint32_t super = (local >> 6) * 8u + xcd, inSuper = local & 63u;
-    const uint32_t superX = (A.tilesX + 7u) >> 3;
-    const uint32_t tx = (super % superX) * 8u + (inSuper & 7u), ty = (super / superX) * 8u + (inSuper >> 3);
-    if (tx >= A.tilesX || ty >= A.tilesY) return;
-    tile = ty * A.tilesX + tx;
+  //
+  // Adaptive split.  On a full-size frame the kernel still ends with a tail: a few percent of the bins (silhouettes,
+  // contact regions) cost 5x the mean, and a wave's steps are dependent.  What a bin cost is known from the previous
+  // frame (binWork, lane-steps; the camera moves little in 1/60 s): rayGenKernel gives such bins 2, 4 or 8 waves and
+  // lists them (splitList), and the first splitBlocks workgroups of the grid -- dispatched first -- trace them.
+  uint32_t shift = A.sliceShift, bin, slice;
+  if (blockIdx.x < A.splitBlocks) {
+    const uint32_t item = blockIdx.x * 4u + wave;
+    if (item >= min(*A.splitCount, A.splitBlocks * 4u)) return;
+    const uint32_t e = A.splitList[item];
+    if (e == 0xFFFFFFFFu) return;
+    bin = e & 0xFFFFFFu; slice = (e >> 24) & 15u; shift = e >> 28;
+    if (bin >= A.numBins) return;
+  } else {
+    const uint32_t slices = 1u << shift;
+    const uint32_t blk = (blockIdx.x - A.splitBlocks) >> shift, sub = (blockIdx.x - A.splitBlocks) & (slices - 1u);
+    uint32_t tile = blk;
+    if (A.tilesX != 0u) {
+      const uint32_t xcd = blk & 7u, local = blk >> 3;
+      const uint32_t super = (local >> 6) * 8u + xcd, inSuper = local & 63u;
+      const uint32_t superX = (A.tilesX + 7u) >> 3;
+      const uint32_t tx = (super % superX) * 8u + (inSuper & 7u), ty = (super / superX) * 8u + (inSuper >> 3);
+      if (tx >= A.tilesX || ty >= A.tilesY) return;
+      tile = ty * A.tilesX + tx;
+    }
+    bin = tile * 4u + ((sub * 4u + wave) >> shift); slice = (sub * 4u + wave) & (slices - 1u);
+    if (bin >= A.numBins) return;
   }
-  const uint32_t bin = tile * 4u + ((sub * 4u + wave) >> A.sliceShift), slice = (sub * 4u + wave) & (slices - 1u);
-  if (bin >= A.numBins) return;
-  const uint32_t count = min(A.binCount[bin], RT_BIN);
+  const uint32_t raysPerWave = 64u >> shift;
+  const uint32_t countWord = A.binCount[bin];
+  if (blockIdx.x >= A.splitBlocks && A.binWork != nullptr && (countWord >> 8) != 0u) return;      // traced by the waves of the split list
+  const uint32_t count = min(countWord & 0xFFu, RT_BIN);
   if (count <= slice * raysPerWave) return;
   int32_t* const stackBase = stackMem + wave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
   int32_t* const stack = stackBase + lane;
@@ -99,7 +120,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   const size_t spillStride = A.spillStride;
   int32_t* const spill = A.overflow + (size_t)bin * 512u + slice * 64u + lane;            // entry e at spill[e * spillStride] (512 lanes per bin: up to 8 waves)
   const unsigned long long laneLt = (1ull << lane) - 1ull;
-  uint32_t nRays = 0;
+  uint32_t nRays = 0, work = 0;
 #ifdef RT_TRACE_STATS
   uint32_t stNode = 0, stLeaf = 0, stIter = 0, stDeep = 0, stSteal = 0, stLeafPhase = 0;
   const unsigned long long stT0 = clock64(), stW0 = wall_clock64();
@@ -131,7 +152,10 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   uint32_t owner = slot;                             // the ray slot whose key this job's hits go to
 
   // ---- traversal -----------------------------------------------------------------------------------------------
-  while (__ballot(job)) {
+  for (;;) {
+    const unsigned long long jobMask = __ballot(job);
+    if (jobMask == 0ull) break;
+    work += (uint32_t)__popcll(jobMask);
     // -- idle lanes take over pending subtrees
     if ((uint32_t)__popcll(__ballot(!job)) >= RT_STEAL_MIN_IDLE) {
       for (int round = 0; round < RT_STEAL_ROUNDS; ++round) {
@@ -257,6 +281,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   // ray statistics: one fire-and-forget atomic per wave, spread over 256 words
   for (int o = 32; o > 0; o >>= 1) nRays += __shfl_down(nRays, o);
   if (lane == 0 && nRays) { atomicAdd(&A.rayTotals[bin & 255u], nRays); atomicAdd(&A.runTotals[bin & 255u], (unsigned long long)nRays); }
+  if (lane == 0 && A.binWork != nullptr) { if (blockIdx.x < A.splitBlocks) atomicAdd(&A.binWork[bin], work); else A.binWork[bin] = work; }
 #ifdef RT_TRACE_STATS
   for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); stSteal += __shfl_down(stSteal, o); stDeep = max(stDeep, (uint32_t)__shfl_down((int)stDeep, o)); }
   if (lane == 0) {   // lane node steps, lane leaf steps, wave iterations, waves, deepest stack, wave lifetime (sum, max), most iterations, steals
@@ -280,7 +305,20 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
 __global__ void stampKernel(uint32_t* totals) { *reinterpret_cast<unsigned long long*>(totals + 1020) = wall_clock64(); }
 #endif
 
-int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY) {
+// How many waves per bin for the whole launch: one when the rays fill the chip (~5000 wave slots x 64 lanes); 2, 4 or
+// 8 when they do not (small frames, thin strips of a multi-GPU frame).  The ray count is last frame's, copied back
+// asynchronously.
+uint32_t chooseSliceShift(rtggx_context* c, bool countRays, uint32_t numBins) {
+  if (countRays && c->rayCountersInFlight && hipEventQuery(c->evRayCounters) == hipSuccess) {
+    uint32_t sum = 0; for (int i = 0; i < 256; ++i) sum += c->hostRayCounters[i];
+    c->lastFrameRays = sum; c->splitDemand = c->hostRayCounters[256]; c->rayCountersInFlight = false;
+  }
+  static const int forcedShift = getenv("RTGGX_SLICE_SHIFT") ? atoi(getenv("RTGGX_SLICE_SHIFT")) : -1;
+  const uint32_t raysGuess = countRays ? c->lastFrameRays : numBins * 40u;
+  return forcedShift >= 0 ? (uint32_t)forcedShift : (raysGuess < 25000u ? 3u : raysGuess < 60000u ? 2u : raysGuess < 110000u ? 1u : 0u);
+}
+
+int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY, uint32_t sliceShift, int splitCap) {
   TraceArgs T;
   if (numBins == 0) return 0;
   if (numBins > c->numBinsMax) { setError("launchTrace: %u bins exceed the %u allocated", numBins, c->numBinsMax); return -1; }
@@ -309,23 +347,20 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounter32);
 #endif
   T.tilesX = tilesX; T.tilesY = tilesY;
-  // How many waves per bin: one when the rays fill the chip (~5000 wave slots x 64 lanes); 2, 4 or 8 when they do not
-  // (small frames, thin strips of a multi-GPU frame).  The ray count is last frame's, copied back asynchronously.
-  if (countRays && c->rayCountersInFlight && hipEventQuery(c->evRayCounters) == hipSuccess) {
-    uint32_t sum = 0; for (int i = 0; i < 256; ++i) sum += c->hostRayCounters[i];
-    c->lastFrameRays = sum; c->rayCountersInFlight = false;
-  }
-  static const int forcedShift = getenv("RTGGX_SLICE_SHIFT") ? atoi(getenv("RTGGX_SLICE_SHIFT")) : -1;
-  const uint32_t raysGuess = countRays ? c->lastFrameRays : numBins * 40u;
-  T.sliceShift = forcedShift >= 0 ? (uint32_t)forcedShift : (raysGuess < 25000u ? 3u : raysGuess < 60000u ? 2u : raysGuess < 110000u ? 1u : 0u);
+  T.sliceShift = sliceShift;
+  const bool adaptive = splitCap >= 0 && sliceShift == 0u && tilesX != 0u;
+  T.splitList = c->splitList; T.splitCount = c->largeCount + 1;
+  T.binWork = adaptive ? c->binWork : nullptr; T.splitBlocks = adaptive ? (uint32_t)splitCap / 4u : 0u;
   const uint32_t superTiles = ((tilesX + 7u) / 8u) * ((tilesY + 7u) / 8u);
-  const uint32_t grid = (tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (numBins + 3u) / 4u) << T.sliceShift;
+  const uint32_t grid = T.splitBlocks + ((tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (numBins + 3u) / 4u) << T.sliceShift);
   hipLaunchKernelGGL(traceKernel, dim3(grid), dim3(256), 0, s, c->dParams + c->slot, T);
-  if (countRays && !c->rayCountersInFlight && (c->traceLaunches++ & 15u) == 0u) {     // every 16th frame: its ray counters, for later launches
+  if (countRays && !c->rayCountersInFlight && (c->traceLaunches < 8u || (c->traceLaunches & 15u) == 0u)) {     // the first frames, then every 16th: ray counters and split demand, for later launches
     RT_HIP(hipMemcpyAsync(c->hostRayCounters, c->rayCounter32, 256 * 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->largeCount + 1, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipEventRecord(c->evRayCounters, s));
     c->rayCountersInFlight = true;
   }
+  if (countRays) ++c->traceLaunches;
   RT_HIP(hipGetLastError());
   return 0;
 }

@@ -70,7 +70,7 @@ RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
 // not been uploaded yet -- copies them (912 bytes, passed by value) into their device slot for the kernels that follow.
 __global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount,
                               FrameParams src, FrameParams* __restrict__ dst) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *largeCount = 0;      // the large-triangle list of rasterSmall starts empty
+  if (blockIdx.x == 0 && threadIdx.x < 2) largeCount[threadIdx.x] = 0;      // the large-triangle list of rasterSmall and the split list of rayGenKernel start empty
   if (blockIdx.x == 0 && dst) {
     const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
     uint32_t* d = reinterpret_cast<uint32_t*>(dst);

@@ -10,9 +10,14 @@ TemporalSSOut[parity] to its two neighbours and receives theirs -- point-to-poin
 (RCCL send/recv, one group launch per frame, 2 x 17 rows x W x 8 B), together with the gather of the
 tone-mapped strips onto rank 0.  The exchange is issued right after the tone map and is only needed by
 the next frame's temporal pass, so it overlaps that frame's visibility, ray trace and spatial passes.
+torch.distributed makes the rendezvous; the per-frame sends and receives go to RCCL directly (rccl.py: the
+P2POp batch of torch.distributed costs more host time per frame than a thin strip takes to render), unless
+RTGGX_EXCHANGE=torch asks for the torch.distributed batch.
 
 With world == 1 this is exactly RayTracedGGX::OnUpdate + OnRender and no communication.
 """
+import os
+
 import numpy as np
 
 from . import app, capi
@@ -96,6 +101,10 @@ class StripRenderer:
                 self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
         self._last = None
         self._ops = [None, None]
+        self._comm = None
+        if world > 1 and dist is not None and transport is None and os.environ.get("RTGGX_EXCHANGE", "rccl") != "torch":
+            from . import rccl
+            self._comm = rccl.Communicator(dist, rank, world)
 
     def _wrap(self, bid, typestr):
         t = self.torch.as_tensor(_DeviceArray(self.context.buffer_ptr(bid), (self.H, self.W), typestr), device="cuda")
@@ -117,10 +126,22 @@ class StripRenderer:
             self.transport(self, exchange_plan(self.H, self.rank, self.world))
             return
         parity = self.context.frame_parity()
+        if self._comm is not None:
+            if self._ops[parity] is None:      # (is_send, pointer, bytes, peer), built once per history target
+                self._ops[parity] = self.raw_ops(exchange_plan(self.H, self.rank, self.world), parity)
+            self._comm.exchange(self._ops[parity], self.stream.cuda_stream)
+            return
         if self._ops[parity] is None:          # built once per history target: the per-frame host cost is the batch call alone
             self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world), self.exchange_buffers())
         with self.torch.cuda.stream(self.stream):
             run_exchange(self.dist, None, None, ops=self._ops[parity])
+
+    def raw_ops(self, plan, parity):
+        """`plan` as (is_send, device pointer, bytes, peer): rows [r0, r1) of TemporalSSOut[parity] (8 B/px) or of the
+        back buffer (4 B/px); every rank holds full-size targets, so both sides address the same rows."""
+        base = {"history": (self.context.buffer_ptr(capi.BUF_TSS1 if parity else capi.BUF_TSS0), 8 * self.W),
+                "backbuffer": (self.context.buffer_ptr(capi.BUF_BACKBUFFER), 4 * self.W)}
+        return [(op == "send", base[name][0] + r0 * base[name][1], (r1 - r0) * base[name][1], peer) for op, name, r0, r1, peer in plan]
 
     def exchange_buffers(self):
         """The torch views of the two exchanged targets (this frame's temporal result, the back buffer)."""
@@ -165,4 +186,8 @@ class StripRenderer:
         return t
 
     def close(self):
+        if self._comm is not None:
+            self.context.sync()
+            self._comm.destroy()
+            self._comm = None
         self.app.OnDestroy()

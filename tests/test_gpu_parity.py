@@ -429,6 +429,79 @@ def test_strips_through_torch_views_on_torch_stream(built):
             s.close()
 
 
+def test_adaptive_split_of_expensive_bins_changes_nothing(built):
+    """Bins that were expensive in the previous frame are traced by 2, 4 or 8 waves in the next (trace.hip "adaptive
+    split"; hits merge with a 64-bit atomic min).  Five frames at 1280x720 with the split forced hard (a new wave per 40
+    lane-steps, up to 8 per bin) against the same frames with it off: every target bit-identical, and the split list in use."""
+    from raytracedggx_amd import app, capi
+    args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 1280, "-height", 720, "-sharedmem", "-metallic", 0.5, 0.5]
+    a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+    try:
+        a.context.debug_trace_split(0, 0)
+        b.context.debug_trace_split(40, 3, 16384)
+        demands = []
+        for f in range(5):
+            for x in (a, b):
+                x.OnUpdate(); x.OnRender(); x.context.sync()
+            demands.append(b.context.debug_trace_split(40, 3, 16384))
+            assert a.context.debug_trace_split(0, 0) == 0
+            for bid in (capi.BUF_VISIBILITY, capi.BUF_DEPTH, capi.BUF_NORMAL, capi.BUF_RT_REFL, capi.BUF_RT_DIFF, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_BACKBUFFER):
+                np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="frame %d buffer %d" % (f, bid))
+        assert demands[0] == 0 and min(demands[1:]) > 1000, demands       # the first frame knows no costs yet
+    finally:
+        a.OnDestroy(); b.OnDestroy()
+
+
+def test_strip_exchange_through_rccl_send_recv(built):
+    """The direct RCCL path of the strip exchange (raytracedggx_amd/rccl.py: ncclSend/ncclRecv in one group on the
+    renderer's stream, pointers from StripRenderer.raw_ops) on the one GPU of the box: a single-rank communicator whose
+    sends and receives pair up with each other, moving the rows between two strips of one process -- against the
+    single-context frame.  (Across processes the only difference is the peer number.)"""
+    import torch
+    from raytracedggx_amd import capi, rccl
+    from raytracedggx_amd.strips import StripRenderer
+    W, H = 480, 272
+    mesh, env = assets.path("bunny.obj"), assets.path("rnl_cross.dds")
+    strips = []
+    comm = rccl.Communicator(None, 0, 1)
+
+    def transport(r, plan):
+        ops = []
+        for op, name, r0, r1, peer in plan:
+            if op == "recv":
+                src = strips[peer]
+                ops += src.raw_ops([("send", name, r0, r1, 0)], src.context.frame_parity())
+                ops += r.raw_ops([("recv", name, r0, r1, 0)], r.context.frame_parity())
+        for t in strips:
+            r.stream.wait_stream(t.stream)
+        comm.exchange(ops, r.stream.cuda_stream)
+
+    full = StripRenderer(W, H, mesh, env, extra_args=("-sharedmem",))
+    strips += [StripRenderer(W, H, mesh, env, rank=r, world=2, transport=transport, torch_buffers=True, extra_args=("-sharedmem",)) for r in range(2)]
+    try:
+        for f in range(3):
+            full.frame()
+            for s in strips:
+                s.render()
+            for s in strips:
+                s.exchange()
+            for s in strips:
+                for t in strips:
+                    s.stream.wait_stream(t.stream)
+            torch.cuda.synchronize(); full.context.sync()
+            np.testing.assert_array_equal(strips[0].context.readback(capi.BUF_BACKBUFFER), full.context.readback(capi.BUF_BACKBUFFER), err_msg="frame %d" % f)
+            b1, e1 = strips[1].b, strips[1].e
+            for k, s in enumerate(strips):          # each strip's history, with the apron rows it received, equals the full frame's
+                lo, hi = max(s.b - 17, 0), min(s.e + 17, H)
+                bid = capi.BUF_TSS1 if s.context.frame_parity() else capi.BUF_TSS0
+                np.testing.assert_array_equal(s.context.readback(bid)[lo:hi], full.context.readback(bid)[lo:hi], err_msg="history of strip %d, frame %d" % (k, f))
+    finally:
+        comm.destroy()
+        full.close()
+        for s in strips:
+            s.close()
+
+
 def test_c_abi_error_behaviour(built):
     """Misuse is reported through the return code + rtggx_last_error(), never by crashing or by silently doing nothing:
     calls out of order, bad arguments, short buffers (INTEGRATION.md "Error behaviour")."""
