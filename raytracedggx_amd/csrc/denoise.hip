@@ -72,6 +72,7 @@ struct Targets {
 struct Centre { float nx, ny, nz, depth, rough, gaussK /* -0.5 log2(e) / sigma^2 */, depthK /* dc 4 log2(e) */; };
 template <bool DIFFUSE>
 RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, float depth, float rough) {
+#pragma clang fp contract(fast)
   float p = fmaxf((c.nx * nx + c.ny * ny) + c.nz * nz, 0.0f);
   p *= p; p *= p; p *= p; p *= p; p *= p;                 // ^32
   const float dd = fabsf(c.depth - depth) * c.depthK;
@@ -202,11 +203,17 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
     const int ci = vertical ? (ly + k * ROWSTEP + RT_RADIUS) * TW + lx : ly * TW + lx + RT_RADIUS;
     const Centre c = makeCentre<diffuse>(sm[0][ci], sm[1][ci], sm[2][ci], sm[3][ci], sm[4][ci], T.W, T.H);
     float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
+    // one LDS address per channel (the first tap's), held in a register: the 33 taps are then immediate offsets of the
+    // ds_read instructions instead of an address computation each
+    typedef __attribute__((address_space(3))) const float LdsFloat;
+    LdsFloat* ch[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ch[q] = (LdsFloat*)&sm[q][ci - RT_RADIUS * (vertical ? TW : 1)]; asm volatile("" : "+v"(ch[q])); }
 #pragma unroll
     for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
-      const int ti = ci + (vertical ? i * TW : i);
-      const float w = tapWeight<diffuse>(c, i, sm[0][ti], sm[1][ti], sm[2][ti], sm[3][ti], sm[4][ti]);
-      mx = __builtin_fmaf(sm[5][ti], w, mx); my = __builtin_fmaf(sm[6][ti], w, my); mz = __builtin_fmaf(sm[7][ti], w, mz);
+      const int ti = (i + RT_RADIUS) * (vertical ? TW : 1);
+      const float w = tapWeight<diffuse>(c, i, ch[0][ti], ch[1][ti], ch[2][ti], ch[3][ti], ch[4][ti]);
+      mx = __builtin_fmaf(ch[5][ti], w, mx); my = __builtin_fmaf(ch[6][ti], w, my); mz = __builtin_fmaf(ch[7][ti], w, mz);
       wsum += w;
     }
     storeFiltered<MODE>(T, (size_t)y * T.W + x, mx, my, mz, wsum);

@@ -23,6 +23,7 @@
 // culling, TMin < t < TMax, ties to the lower (instance, primitive).  The closest hit does not depend on the
 // order in which boxes are visited, so the 4-wide collapse, the work sharing and the postponed triangle tests
 // leave every hit record bit-identical to the oracle's binary-tree walk (tests/test_gpu_parity.py).
+#include <type_traits>
 #include "rt_queue.h"
 #include "rt_traverse.h"
 
@@ -130,34 +131,43 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   const uint32_t slot = bin * RT_BIN + min(rayIndex, RT_BIN - 1u);
   const bool hasRay = lane < raysPerWave && rayIndex < count;
 
-  // ---- the ray: world space -> the object spaces of both instances --------------------------------------------
+  // ---- the ray (world space) ------------------------------------------------------------------------------------
   const float4* rp = reinterpret_cast<const float4*>(A.rays + (hasRay ? slot : bin * RT_BIN));
   const float4 ra = rp[0], rb = rp[1];
   const uint4 rc = reinterpret_cast<const uint4*>(rp)[2];
-  float tmin = ra.w;
+  const float tmin0 = ra.w;
   float bestT = rb.w;
   uint32_t bestId = 0xFFFFFFFFu;
-  uint32_t skip = rc.y;
-  uint32_t inst = A.haveMesh0 ? 0u : 1u;
-  const LaneRay r1 = toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[1]);
-  LaneRay r = inst ? r1 : toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[0]);
-  int32_t cur = inst ? A.root1 : A.root0;
-  int sp = 0, sb = 0;                                // my stack holds entries [sb, sp)
   {
     const uint32_t row = rc.x / A.width;
     if (hasRay && row >= A.countRowBegin && row < A.countRowEnd) ++nRays;
   }
-  // job state: the primary job of my own ray (none for a degenerate interval or an empty scene: the key stays a miss)
-  bool job = hasRay && bestT > tmin && !(inst == 1u && A.haveMesh1 == 0u), helper = false;
-  uint32_t owner = slot;                             // the ray slot whose key this job's hits go to
 
-  // ---- traversal -----------------------------------------------------------------------------------------------
+  // ---- traversal of one instance (0: the ground, 1: the model), all rays of the round -------------------------------
+  // One loop per instance, one after the other: inside a loop the instance is a compile-time constant (node and triangle
+  // bases are scalars, no per-lane selection, and a job never has to swap one object-space ray for the other).  A primary
+  // job keeps its best hit in registers from the first loop to the second; helpers merge theirs into the ray's key.
+  auto traverse = [&](auto instTag) {
+  constexpr uint32_t INST = decltype(instTag)::value;
+  if ((INST ? A.haveMesh1 : A.haveMesh0) == 0u) return;
+  const float4* const nodes = INST ? A.nodes1 : A.nodes0;
+  const float4* const tris = INST ? A.tris1 : A.tris0;
+  LaneRay r = toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[INST]);
+  float tmin = tmin0;
+  uint32_t skip = rc.y;
+  int32_t cur = INST ? A.root1 : A.root0;
+  int sp = 0, sb = 0;                                // my stack holds entries [sb, sp)
+  // job state: the primary job of my own ray (none for a degenerate interval: the key stays a miss)
+  bool job = hasRay && bestT > tmin, helper = false;
+  uint32_t owner = slot;                             // the ray slot whose key this job's hits go to
+  float myT = bestT; uint32_t myId = bestId;         // the best hit of the job in hand (a helper's: its victim's, then its own)
+
   for (;;) {
     const unsigned long long jobMask = __ballot(job);
     if (jobMask == 0ull) break;
     work += (uint32_t)__popcll(jobMask);
     // -- idle lanes take over pending subtrees
-    if ((uint32_t)__popcll(__ballot(!job)) >= RT_STEAL_MIN_IDLE) {
+    if ((uint32_t)__popcll(~jobMask) >= RT_STEAL_MIN_IDLE) {
       for (int round = 0; round < RT_STEAL_ROUNDS; ++round) {
         const bool offers = job && sb < sp && sb < RT_STACK;                 // bottom entry exists and lives in LDS
         const unsigned long long victimMask = __ballot(offers), idleMask = __ballot(!job);
@@ -173,14 +183,14 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
         const float v_ix = __shfl(r.ix, (int)v), v_iy = __shfl(r.iy, (int)v), v_iz = __shfl(r.iz, (int)v);
         const float v_Sx = __shfl(r.Sx, (int)v), v_Sy = __shfl(r.Sy, (int)v), v_Sz = __shfl(r.Sz, (int)v);
         const int v_kx = __shfl(r.kx, (int)v), v_ky = __shfl(r.ky, (int)v), v_kz = __shfl(r.kz, (int)v);
-        const float v_tmin = __shfl(tmin, (int)v), v_bestT = __shfl(bestT, (int)v);
-        const uint32_t v_bestId = (uint32_t)__shfl((int)bestId, (int)v), v_skip = (uint32_t)__shfl((int)skip, (int)v);
-        const uint32_t v_inst = (uint32_t)__shfl((int)inst, (int)v), v_owner = (uint32_t)__shfl((int)owner, (int)v);
+        const float v_tmin = __shfl(tmin, (int)v), v_bestT = __shfl(myT, (int)v);
+        const uint32_t v_bestId = (uint32_t)__shfl((int)myId, (int)v), v_skip = (uint32_t)__shfl((int)skip, (int)v);
+        const uint32_t v_owner = (uint32_t)__shfl((int)owner, (int)v);
         if (thief) {
           cur = stackBase[vsb * 64 + (int)v];
           r.ox = v_ox; r.oy = v_oy; r.oz = v_oz; r.ix = v_ix; r.iy = v_iy; r.iz = v_iz; r.Sx = v_Sx; r.Sy = v_Sy; r.Sz = v_Sz;
           r.kx = v_kx; r.ky = v_ky; r.kz = v_kz;
-          tmin = v_tmin; bestT = v_bestT; bestId = v_bestId; skip = v_skip; inst = v_inst; owner = v_owner;
+          tmin = v_tmin; myT = v_bestT; myId = v_bestId; skip = v_skip; owner = v_owner;
           sp = sb = 0; job = true; helper = true;
 #ifdef RT_TRACE_STATS
           ++stSteal;
@@ -193,22 +203,23 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
     ++stIter; if (job && cur >= 0) ++stNode;
 #endif
     bool finished = false;
-    // Pop the next entry of my stack; with none left the job is over (the primary job first moves on from the ground
-    // instance to the model: same world ray, object-space copy r1).
+    // Pop the next entry of my stack; with none left the job is over.  (The LDS part of the stack is read
+    // unconditionally: keeping the two address spaces apart keeps the pop a ds_read instead of a flat load.)
     auto popOrFinish = [&]() {
       if (sp > sb) {
         --sp;
-        if (sp < RT_STACK) cur = stack[sp * 64]; else cur = spill[(size_t)(sp - RT_STACK) * spillStride];
+        cur = stack[min(sp, RT_STACK - 1) * 64];
+        asm volatile("" : "+v"(cur));
+        if (sp >= RT_STACK) cur = spill[(size_t)(sp - RT_STACK) * spillStride];
         if (sp == sb) sp = sb = 0;
       } else {
         sp = sb = 0;
-        if (!helper && inst == 0u && A.haveMesh1 != 0u) { inst = 1u; r = r1; cur = A.root1; }
-        else { job = false; finished = true; }
+        job = false; finished = true;
       }
     };
     // -- node phase: lanes standing on a 4-wide node test its boxes (one 128-byte fetch); lanes standing on a leaf wait
     if (job && cur >= 0) {
-      const float4* rec = (inst ? A.nodes1 : A.nodes0) + (size_t)cur * 8;
+      const float4* rec = nodes + (size_t)cur * 8;
       float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
       asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
       asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
@@ -218,10 +229,10 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
       float t0, t1, t2, t3, tf;
       int32_t c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
       const float inf = __builtin_inff();
-      slabTest(r, q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, tmin, bestT, t0, tf); t0 = (t0 <= tf * 1.0000004f && c0 != RT_BVH4_EMPTY) ? t0 : inf;
-      slabTest(r, q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, tmin, bestT, t1, tf); t1 = (t1 <= tf * 1.0000004f && c1 != RT_BVH4_EMPTY) ? t1 : inf;
-      slabTest(r, q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, tmin, bestT, t2, tf); t2 = (t2 <= tf * 1.0000004f && c2 != RT_BVH4_EMPTY) ? t2 : inf;
-      slabTest(r, q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, tmin, bestT, t3, tf); t3 = (t3 <= tf * 1.0000004f && c3 != RT_BVH4_EMPTY) ? t3 : inf;
+      slabTest(r, q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, tmin, myT, t0, tf); t0 = (t0 <= tf * 1.0000004f && c0 != RT_BVH4_EMPTY) ? t0 : inf;
+      slabTest(r, q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, tmin, myT, t1, tf); t1 = (t1 <= tf * 1.0000004f && c1 != RT_BVH4_EMPTY) ? t1 : inf;
+      slabTest(r, q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, tmin, myT, t2, tf); t2 = (t2 <= tf * 1.0000004f && c2 != RT_BVH4_EMPTY) ? t2 : inf;
+      slabTest(r, q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, tmin, myT, t3, tf); t3 = (t3 <= tf * 1.0000004f && c3 != RT_BVH4_EMPTY) ? t3 : inf;
       // order the entries by entry distance (misses last); the order only affects how soon far boxes get culled
 #define RT_CSWAP(ta, ca, tb, cb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; const int32_t cc = sw ? cb : ca; cb = sw ? ca : cb; ca = cc; }
       RT_CSWAP(t0, c0, t1, c1) RT_CSWAP(t2, c2, t3, c3) RT_CSWAP(t0, c0, t2, c2) RT_CSWAP(t1, c1, t3, c3) RT_CSWAP(t1, c1, t2, c2)
@@ -248,18 +259,18 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
         ++stLeafPhase;
 #endif
         if (atLeaf) {
-          const float4* rec = (inst ? A.tris1 : A.tris0) + (size_t)(~cur) * 4;
+          const float4* rec = tris + (size_t)(~cur) * 4;
           float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
           asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
           asm volatile("" : "+v"(q2.x), "+v"(q3.x));
           // q0 = v0.xyz v1.x | q1 = v1.yz v2.xy | q2 = v2.z pad pad pad | q3 = prim pad pad pad
-          const uint32_t id = (inst << 24) | __float_as_uint(q3.x);
+          const uint32_t id = (INST << 24) | __float_as_uint(q3.x);
           if (id != skip) {
             float t, b1, b2;
             if (woopTest(r, q0, q1, q2, t, b1, b2) && t > tmin) {
-              const bool closer = t < bestT;
-              const bool tie = bestId != 0xFFFFFFFFu && t == bestT && id < bestId;
-              if (closer || tie) { bestT = t; bestId = id; }
+              const bool closer = t < myT;
+              const bool tie = myId != 0xFFFFFFFFu && t == myT && id < myId;
+              if (closer || tie) { myT = t; myId = id; }
             }
           }
           popOrFinish();
@@ -269,13 +280,17 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
         }
       }
     }
-    // -- a finished job merges its best hit into the ray's key (a helper that found nothing closer than what it started
-    //    with repeats its victim's candidate: harmless)
+    // -- a finished helper merges its best hit into the ray's key (one that found nothing closer than what it started
+    //    with repeats its victim's candidate: harmless); a finished primary job keeps its own in bestT / bestId
     if (finished) {
-      if (bestId != 0xFFFFFFFFu) atomicMin(&A.hits[owner], hitKey(bestT, bestId));
-      helper = false;
+      if (helper) { if (myId != 0xFFFFFFFFu) atomicMin(&A.hits[owner], hitKey(myT, myId)); helper = false; }
+      else { bestT = myT; bestId = myId; }
     }
   }
+  };   // traverse
+  traverse(std::integral_constant<uint32_t, 0u>{});
+  traverse(std::integral_constant<uint32_t, 1u>{});
+  if (hasRay && bestId != 0xFFFFFFFFu) atomicMin(&A.hits[slot], hitKey(bestT, bestId));
   }   // base
 
   // ray statistics: one fire-and-forget atomic per wave, spread over 256 words
