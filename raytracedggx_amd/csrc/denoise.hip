@@ -299,6 +299,7 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   // history: bilinear, clamped addressing :259-260
   f4 history;
   {
+#pragma clang fp contract(fast)       // smooth terms (reprojection, bilinear weights): fused multiply-adds are welcome
     const float sx = (uvx - vmax.x) * Wf - 0.5f, sy = (uvy - vmax.y) * Hf - 0.5f;
     const float x0 = floorf(sx), y0 = floorf(sy);
     const float fx = sx - x0, fy = sy - y0;
@@ -346,6 +347,10 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     }
     nmin[3] = mu[0] - sigma[0]; nmax[3] = mu[0] + sigma[0];
   }
+  // from here on smooth terms again (the clamp window nmin/nmax above is the part that needs the reference's rounding)
+  f3 result; float hw;
+  {
+#pragma clang fp contract(fast)
   curHistoryBlur = saturatef(curHistoryBlur);   // :290-291
   historyBlur = saturatef(historyBlur);
   const f3 hTM = tssTMSmooth(mk3(history.x, history.y, history.z));   // :294-299
@@ -362,14 +367,16 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   float blend = 0.25f * rcpFast(lerpf(8.0f, distToClamp + contrast, historyAmt));
   blend = fminf(blend, 0.25f);
   blend = fl[3] > 0.0f ? blend : 1.0f;
-  f3 result = tssITM(mk3(lerpf(historyTM[0], fl[0], blend), lerpf(historyTM[1], fl[1], blend), lerpf(historyTM[2], fl[2], blend)));   // :327-329
+  result = tssITM(mk3(lerpf(historyTM[0], fl[0], blend), lerpf(historyTM[1], fl[1], blend), lerpf(historyTM[2], fl[2], blend)));   // :327-329
   if (isnan(result.x) || isnan(result.y) || isnan(result.z)) result = tssITM(mk3(fl[0], fl[1], fl[2]));
-  const float hw = fminf(history.w * (1.0f / 15.0f), 1.0f - curHistoryBlur);
+  hw = fminf(history.w * (1.0f / 15.0f), 1.0f - curHistoryBlur);
+  }
   T.scratch[(size_t)y * W + x] = packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
 }
 
 // PSToneMap.hlsl:13-41; source = TSS[parity] (passed as T.scratch)
 __global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
+#pragma clang fp contract(fast)
   __shared__ float4 tile[6][66];          // c / (c + 0.5) of the block's pixels and a one-texel apron, computed once per texel
   const int W = T.W, H = T.H;
   {
