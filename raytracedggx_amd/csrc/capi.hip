@@ -77,14 +77,6 @@ static int uploadParamsStreamB(rtggx_context* c) {
   return 0;
 }
 static int ensureParams(rtggx_context* c) { return c->slotUploaded ? 0 : uploadParamsStreamB(c); }
-// The main stream has just been given work that reads the current input set (G-buffer, depth, traced images):
-// stream B may not overwrite that set (two frames from now) before this point.
-static int markSetRead(rtggx_context* c) {
-  RT_HIP(hipEventRecord(c->evSetRead[c->setIndex], c->streamMain));
-  c->setReadRecorded[c->setIndex] = true;
-  return 0;
-}
-
 static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t ni) {
   MeshDev& m = c->mesh[slot];
   RT_HIP(hipStreamSynchronize(mainStream(c)));
@@ -144,6 +136,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipStreamCreateWithPriority(&c->ownMain, hipStreamNonBlocking, prioLeast));
   RT_HIP(hipStreamCreateWithPriority(&c->streamAS, hipStreamNonBlocking, prioGreatest));
   c->streamMain = c->ownMain;
+  c->attachEvents = !(getenv("RTGGX_ATTACH_EVENTS") && atoi(getenv("RTGGX_ATTACH_EVENTS")) == 0);
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -345,22 +338,25 @@ int rtggx_ray_trace(rtggx_context* c) {
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[3], c->streamAS);
-  int r = launchRayTrace(c, c->slots[c->slot], c->streamAS);
+  int r = launchRayTrace(c, c->slots[c->slot], c->streamAS, c->evRT);
   // stream B runs ahead with ray generation and traversal; shading and the denoiser consume the bins, the G-buffer
-  // and the traced images on the main stream
-  RT_HIP(hipEventRecord(c->evRT, c->streamAS));
+  // and the traced images on the main stream (evRT completes with the trace kernel)
   RT_HIP(hipStreamWaitEvent(c->streamMain, c->evRT, 0));
-  if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain);
+  // the main stream has now been given work that reads the current input set: stream B may not overwrite that set (two
+  // frames from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
+  if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain, c->evSetRead[c->setIndex]);
+  c->setReadRecorded[c->setIndex] = true;
   if (c->timing) hipEventRecord(c->tev[14], c->streamMain);
-  return r ? r : markSetRead(c);
+  return r;
 }
 
 int rtggx_denoise(rtggx_context* c, int useSharedMem) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_denoise: no frame constants"); return -1; }
   if (c->timing) hipEventRecord(c->tev[9], c->streamMain);   // start of denoise
-  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain);
-  return r ? r : markSetRead(c);
+  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, c->evSetRead[c->setIndex]);
+  c->setReadRecorded[c->setIndex] = true;
+  return r;
 }
 
 int rtggx_tone_map(rtggx_context* c) {

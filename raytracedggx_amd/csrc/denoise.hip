@@ -16,6 +16,7 @@
 // exponentials merged into one exp2 -- ~35 VALU instructions per tap instead of ~400 with libm calls.  The passes
 // are VALU-bound (33 taps per covered pixel); their HBM traffic (22-30 B/pixel/pass) is ~5% of the
 // time.  Out-of-range texels are the zeros D3D returns.
+#include <hip/hip_ext.h>
 #include "rtggx_context.h"
 
 namespace rt {
@@ -296,6 +297,15 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     }
     vmax.x = f16ToF32(raw & 0xFFFFu); vmax.y = f16ToF32(raw >> 16);
   }
+  // The alpha of the 3x3 neighbourhood, filtered like the colour below (fl[3] of NeighborMinMax).  Zero means there is no
+  // surface anywhere in the neighbourhood (background: FilteredOut1 carries alpha 0 there), and then blend = 1 at :325:
+  // the history does not contribute to the colour.  Such pixels -- most of the frame -- take the short path at the end
+  // of this kernel, which leaves out what only feeds the history term: the history colour, the chroma variances, the
+  // clamp window.  It computes a + 1 (b - a) as b, so it matches the long path to rounding, not to the bit.
+  float alphaFiltered = cur.w;
+  for (int i = 0; i < 8; ++i) alphaFiltered = __builtin_fmaf(tile[ly + oy[i]][lx + ox[i]].w, i < 4 ? 0.5f : 0.25f, alphaFiltered);
+  alphaFiltered /= 4.0f;
+  const bool plain = !(alphaFiltered > 0.0f);
   // history: bilinear, clamped addressing :259-260
   f4 history;
   {
@@ -307,19 +317,51 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     const int ix1 = x0 + 1.0f < 0.0f ? 0 : (x0 + 1.0f > (float)(W - 1) ? W - 1 : (int)(x0 + 1.0f));
     const int iy0 = y0 < 0.0f ? 0 : (y0 > (float)(H - 1) ? H - 1 : (int)y0);
     const int iy1 = y0 + 1.0f < 0.0f ? 0 : (y0 + 1.0f > (float)(H - 1) ? H - 1 : (int)(y0 + 1.0f));
-    const f4 t00 = unpackRGBA16F(T.history[(size_t)iy0 * W + ix0]), t10 = unpackRGBA16F(T.history[(size_t)iy0 * W + ix1]);
-    const f4 t01 = unpackRGBA16F(T.history[(size_t)iy1 * W + ix0]), t11 = unpackRGBA16F(T.history[(size_t)iy1 * W + ix1]);
     const float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-    history.x = ((t00.x * w00 + t10.x * w10) + t01.x * w01) + t11.x * w11;
-    history.y = ((t00.y * w00 + t10.y * w10) + t01.y * w01) + t11.y * w11;
-    history.z = ((t00.z * w00 + t10.z * w10) + t01.z * w01) + t11.z * w11;
-    history.w = ((t00.w * w00 + t10.w * w10) + t01.w * w01) + t11.w * w11;
+    const uint2* h00 = T.history + (size_t)iy0 * W + ix0; const uint2* h10 = T.history + (size_t)iy0 * W + ix1;
+    const uint2* h01 = T.history + (size_t)iy1 * W + ix0; const uint2* h11 = T.history + (size_t)iy1 * W + ix1;
+    if (plain) {      // only the alpha (history length) is needed
+      history.x = history.y = history.z = 0.0f;
+      history.w = ((f16ToF32(h00->y >> 16) * w00 + f16ToF32(h10->y >> 16) * w10) + f16ToF32(h01->y >> 16) * w01) + f16ToF32(h11->y >> 16) * w11;
+    } else {
+      const f4 t00 = unpackRGBA16F(*h00), t10 = unpackRGBA16F(*h10), t01 = unpackRGBA16F(*h01), t11 = unpackRGBA16F(*h11);
+      history.x = ((t00.x * w00 + t10.x * w10) + t01.x * w01) + t11.x * w11;
+      history.y = ((t00.y * w00 + t10.y * w10) + t01.y * w01) + t11.y * w11;
+      history.z = ((t00.z * w00 + t10.z * w10) + t01.z * w01) + t11.z * w11;
+      history.w = ((t00.w * w00 + t10.w * w10) + t01.w * w01) + t11.w * w11;
+    }
   }
   // :262-281
   float curHistoryBlur = fabsf(vmax.x) * (4.0f * Wf) + fabsf(vmax.y) * (4.0f * Hf);
   float historyBlur = 1.0f - history.w;
   historyBlur = fmaxf(historyBlur, curHistoryBlur);
   history.w = history.w * 15.0f + 1.0f;
+  f3 result; float hw;
+  if (plain) {
+    // NeighborMinMax :166-236, the part that reaches the result when blend = 1: the filtered colour and the luma contrast
+    float fl[3] = {currentTM.x, currentTM.y, currentTM.z};
+    float mu0 = currentTM.x, m20 = mu0 * mu0;
+    for (int i = 0; i < 8; ++i) {
+      const float4 t = tile[ly + oy[i]][lx + ox[i]];
+      const float wgt = i < 4 ? 0.5f : 0.25f;
+      fl[0] = __builtin_fmaf(t.x, wgt, fl[0]); fl[1] = __builtin_fmaf(t.y, wgt, fl[1]); fl[2] = __builtin_fmaf(t.z, wgt, fl[2]);
+      mu0 += t.x; m20 += t.x * t.x;
+    }
+    for (int k = 0; k < 3; ++k) fl[k] /= 4.0f;
+    mu0 = divBy9(mu0);
+    const float sigma0 = sqrtRN(fabsf(divBy9(m20) - mu0 * mu0));
+    const float nmin3 = mu0 - sigma0, nmax3 = mu0 + sigma0;
+    {
+#pragma clang fp contract(fast)
+      curHistoryBlur = saturatef(curHistoryBlur);
+      historyBlur = saturatef(historyBlur);
+      const float contrast = nmax3 - nmin3;
+      float addAlias = historyBlur * 0.5f + 0.25f;
+      addAlias = saturatef(addAlias + rcpFast(1.0f + contrast * (32.0f * 4.0f)));
+      result = tssITM(mk3(lerpf(fl[0], currentTM.x, addAlias), lerpf(fl[1], currentTM.y, addAlias), lerpf(fl[2], currentTM.z, addAlias)));
+      hw = fminf(history.w * (1.0f / 15.0f), 1.0f - curHistoryBlur);
+    }
+  } else {
   float gamma = current.w <= 0.0f ? 1.0f : clampf(8.0f * rcpFast(historyBlur), 1.0f, 32.0f);
   // NeighborMinMax :166-236
   float fl[4] = {currentTM.x, currentTM.y, currentTM.z, current.w};
@@ -348,7 +390,6 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     nmin[3] = mu[0] - sigma[0]; nmax[3] = mu[0] + sigma[0];
   }
   // from here on smooth terms again (the clamp window nmin/nmax above is the part that needs the reference's rounding)
-  f3 result; float hw;
   {
 #pragma clang fp contract(fast)
   curHistoryBlur = saturatef(curHistoryBlur);   // :290-291
@@ -370,6 +411,7 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   result = tssITM(mk3(lerpf(historyTM[0], fl[0], blend), lerpf(historyTM[1], fl[1], blend), lerpf(historyTM[2], fl[2], blend)));   // :327-329
   if (isnan(result.x) || isnan(result.y) || isnan(result.z)) result = tssITM(mk3(fl[0], fl[1], fl[2]));
   hw = fminf(history.w * (1.0f / 15.0f), 1.0f - curHistoryBlur);
+  }
   }
   T.scratch[(size_t)y * W + x] = packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
 }
@@ -411,7 +453,7 @@ static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass
   return T;
 }
 
-int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s) {
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done) {
   c->frameParity ^= 1u;   // Denoiser.cpp:69
   if (fp.rowEnd <= fp.rowBegin) return 0;
   const Targets TH = makeTargets(c, fp, ROWS_GBUFFER), TV = makeTargets(c, fp, ROWS_VFILTER), TT = makeTargets(c, fp, ROWS_TEMPORAL);
@@ -429,7 +471,9 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
     hipLaunchKernelGGL(spatialDirectKernel<2>, grid(TH, 64, 4), block, 0, s, TH); mark(6);
     hipLaunchKernelGGL(spatialDirectKernel<3>, grid(TV, 64, 4), block, 0, s, TV); mark(7);
   }
-  hipLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, TT); mark(8);
+  if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, nullptr, done, 0, TT);
+  else { hipLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, TT); if (done) hipEventRecord(done, s); }
+  mark(8);
   RT_HIP(hipGetLastError());
   return 0;
 }

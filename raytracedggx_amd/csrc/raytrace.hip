@@ -23,6 +23,7 @@
 // rayGen 18 B/pixel (+64 B per queued ray); trace 64 B ray + 16 B hit per ray + the scene arrays
 // once; shade 64+16 B in, 4 B out per ray.  The BVH (<= 14 MB) is L2/MALL resident, so traversal is
 // bound by L1 request rate, issue and latency, not by HBM (DESIGN.md "Roofline").
+#include <hip/hip_ext.h>
 #include "rt_queue.h"
 #include "rt_traverse.h"
 
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict
 // =========================================================================================================
 // host side
 // =========================================================================================================
-int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
+int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done) {
   uint32_t rb, re;
   passRows(fp, ROWS_GBUFFER, rb, re);
   if (re <= rb) return 0;
@@ -458,15 +459,20 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, G);
   if (c->timing) hipEventRecord(c->tev[11], s);
   const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size() && (c->ringTick++ % c->ringStride) == 0u;
-  if (ring) hipEventRecord(c->kevBegin[c->kevCount], s);
-  { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true, tilesX, tilesY, sliceShift, adaptive ? (int)G.splitCap : -1); if (r) return r; }
+  // a sampled frame: the event pair of the kernel ring rides on the dispatch (and `done` is recorded behind it)
+  const bool attach = c->attachEvents;
+  if (ring && !attach) hipEventRecord(c->kevBegin[c->kevCount], s);
+  { const int r = launchTrace(c, fp, s, G.numTiles * 4u, true, tilesX, tilesY, sliceShift, adaptive ? (int)G.splitCap : -1,
+                              ring && attach ? c->kevBegin[c->kevCount] : nullptr, !attach ? nullptr : ring ? c->kevEnd[c->kevCount] : done); if (r) return r; }
   if (c->timing) hipEventRecord(c->tev[12], s);
-  if (ring) hipEventRecord(c->kevEnd[c->kevCount++], s);
+  if (ring && !attach) hipEventRecord(c->kevEnd[c->kevCount], s);
+  if (ring) ++c->kevCount;
+  if (done && (ring || !attach)) hipEventRecord(done, s);
   RT_HIP(hipGetLastError());
   return 0;
 }
 
-int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
+int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done) {
   uint32_t rb, re;
   passRows(fp, ROWS_GBUFFER, rb, re);
   if (re <= rb) return 0;
@@ -476,7 +482,11 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   S.verts0 = c->mesh[0].verts; S.idx0 = c->mesh[0].indices; S.verts1 = c->mesh[1].verts; S.idx1 = c->mesh[1].indices;
   S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;
   S.reflOut = c->rtRefl; S.diffOut = c->rtDiff;
-  hipLaunchKernelGGL(shadeKernel, dim3(numTiles), dim3(256), 0, s, c->dParams + c->slot, S);
+  if (done && c->attachEvents) hipExtLaunchKernelGGL(shadeKernel, dim3(numTiles), dim3(256), 0, s, nullptr, done, 0, (const FrameParams*)(c->dParams + c->slot), S);
+  else {
+    hipLaunchKernelGGL(shadeKernel, dim3(numTiles), dim3(256), 0, s, c->dParams + c->slot, S);
+    if (done) hipEventRecord(done, s);
+  }
   RT_HIP(hipGetLastError());
   return 0;
 }

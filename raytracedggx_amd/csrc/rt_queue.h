@@ -48,6 +48,8 @@ RT_HD uint32_t hitKeyId(HitKey k) { return (uint32_t)k; }
 // the bins rayGenKernel marked (bits 8.. of binCount, c->splitList with room for splitCap waves) are traced by several
 // waves, and the kernel records what each bin cost (c->binWork) for the next frame's decision; -1: off.
 uint32_t chooseSliceShift(rtggx_context* c, bool countRays, uint32_t numBins);
-int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY, uint32_t sliceShift, int splitCap);
+// start / stop (may be null): events attached to the kernel's dispatch (begin of execution / completion).
+int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY, uint32_t sliceShift, int splitCap,
+                hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 }  // namespace rt

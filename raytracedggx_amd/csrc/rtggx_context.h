@@ -65,6 +65,7 @@ struct rtggx_context {
   uint32_t W = 0, H = 0;
   uint32_t rowBegin = 0, rowEnd = 0;
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
+  bool attachEvents = true;             // RTGGX_ATTACH_EVENTS=0: record the cross-stream events with hipEventRecord instead
   hipEvent_t evAS = nullptr;      // constants uploaded (stream B -> main)
   hipEvent_t evRT = nullptr, evSetRead[2] = {nullptr, nullptr};   // ray trace done (stream B -> main); last reader of input set i done (main -> stream B)
   bool setReadRecorded[2] = {false, false};
@@ -165,10 +166,13 @@ int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s);
 int uploadScene(rtggx_context* c, hipStream_t s);
 int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s);
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
-int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s);   // ray generation + traversal
-int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s);      // hit / miss shading of the traced bins
+int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);   // ray generation + traversal
+// `done` (may be null) on the launch functions below: an event that completes with the pass's last kernel.  It rides on that
+// kernel's own completion signal (hipExtLaunchKernelGGL) instead of a marker packet behind it: a marker costs its queue
+// 5-7 us, and the frame's two chains had four of them (rocprofv3 kernel trace, profiles/).
+int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);      // hit / miss shading of the traced bins
 int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s);
-int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s);
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done = nullptr);
 int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s);
 int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* hostData, size_t bytes, hipStream_t s);
 int projectSH(rtggx_context* c, hipStream_t s);

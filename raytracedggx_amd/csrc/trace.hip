@@ -24,6 +24,7 @@
 // order in which boxes are visited, so the 4-wide collapse, the work sharing and the postponed triangle tests
 // leave every hit record bit-identical to the oracle's binary-tree walk (tests/test_gpu_parity.py).
 #include <type_traits>
+#include <hip/hip_ext.h>
 #include "rt_queue.h"
 #include "rt_traverse.h"
 
@@ -71,11 +72,27 @@ struct TraceArgs {
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 8u         // lanes standing on a leaf that make a triangle-test phase worthwhile
 #endif
-__global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
-  __shared__ int32_t stackMem[RT_STACK * 256];
-  __shared__ uint32_t victimMem[256];              // scratch: the lanes offering work, compacted
+// Workgroup = ONE wave.  The LDS stack of a workgroup stays allocated until its last wave ends; with four bins per
+// workgroup, three of them empty or cheap, a CU ran out of LDS (6 workgroups) long before it ran out of wave slots, and
+// the kernel averaged 2100 live waves on 5120 slots (tools/probes/trace_stats_probe.py).  The index arithmetic below
+// still speaks of 256-thread "blocks" (four consecutive bins of a tile): hardware workgroup g is wave (g >> 3) & 3 of
+// virtual block ((g >> 5) << 3) | (g & 7) -- same XCD (g & 7) for the four waves of a block.
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 1
+#endif
+#ifndef RT_TRACE_MIN_WAVES
+#define RT_TRACE_MIN_WAVES 6     // waves per SIMD the register allocation aims for (80 VGPRs; 85 without the hint = 5 waves)
+#endif
+__global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
+  __shared__ int32_t stackMem[RT_STACK * 64 * RT_TRACE_WAVES];
+  __shared__ uint32_t victimMem[64 * RT_TRACE_WAVES];              // scratch: the lanes offering work, compacted
   const FrameParams& fp = *fpp;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+#if RT_TRACE_WAVES == 1
+  const uint32_t wave = (blockIdx.x >> 3) & 3u, vblock = ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7u), ldsWave = 0u;
+#else
+  const uint32_t wave = threadIdx.x >> 6, vblock = blockIdx.x, ldsWave = wave;
+#endif
   // Workgroup -> tile.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2; handing every
   // XCD whole super-tiles of 8x8 tiles (128x128 pixels), dealt round-robin over the screen, keeps the part of the tree
   // an L2 needs at any one time small without tying an XCD to one (cheap or expensive) region of the screen.
@@ -88,8 +105,8 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   // frame (binWork, lane-steps; the camera moves little in 1/60 s): rayGenKernel gives such bins 2, 4 or 8 waves and
   // lists them (splitList), and the first splitBlocks workgroups of the grid -- dispatched first -- trace them.
   uint32_t shift = A.sliceShift, bin, slice;
-  if (blockIdx.x < A.splitBlocks) {
-    const uint32_t item = blockIdx.x * 4u + wave;
+  if (vblock < A.splitBlocks) {
+    const uint32_t item = vblock * 4u + wave;
     if (item >= min(*A.splitCount, A.splitBlocks * 4u)) return;
     const uint32_t e = A.splitList[item];
     if (e == 0xFFFFFFFFu) return;
@@ -97,7 +114,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
     if (bin >= A.numBins) return;
   } else {
     const uint32_t slices = 1u << shift;
-    const uint32_t blk = (blockIdx.x - A.splitBlocks) >> shift, sub = (blockIdx.x - A.splitBlocks) & (slices - 1u);
+    const uint32_t blk = (vblock - A.splitBlocks) >> shift, sub = (vblock - A.splitBlocks) & (slices - 1u);
     uint32_t tile = blk;
     if (A.tilesX != 0u) {
       const uint32_t xcd = blk & 7u, local = blk >> 3;
@@ -112,12 +129,12 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   }
   const uint32_t raysPerWave = 64u >> shift;
   const uint32_t countWord = A.binCount[bin];
-  if (blockIdx.x >= A.splitBlocks && A.binWork != nullptr && (countWord >> 8) != 0u) return;      // traced by the waves of the split list
+  if (vblock >= A.splitBlocks && A.binWork != nullptr && (countWord >> 8) != 0u) return;      // traced by the waves of the split list
   const uint32_t count = min(countWord & 0xFFu, RT_BIN);
   if (count <= slice * raysPerWave) return;
-  int32_t* const stackBase = stackMem + wave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
+  int32_t* const stackBase = stackMem + ldsWave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
   int32_t* const stack = stackBase + lane;
-  uint32_t* const victims = victimMem + wave * 64;
+  uint32_t* const victims = victimMem + ldsWave * 64;
   const size_t spillStride = A.spillStride;
   int32_t* const spill = A.overflow + (size_t)bin * 512u + slice * 64u + lane;            // entry e at spill[e * spillStride] (512 lanes per bin: up to 8 waves)
   const unsigned long long laneLt = (1ull << lane) - 1ull;
@@ -296,7 +313,7 @@ __global__ void __launch_bounds__(256) traceKernel(const FrameParams* __restrict
   // ray statistics: one fire-and-forget atomic per wave, spread over 256 words
   for (int o = 32; o > 0; o >>= 1) nRays += __shfl_down(nRays, o);
   if (lane == 0 && nRays) { atomicAdd(&A.rayTotals[bin & 255u], nRays); atomicAdd(&A.runTotals[bin & 255u], (unsigned long long)nRays); }
-  if (lane == 0 && A.binWork != nullptr) { if (blockIdx.x < A.splitBlocks) atomicAdd(&A.binWork[bin], work); else A.binWork[bin] = work; }
+  if (lane == 0 && A.binWork != nullptr) { if (vblock < A.splitBlocks) atomicAdd(&A.binWork[bin], work); else A.binWork[bin] = work; }
 #ifdef RT_TRACE_STATS
   for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); stSteal += __shfl_down(stSteal, o); stDeep = max(stDeep, (uint32_t)__shfl_down((int)stDeep, o)); }
   if (lane == 0) {   // lane node steps, lane leaf steps, wave iterations, waves, deepest stack, wave lifetime (sum, max), most iterations, steals
@@ -333,7 +350,8 @@ uint32_t chooseSliceShift(rtggx_context* c, bool countRays, uint32_t numBins) {
   return forcedShift >= 0 ? (uint32_t)forcedShift : (raysGuess < 25000u ? 3u : raysGuess < 60000u ? 2u : raysGuess < 110000u ? 1u : 0u);
 }
 
-int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY, uint32_t sliceShift, int splitCap) {
+int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY, uint32_t sliceShift, int splitCap,
+                hipEvent_t start, hipEvent_t stop) {
   TraceArgs T;
   if (numBins == 0) return 0;
   if (numBins > c->numBinsMax) { setError("launchTrace: %u bins exceed the %u allocated", numBins, c->numBinsMax); return -1; }
@@ -367,8 +385,9 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.splitList = c->splitList; T.splitCount = c->largeCount + 1;
   T.binWork = adaptive ? c->binWork : nullptr; T.splitBlocks = adaptive ? (uint32_t)splitCap / 4u : 0u;
   const uint32_t superTiles = ((tilesX + 7u) / 8u) * ((tilesY + 7u) / 8u);
-  const uint32_t grid = T.splitBlocks + ((tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (numBins + 3u) / 4u) << T.sliceShift);
-  hipLaunchKernelGGL(traceKernel, dim3(grid), dim3(256), 0, s, c->dParams + c->slot, T);
+  const uint32_t grid = T.splitBlocks + ((tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (((numBins + 3u) / 4u + 7u) / 8u) * 8u) << T.sliceShift);   // virtual blocks, a multiple of 8
+  if (start || stop) hipExtLaunchKernelGGL(traceKernel, dim3(grid * (4u / RT_TRACE_WAVES)), dim3(64 * RT_TRACE_WAVES), 0, s, start, stop, 0, (const FrameParams*)(c->dParams + c->slot), T);
+  else hipLaunchKernelGGL(traceKernel, dim3(grid * (4u / RT_TRACE_WAVES)), dim3(64 * RT_TRACE_WAVES), 0, s, c->dParams + c->slot, T);
   if (countRays && !c->rayCountersInFlight && (c->traceLaunches < 8u || (c->traceLaunches & 15u) == 0u)) {     // the first frames, then every 16th: ray counters and split demand, for later launches
     RT_HIP(hipMemcpyAsync(c->hostRayCounters, c->rayCounter32, 256 * 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->largeCount + 1, 4, hipMemcpyDeviceToHost, s));

@@ -7,7 +7,7 @@ from raytracedggx_amd import app
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 a = app.RayTracedGGX(["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", W, "-height", H])
 a.context.enable_timing(1)
-for f in range(3):
+for f in range(int(sys.argv[3]) if len(sys.argv) > 3 else 3):
     a.OnUpdate(); a.OnRender(); a.context.sync()
     allc = a.context.debug_counters(768, reset=True)
     raw = allc[:256].astype(float).reshape(16, 16)   # 16 copies of the counters
