@@ -58,6 +58,14 @@ def exchange_plan(height, rank, world, apron=HISTORY_APRON):
     return ops
 
 
+def plan_to_raw(plan, history_ptr, backbuffer_ptr, width):
+    """`plan` as the argument lists of ncclSend / ncclRecv: (is_send, device pointer, bytes, peer).  Rows [r0, r1) of
+    TemporalSSOut[parity] (8 B/px) or of the back buffer (4 B/px); every rank holds full-size targets, so both sides
+    address the same rows."""
+    base = {"history": (history_ptr, 8 * width), "backbuffer": (backbuffer_ptr, 4 * width)}
+    return [(op == "send", base[name][0] + r0 * base[name][1], (r1 - r0) * base[name][1], peer) for op, name, r0, r1, peer in plan]
+
+
 def make_ops(dist, plan, buffers):
     """The P2P operations of `plan` over `buffers` = {"history": tensor[H, W], "backbuffer": tensor[H, W]} (row slices
     are views: the list can be built once and reused every frame)."""
@@ -137,15 +145,8 @@ class StripRenderer:
             run_exchange(self.dist, None, None, ops=self._ops[parity])
 
     def raw_ops(self, plan, parity):
-        """`plan` as (is_send, device pointer, bytes, peer): rows [r0, r1) of TemporalSSOut[parity] (8 B/px) or of the
-        back buffer (4 B/px); every rank holds full-size targets, so both sides address the same rows."""
-        base = {"history": (self.context.buffer_ptr(capi.BUF_TSS1 if parity else capi.BUF_TSS0), 8 * self.W),
-                "backbuffer": (self.context.buffer_ptr(capi.BUF_BACKBUFFER), 4 * self.W)}
-        return [(op == "send", base[name][0] + r0 * base[name][1], (r1 - r0) * base[name][1], peer) for op, name, r0, r1, peer in plan]
-
-    def exchange_buffers(self):
-        """The torch views of the two exchanged targets (this frame's temporal result, the back buffer)."""
-        return {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer}
+        """`plan` for rccl.Communicator.exchange, over this renderer's TemporalSSOut[parity] and back buffer."""
+        return plan_to_raw(plan, self.context.buffer_ptr(capi.BUF_TSS1 if parity else capi.BUF_TSS0), self.context.buffer_ptr(capi.BUF_BACKBUFFER), self.W)
 
     # -- statistics --------------------------------------------------------------------------------------
     def rays_traced_since_reset(self):

@@ -77,3 +77,49 @@ def test_plan_is_consistent():
                     assert r1 <= rows[r][0] or r0 >= rows[r][1], "and only receives rows it did not"
         single = exchange_plan(height, 0, 1)
         assert single == []
+
+
+def test_direct_rccl_binding_resolves_every_entry_point():
+    """raytracedggx_amd/rccl.py binds the librccl.so torch ships (no GPU needed to load it): every entry point the strip
+    exchange calls resolves, and the unique-id structure has the size rccl.h gives it."""
+    import ctypes
+    from raytracedggx_amd import rccl
+    L = rccl.lib()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert getattr(L, name) is not None
+    assert ctypes.sizeof(rccl._UniqueId) == rccl.NCCL_UNIQUE_ID_BYTES == 128
+    v = ctypes.c_int()
+    L.ncclGetVersion.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    assert L.ncclGetVersion(ctypes.byref(v)) == 0 and v.value >= 21800      # ncclSend/ncclRecv to self need >= 2.7
+    assert L.ncclGetErrorString(0).decode() != ""
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_raw_send_recv_lists_move_the_right_rows(world):
+    """strips.plan_to_raw (the argument lists of ncclSend / ncclRecv): carried out with memmove between host arrays, pairing
+    the k-th send of rank a to rank b with the k-th receive of rank b from rank a -- RCCL's matching rule inside a group --
+    every rank ends up with its neighbours' boundary rows and rank 0 with the whole back buffer."""
+    import ctypes
+    from raytracedggx_amd import strips
+    H, W = 8 * 20 + 3, 6
+    hist = [np.zeros((H, W), np.uint64) for _ in range(world)]
+    bb = [np.zeros((H, W), np.uint32) for _ in range(world)]
+    truth_h = (np.arange(H * W, dtype=np.uint64).reshape(H, W) + 1) * 1000003
+    truth_b = ((np.arange(H * W, dtype=np.uint64).reshape(H, W) + 7) * 2654435761 % (2 ** 32)).astype(np.uint32)
+    for r in range(world):
+        b, e = strips.strip_rows(H, r, world)
+        hist[r][b:e] = truth_h[b:e]; bb[r][b:e] = truth_b[b:e]
+    raw = [strips.plan_to_raw(strips.exchange_plan(H, r, world), hist[r].ctypes.data, bb[r].ctypes.data, W) for r in range(world)]
+    for a in range(world):
+        for b_ in range(world):
+            sends = [op for op in raw[a] if op[0] and op[3] == b_]
+            recvs = [op for op in raw[b_] if not op[0] and op[3] == a]
+            assert len(sends) == len(recvs)
+            for (_, sp, sn, _), (_, rp, rn, _) in zip(sends, recvs):
+                assert sn == rn
+                ctypes.memmove(rp, sp, sn)
+    np.testing.assert_array_equal(bb[0], truth_b)
+    for r in range(world):
+        b, e = strips.strip_rows(H, r, world)
+        lo, hi = max(b - strips.HISTORY_APRON, 0), min(e + strips.HISTORY_APRON, H)
+        np.testing.assert_array_equal(hist[r][lo:hi], truth_h[lo:hi])
