@@ -460,11 +460,21 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
   const dim3 block(256);
   auto grid = [&](const Targets& T, uint32_t bw, uint32_t bh) { return dim3((fp.W + bw - 1) / bw, (T.rowEnd - T.rowBegin + bh - 1) / bh); };
   auto mark = [&](int i) { if (c->timing) hipEventRecord(c->tev[i], s); };
+  // The diffuse passes only touch pixels whose metallic is below 1, and metallic is a per-instance material constant
+  // (Material.hlsli:20-30: no textures): with both instances fully metallic -- the sample's default -- they have nothing
+  // to do (the reflection V pass already wrote FilteredOut1) and are not launched.  RTGGX_KEEP_EMPTY_DIFFUSE=1 launches them.
+  static const bool keepEmpty = getenv("RTGGX_KEEP_EMPTY_DIFFUSE") && atoi(getenv("RTGGX_KEEP_EMPTY_DIFFUSE")) != 0;
+  const bool anyDiffuse = keepEmpty || fp.mat.RoughMetals[0][1] < 1.0f || fp.mat.RoughMetals[1][1] < 1.0f;
   if (useLds) {
     hipLaunchKernelGGL(spatialTiledKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
     hipLaunchKernelGGL(spatialTiledKernel<1>, grid(TV, RT_VBW, RT_VBH), block, 0, s, TV); mark(5);
-    hipLaunchKernelGGL(spatialTiledKernel<2>, grid(TH, 64, 4), block, 0, s, TH); mark(6);
-    hipLaunchKernelGGL(spatialTiledKernel<3>, grid(TV, RT_VBW, RT_VBH), block, 0, s, TV); mark(7);
+    if (anyDiffuse) hipLaunchKernelGGL(spatialTiledKernel<2>, grid(TH, 64, 4), block, 0, s, TH);
+    mark(6);
+    if (anyDiffuse) hipLaunchKernelGGL(spatialTiledKernel<3>, grid(TV, RT_VBW, RT_VBH), block, 0, s, TV);
+    mark(7);
+  } else if (!anyDiffuse) {
+    hipLaunchKernelGGL(spatialDirectKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
+    hipLaunchKernelGGL(spatialDirectKernel<1>, grid(TV, 64, 4), block, 0, s, TV); mark(5); mark(6); mark(7);
   } else {
     hipLaunchKernelGGL(spatialDirectKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
     hipLaunchKernelGGL(spatialDirectKernel<1>, grid(TV, 64, 4), block, 0, s, TV); mark(5);

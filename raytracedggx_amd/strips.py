@@ -148,6 +148,10 @@ class StripRenderer:
         """`plan` for rccl.Communicator.exchange, over this renderer's TemporalSSOut[parity] and back buffer."""
         return plan_to_raw(plan, self.context.buffer_ptr(capi.BUF_TSS1 if parity else capi.BUF_TSS0), self.context.buffer_ptr(capi.BUF_BACKBUFFER), self.W)
 
+    def exchange_buffers(self):
+        """The torch views of the two exchanged targets (this frame's temporal result, the back buffer)."""
+        return {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer}
+
     # -- statistics --------------------------------------------------------------------------------------
     def rays_traced_since_reset(self):
         return self.context.ray_total(reset=True)
