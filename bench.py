@@ -123,7 +123,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
-                         "note": "dependent-gather kernel: bound by L1 request rate and latency, not by HBM (DESIGN.md 'Roofline')",
+                         "note": "traversal is not bandwidth-shaped: with both streams busy the frame is bound by VALU issue (~80 % of the issue slots of 1024 SIMDs, profiles/*_pmc_report.txt; DESIGN.md 'Roofline')",
                          "frame": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                                    "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
             "passes_ms": r.last_timings(),

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the judged summaries under profiles/ for one tag (run on the GPU box through gpurun, from the repo root):
 #   tools/make_profiles.sh r01_h
-# 1. the default bench line                          -> profiles/<tag>_bench.json
-# 2. rocprofv3 --kernel-trace --stats of the same    -> profiles/<tag>_kernel_stats.csv
-# 3. counter passes (tools/pmc.sh groups 1,2,10,11)  -> profiles/<tag>_pmc_report.txt, profiles/<tag>_pmc_traffic.json
+# 1. counter passes (tools/pmc.sh groups 1,2,10,11)  -> profiles/<tag>_pmc_report.txt, profiles/<tag>_pmc_traffic.json
+# 2. the default bench line                          -> profiles/<tag>_bench.json
+# 3. rocprofv3 --kernel-trace --stats of the same    -> profiles/<tag>_kernel_stats.csv
 # Raw rocprofv3 output goes to gpurun_out/profiles_<tag>/ (scratch).  On the GPU box only gpurun_out/ travels back: run
 #   tools/make_profiles.sh <tag> --summaries-only
 # afterwards in the repo to rebuild profiles/<tag>_* from the raw files that came back.
@@ -12,14 +12,12 @@ tag=${1:?tag}
 export TMPDIR=/tmp
 out=gpurun_out/profiles_$tag
 mkdir -p "$out" profiles
-if [ "$2" != "--summaries-only" ]; then
-python3 bench.py > "$out/bench.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o run --output-format csv -- python3 bench.py --no-cpu-baseline > "$out/trace.log" 2>&1
+summaries_only=$2
+if [ "$summaries_only" != "--summaries-only" ]; then
 tools/pmc.sh "$out/pmc" 1 2 > /dev/null
 tools/pmc.sh "$out/pmc" 10 11 > /dev/null
 fi
-grep '^{' "$out/bench.log" | tail -n 1 > "profiles/${tag}_bench.json"
-cp "$out/trace/run_kernel_stats.csv" "profiles/${tag}_kernel_stats.csv"
+# the counter summaries come first: bench.py quotes the newest profiles/*_pmc_traffic.json in its roofline.traffic
 python3 tools/pmc_report.py "$out/pmc" > "profiles/${tag}_pmc_report.txt"
 python3 - "$tag" <<'EOF'
 import json, re, sys
@@ -37,4 +35,10 @@ for block in re.split(r"\n(?=\S)", txt):
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 print("trace kernel traffic:", out["kernels"].get("rt::traceKernel"))
 EOF
+if [ "$summaries_only" != "--summaries-only" ]; then
+python3 bench.py > "$out/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o run --output-format csv -- python3 bench.py --no-cpu-baseline > "$out/trace.log" 2>&1
+fi
+grep '^{' "$out/bench.log" | tail -n 1 > "profiles/${tag}_bench.json"
+cp "$out/trace/run_kernel_stats.csv" "profiles/${tag}_kernel_stats.csv"
 echo "profiles/${tag}_* written"
