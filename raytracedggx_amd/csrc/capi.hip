@@ -144,7 +144,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < RT_SETS; ++i) {
     RT_HIP(hipMalloc(&c->visDepthBuf[i], n * 8)); RT_HIP(hipMemset(c->visDepthBuf[i], 0, n * 8));
     RT_HIP(hipMalloc(&c->normalBuf[i], n * 4)); RT_HIP(hipMemset(c->normalBuf[i], 0, n * 4));
     RT_HIP(hipMalloc(&c->velocityBuf[i], n * 4)); RT_HIP(hipMemset(c->velocityBuf[i], 0, n * 4));
@@ -170,7 +170,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     const uint32_t tiles = ((width + 15) / 16) * ((height + 15) / 16);
     c->numBinsMax = tiles * 4u;
     if (c->numBinsMax < 64u) c->numBinsMax = 64u;            // room for rtggx_trace_rays batches on tiny frames
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RT_SETS; ++i) {
       RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * 128 * 64));
       RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * 128 * 8));
       RT_HIP(hipMalloc(&c->binCountBuf[i], (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCountBuf[i], 0, (size_t)c->numBinsMax * 4));
@@ -186,7 +186,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   }
   RT_HIP(hipMalloc(&c->sh, 27 * 4)); RT_HIP(hipMemset(c->sh, 0, 27 * 4));
   RT_HIP(hipMalloc(&c->cosSinTab, 512 * 4));
-  RT_HIP(hipMalloc(&c->dParams, 3 * sizeof(FrameParams)));
+  RT_HIP(hipMalloc(&c->dParams, RT_SLOTS * sizeof(FrameParams)));
   RT_HIP(hipMalloc(&c->dScene, sizeof(Scene)));
   {  // cos/sin(2*pi*s/256): double libm, rounded once (RayTracing.hlsl:94,100 with xi.x = s/256, :391)
     float tab[512];
@@ -213,17 +213,17 @@ void rtggx_destroy(rtggx_context* c) {
   hipDeviceSynchronize();
   for (auto& m : c->mesh) { hipFree(m.verts); hipFree(m.indices); hipFree(m.nodes); hipFree(m.nodes4); hipFree(m.tris); }
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->backbuffer);
-  for (int i = 0; i < 2; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
+  for (int i = 0; i < RT_SETS; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
-  for (int i = 0; i < 2; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
+  for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
   hipFree(c->binWork); hipFree(c->splitList);
   hipFree(c->stackOverflow); hipFree(c->dummyRecord);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
-  hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); hipEventDestroy(c->evSetRead[0]); hipEventDestroy(c->evSetRead[1]);
+  hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS);
   delete c;
 }
@@ -281,7 +281,7 @@ int rtggx_build_as(rtggx_context* c) {
 int rtggx_update_frame(rtggx_context* c, const RtggxFrameConstants* k) {
   RT_CHECK_CTX(c);
   if (!k) { setError("rtggx_update_frame: null constants"); return -1; }
-  c->slot = (c->slot + 1) % 3;   // RayTracer::FrameCount
+  c->slot = (c->slot + 1) % RT_SLOTS;   // RayTracer::FrameCount + 1 (rtggx_context.h)
   FrameParams& fp = c->slots[c->slot];
   fp.g = k->global; fp.rg = k->rayGen; fp.po[0] = k->perObject[0]; fp.po[1] = k->perObject[1];
   fp.mat = c->material;
@@ -326,8 +326,13 @@ int rtggx_render_visibility(rtggx_context* c) {
   if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamAS); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
   // Stream B renders into the other input set, so the pass overlaps whatever the main stream still has queued from
   // the previous frame (the sample overlaps its two queues in the same spirit, RayTracedGGX.cpp:302-353).
-  c->selectSet(c->setIndex ^ 1u);
-  if (c->setReadRecorded[c->setIndex]) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
+  c->selectSet((c->setIndex + 1u) % RT_SETS);
+  // the set was last read three frames ago: normally long done; a host that has run further ahead than that waits here
+  static const bool gpuSideWait = getenv("RTGGX_SET_WAIT_ON_GPU") != nullptr;      // the cross-queue wait instead (measurement)
+  if (c->setReadRecorded[c->setIndex]) {
+    if (gpuSideWait) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
+    else if (hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
+  }
   if (c->timing) hipEventRecord(c->tev[2], c->streamAS);
   const int r = launchVisibility(c, c->slots[c->slot], c->streamAS);
   if (c->timing) hipEventRecord(c->tev[13], c->streamAS);

@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
     // G-buffer stores :552-554
     A.normalOut[pix] = packR10G10B10A2(N.x * 0.5f + 0.5f, N.y * 0.5f + 0.5f, N.z * 0.5f + 0.5f, hit ? 1.0f : 0.0f);
     // the reference leaves RoughMetal untouched where nothing is hit, and RayTracingOut1 where no diffuse ray is traced:
-    // with double-buffered targets "untouched" means carrying the previous frame's word over
+    // with several input sets "untouched" means carrying the word of the previous frame.s set over
     A.roughMetalOut[pix] = hit ? (uint16_t)packR8G8(rghMtl.x, rghMtl.y) : A.roughMetalPrev[pix];
     A.velocityOut[pix] = packR16G16F(velocity.x, velocity.y);
 
@@ -441,7 +441,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEv
   const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
   GenArgs G;
   G.visDepth = c->visDepth; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
-  G.roughMetalPrev = c->roughMetalBuf[c->setIndex ^ 1u]; G.diffPrev = c->rtDiffBuf[c->setIndex ^ 1u];
+  G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS]; G.diffPrev = c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
   G.verts0 = c->mesh[0].verts; G.idx0 = c->mesh[0].indices; G.verts1 = c->mesh[1].verts; G.idx1 = c->mesh[1].indices;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
   G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;

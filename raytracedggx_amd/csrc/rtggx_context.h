@@ -60,6 +60,14 @@ struct Scene {
 
 }  // namespace rt
 
+// Input sets (G-buffer, traced images, ray bins): three, used round-robin.  Stream B fills set i while the main stream
+// still consumes the set of the frame before; before stream B is given the work that overwrites a set, the HOST waits
+// for the event of that set's last reader, three frames back -- the frames-in-flight fence of the sample
+// (RayTracedGGX.cpp: FrameCount = 3), and cheaper than a cross-queue wait on the GPU (10 us per frame on stream B's
+// chain).  The frame constants live in a ring of RT_SLOTS device slots: one more than sets, because the tone map of
+// frame f still reads its slot after the event of set f has completed.
+#define RT_SETS 3
+#define RT_SLOTS 4
 struct rtggx_context {
   int device = 0;
   uint32_t W = 0, H = 0;
@@ -67,8 +75,8 @@ struct rtggx_context {
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
   bool attachEvents = true;             // RTGGX_ATTACH_EVENTS=0: record the cross-stream events with hipEventRecord instead
   hipEvent_t evAS = nullptr;      // constants uploaded (stream B -> main)
-  hipEvent_t evRT = nullptr, evSetRead[2] = {nullptr, nullptr};   // ray trace done (stream B -> main); last reader of input set i done (main -> stream B)
-  bool setReadRecorded[2] = {false, false};
+  hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
+  bool setReadRecorded[RT_SETS] = {};
   bool externalStream = false;
 
   rt::MeshDev mesh[2];
@@ -83,12 +91,12 @@ struct rtggx_context {
   unsigned long long* visDepth = nullptr;
   uint32_t *normal = nullptr, *velocity = nullptr, *rtRefl = nullptr, *rtDiff = nullptr, *backbuffer = nullptr;
   uint16_t* roughMetal = nullptr;
-  unsigned long long* visDepthBuf[2] = {nullptr, nullptr};
-  uint32_t *normalBuf[2] = {nullptr, nullptr}, *velocityBuf[2] = {nullptr, nullptr}, *rtReflBuf[2] = {nullptr, nullptr}, *rtDiffBuf[2] = {nullptr, nullptr};
-  uint16_t* roughMetalBuf[2] = {nullptr, nullptr};
+  unsigned long long* visDepthBuf[RT_SETS] = {};
+  uint32_t *normalBuf[RT_SETS] = {}, *velocityBuf[RT_SETS] = {}, *rtReflBuf[RT_SETS] = {}, *rtDiffBuf[RT_SETS] = {};
+  uint16_t* roughMetalBuf[RT_SETS] = {};
   uint32_t setIndex = 0;
-  void *rayQueueBuf[2] = {nullptr, nullptr}, *hitQueueBuf[2] = {nullptr, nullptr};   // ray bins: written on stream B, shaded on the main stream
-  uint32_t* binCountBuf[2] = {nullptr, nullptr};
+  void *rayQueueBuf[RT_SETS] = {}, *hitQueueBuf[RT_SETS] = {};   // ray bins: written on stream B, shaded on the main stream
+  uint32_t* binCountBuf[RT_SETS] = {};
   void selectSet(uint32_t i) {
     setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
@@ -126,7 +134,7 @@ struct rtggx_context {
   unsigned long long* rayCounter = nullptr;   // [0..255] last frame, [256..511] running total
 
   // per-frame constants: ring of RayTracer::FrameCount slots (host side; kernels take them by value)
-  rt::FrameParams slots[3];
+  rt::FrameParams slots[RT_SLOTS];
   uint32_t slot = 0;
   rt::FrameParams* dParams = nullptr;   // device ring, 3 slots; kernels read their constants from here
   rt::Scene* dScene = nullptr;          // device copy of the scene pointers
