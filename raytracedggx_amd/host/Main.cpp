@@ -9,8 +9,8 @@
 
 int main(int argc, char* argv[]) {
   RayTracedGGX app(1280, 720, "DXR Ray-Traced GGX");   // Main.cpp:17
-  app.ParseCommandLineArgs(argv, argc);
   try {
+    app.ParseCommandLineArgs(argv, argc);
     app.OnInit();
     rtggx_context* ctx = app.GetContext();
     const auto t0 = std::chrono::steady_clock::now();

@@ -87,7 +87,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     return (arg[0] == '-' || arg[0] == '/') && lower(arg + 1) == lower(name);
   };
   // On POSIX an absolute path also starts with '/': such a token is a flag only when it names one.
-  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump"};
+  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus"};
   const auto isFlagName = [&](const char* name) { for (const char* f : kFlags) if (lower(name) == f) return true; return false; };
   const auto hasNextArgValue = [&](int i) {
     if (i + 1 >= argc) return false;
@@ -112,6 +112,13 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     else if (isArgMatched(i, "sync")) m_asyncCompute = 0;
     else if (isArgMatched(i, "device")) { if (hasNextArgValue(i)) m_device = std::atoi(argv[++i]); }
     else if (isArgMatched(i, "dump")) { if (hasNextArgValue(i)) m_dumpPrefix = argv[++i]; }
+    else if (isArgMatched(i, "gpus")) {
+      // One process drives one GPU.  Several GPUs = one process per GPU, each rendering a strip of rows and exchanging the
+      // temporal history over RCCL (raytracedggx_amd/strips.py; bench.py under torch.distributed.run): say so, loudly.
+      const int n = hasNextArgValue(i) ? std::atoi(argv[++i]) : 1;
+      if (n != 1) throw std::runtime_error("-gpus " + std::to_string(n) + ": this executable drives one GPU; run one process per GPU: "
+                                           "python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N");
+    }
   }
 }
 

@@ -114,3 +114,10 @@ def test_headless_executable_reports_missing_gpu(built):
     r = subprocess.run([exe, "-mesh", assets.path("triangle.obj"), "-env", assets.path("rnl_cross.dds"), "-width", "64", "-height", "64"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+def test_headless_executable_refuses_gpus_flag_with_instructions(built):
+    """-gpus N: the executable drives one GPU; N > 1 is the per-GPU-process strip path and the flag says so."""
+    exe = os.path.join(ROOT, "raytracedggx_amd", "RayTracedGGX")
+    r = subprocess.run([exe, "-gpus", "8", "-mesh", assets.path("triangle.obj")], capture_output=True, text=True)
+    assert r.returncode == 1 and "one process per GPU" in r.stderr and "bench.py --gpus N" in r.stderr
