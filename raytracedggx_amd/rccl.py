@@ -56,17 +56,27 @@ class Communicator:
 
     def __init__(self, dist, rank, world):
         import torch
-        L = lib()
-        uid = _UniqueId()
-        if rank == 0:
-            _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        if world > 1:
-            t = torch.frombuffer(bytearray(ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES)), dtype=torch.uint8).cuda()
-            dist.broadcast(t, src=0)
-            raw = bytes(t.cpu().numpy().tobytes())
-            ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
         self.rank, self.world = rank, world
         self.handle = ctypes.c_void_p()
+        uid = _UniqueId()
+        ok, why = 1, ""
+        try:
+            L = lib()
+            if rank == 0:
+                _check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        except Exception as e:             # the ranks must still meet in the broadcast below, and all must learn of it
+            ok, why = 0, repr(e)
+        if world > 1:
+            t = torch.frombuffer(bytearray(bytes([ok]) + ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES)), dtype=torch.uint8).cuda()
+            dist.broadcast(t, src=0)
+            raw = t.cpu().numpy().tobytes()
+            flag = torch.tensor([ok and raw[0]], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                raise RuntimeError("direct RCCL exchange unavailable on at least one rank (%s)" % (why or "see the other ranks"))
+            ctypes.memmove(ctypes.byref(uid), raw[1:], NCCL_UNIQUE_ID_BYTES)
+        elif not ok:
+            raise RuntimeError(why)
         _check(L.ncclCommInitRank(ctypes.byref(self.handle), world, uid, rank), "ncclCommInitRank")
 
     def exchange(self, ops, stream):

@@ -112,7 +112,13 @@ class StripRenderer:
         self._comm = None
         if world > 1 and dist is not None and transport is None and os.environ.get("RTGGX_EXCHANGE", "rccl") != "torch":
             from . import rccl
-            self._comm = rccl.Communicator(dist, rank, world)
+            try:
+                self._comm = rccl.Communicator(dist, rank, world)
+            except RuntimeError as e:          # raised on every rank or on none (rccl.Communicator agrees on it first)
+                if rank == 0:
+                    import sys
+                    print("strips: %s -- using torch.distributed's P2P batch instead" % e, file=sys.stderr, flush=True)
+                self._comm = None
 
     def _wrap(self, bid, typestr):
         t = self.torch.as_tensor(_DeviceArray(self.context.buffer_ptr(bid), (self.H, self.W), typestr), device="cuda")
