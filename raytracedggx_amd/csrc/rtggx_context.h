@@ -6,9 +6,9 @@
 //   normal     u32   R10G10B10A2_UNORM      roughMetal u16 R8G8_UNORM     velocity u32 R16G16_FLOAT
 //   rtRefl/rtDiff u32 R11G11B10_FLOAT       tss[2], fltRfl, fltDff u64 R16G16B16A16_FLOAT
 //   backbuffer u32   R8G8B8A8_UNORM
-// visDepth, normal, roughMetal, velocity, rtRefl, rtDiff and the ray bins exist twice ("input sets"): stream B
+// visDepth, normal, roughMetal, velocity, rtRefl, rtDiff and the ray bins exist RT_SETS times ("input sets"): stream B
 // (visibility, ray generation, traversal) fills one set while the main stream (shading, denoise, tone map) still
-// reads the other.
+// reads an earlier one.
 // Scene: per mesh 24-byte vertices, u32 indices, 64-byte binary BVH nodes, their 128-byte 4-wide collapse,
 // 64-byte leaf triangles; environment as RGBA16F mip-major (6 faces per mip); 9 float3 SH coefficients.
 #pragma once
@@ -86,8 +86,8 @@ struct rtggx_context {
 
   // render targets
   // Everything the visibility and ray-tracing passes (stream B) write and the denoiser (main stream) reads exists
-  // twice, so that frame N+1's visibility + ray trace overlap frame N's denoise + tone map.  The unsuffixed pointers
-  // are set `setIndex`, the frame being rendered (toggled by rtggx_render_visibility).
+  // RT_SETS times, so that frame N+1's visibility + ray trace overlap frame N's denoise + tone map.  The unsuffixed
+  // pointers are set `setIndex`, the frame being rendered (advanced by rtggx_render_visibility).
   unsigned long long* visDepth = nullptr;
   uint32_t *normal = nullptr, *velocity = nullptr, *rtRefl = nullptr, *rtDiff = nullptr, *backbuffer = nullptr;
   uint16_t* roughMetal = nullptr;
