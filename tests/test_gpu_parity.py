@@ -452,6 +452,28 @@ def test_adaptive_split_of_expensive_bins_changes_nothing(built):
         a.OnDestroy(); b.OnDestroy()
 
 
+def test_free_running_frames_equal_synchronised_frames(built):
+    """The host may run ahead of the GPU (three input sets, four constant slots, the fence in rtggx_render_visibility;
+    the ray counters and the split-list demand come back asynchronously): 40 frames issued without a single
+    synchronisation against the same 40 frames with a sync after each -- every target bit-identical at the end, at a
+    size where the trace launch uses one wave per bin and the adaptive split (1280x720), and at a thin one (1920x64)."""
+    from raytracedggx_amd import app, capi
+    for size in ((1280, 720), (1920, 64)):
+        args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", size[0], "-height", size[1], "-sharedmem", "-metallic", 1.0, 0.5]
+        a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+        try:
+            for f in range(40):
+                a.OnUpdate(); a.OnRender(); a.context.sync()
+                b.OnUpdate(); b.OnRender()
+            b.context.sync()
+            for bid in (capi.BUF_VISIBILITY, capi.BUF_DEPTH, capi.BUF_NORMAL, capi.BUF_ROUGH_METAL, capi.BUF_VELOCITY, capi.BUF_RT_REFL, capi.BUF_RT_DIFF,
+                        capi.BUF_FLT_RFL, capi.BUF_FLT_DFF, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_BACKBUFFER):
+                np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="%dx%d buffer %d" % (size[0], size[1], bid))
+            assert a.context.ray_count() == b.context.ray_count()
+        finally:
+            a.OnDestroy(); b.OnDestroy()
+
+
 def test_strip_exchange_through_rccl_send_recv(built):
     """The direct RCCL path of the strip exchange (raytracedggx_amd/rccl.py: ncclSend/ncclRecv in one group on the
     renderer's stream, pointers from StripRenderer.raw_ops) on the one GPU of the box: a single-rank communicator whose
