@@ -142,10 +142,13 @@ int  rtggx_set_metallic(rtggx_context* ctx, uint32_t mesh, float metallic);
 /* LBVH build of both bottom-level structures on the context's build stream. */
 int  rtggx_build_as(rtggx_context* ctx);
 
-/* Per-frame constants; copied into the next of RayTracer::FrameCount (=3) slots. */
+/* Per-frame constants; copied into the next slot of a ring of RayTracer::FrameCount + 1 (= 4). */
 int  rtggx_update_frame(rtggx_context* ctx, const RtggxFrameConstants* constants);
 int  rtggx_update_as(rtggx_context* ctx);
 int  rtggx_transform_sh(rtggx_context* ctx);
+/* Starts a frame: advances to the next of RayTracer::FrameCount (= 3) input sets (G-buffer, traced images, ray bins).  All
+ * pass functions only enqueue work; this one is the frames-in-flight fence of the sample (RayTracedGGX.cpp:672-701): it
+ * blocks the calling thread while the frame that last used that set, three frames back, is still being read on the GPU. */
 int  rtggx_render_visibility(rtggx_context* ctx);
 int  rtggx_ray_trace(rtggx_context* ctx);
 int  rtggx_denoise(rtggx_context* ctx, int use_shared_mem);
