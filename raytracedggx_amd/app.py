@@ -14,7 +14,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "libRayTracedGGX.so")
 HOST_EXPORTS = ["rtggx_app_last_error", "rtggx_app_create", "rtggx_app_destroy", "rtggx_app_on_update", "rtggx_app_on_render",
                 "rtggx_app_on_key_up", "rtggx_app_set_time_step", "rtggx_app_context", "rtggx_app_size",
                 "rtggx_app_frame_constants", "rtggx_app_save_image", "rtggx_host_obj_import", "rtggx_host_obj_copy",
-                "rtggx_host_halton", "rtggx_host_frame_constants"]
+                "rtggx_host_halton", "rtggx_host_frame_constants", "rtggx_host_write_png"]
 
 _lib = None
 

@@ -21,7 +21,9 @@ int main(int argc, char* argv[]) {
     std::printf("%u frames %ux%u: %.3f ms/frame, last frame %llu rays\n", app.GetNumFrames(), app.GetWidth(), app.GetHeight(),
                 ms / app.GetNumFrames(), (unsigned long long)rays);
     if (!app.GetDumpPrefix().empty()) {
-      const std::string name = app.GetDumpPrefix() + ".ppm";
+      std::string name = app.GetDumpPrefix();      // "-dump shot.png" / "-dump shot.ppm" as given, a bare prefix gets .ppm
+      const bool hasExt = name.size() >= 4 && (name.compare(name.size() - 4, 4, ".png") == 0 || name.compare(name.size() - 4, 4, ".ppm") == 0);
+      if (!hasExt) name += ".ppm";
       if (app.SaveImage(name.c_str())) std::printf("wrote %s\n", name.c_str());
     }
     app.OnDestroy();

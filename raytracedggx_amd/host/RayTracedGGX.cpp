@@ -1,3 +1,4 @@
+#include <cstring>
 #include "RayTracedGGX.h"
 
 #include <algorithm>
@@ -122,11 +123,60 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
   }
 }
 
+// PNG, the container the sample's screenshot uses (stbi_write_png, RayTracedGGX.cpp:736): 8-bit RGB or RGBA, one IDAT of
+// stored (uncompressed) deflate blocks -- every PNG reader accepts it, and no compression library is needed.
+bool WritePng(const char* fileName, uint32_t w, uint32_t h, uint32_t comp, const uint8_t* pixels) {
+  if ((comp != 3 && comp != 4) || w == 0 || h == 0) return false;
+  static uint32_t crcTable[256];
+  if (!crcTable[1]) for (uint32_t n = 0; n < 256; ++n) { uint32_t c = n; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; crcTable[n] = c; }
+  const auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); };
+  std::vector<uint8_t> file = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+  const auto chunk = [&](const char* type, const std::vector<uint8_t>& data) {
+    be32(file, (uint32_t)data.size());
+    const size_t start = file.size();
+    file.insert(file.end(), type, type + 4); file.insert(file.end(), data.begin(), data.end());
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = start; i < file.size(); ++i) c = crcTable[(c ^ file[i]) & 0xFFu] ^ (c >> 8);
+    be32(file, c ^ 0xFFFFFFFFu);
+  };
+  std::vector<uint8_t> ihdr; be32(ihdr, w); be32(ihdr, h);
+  ihdr.push_back(8); ihdr.push_back(comp == 3 ? 2 : 6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+  chunk("IHDR", ihdr);
+  // raw image: per scanline a filter byte (0 = none) + the pixels
+  const size_t stride = (size_t)w * comp + 1;
+  std::vector<uint8_t> raw(stride * h);
+  for (uint32_t y = 0; y < h; ++y) { raw[y * stride] = 0; std::memcpy(&raw[y * stride + 1], pixels + (size_t)y * w * comp, (size_t)w * comp); }
+  std::vector<uint8_t> z = {0x78, 0x01};      // zlib header, then stored blocks of at most 65535 bytes
+  uint32_t a = 1, b = 0;                       // Adler-32 of the raw data
+  for (size_t pos = 0; pos < raw.size();) {
+    const size_t n = std::min<size_t>(65535, raw.size() - pos);
+    z.push_back(pos + n == raw.size() ? 1 : 0);
+    z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+    for (size_t i = pos; i < pos + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+    pos += n;
+  }
+  be32(z, (b << 16) | a);
+  chunk("IDAT", z);
+  chunk("IEND", {});
+  FILE* f = std::fopen(fileName, "wb");
+  if (!f) return false;
+  const bool ok = std::fwrite(file.data(), 1, file.size(), f) == file.size();
+  std::fclose(f);
+  return ok;
+}
+
 bool RayTracedGGX::SaveImage(const char* fileName) {
   rtggx_context* ctx = GetContext();
   if (!ctx) return false;
   std::vector<uint32_t> px((size_t)m_width * m_height);
   if (rtggx_readback(ctx, RTGGX_BUF_BACKBUFFER, px.data(), px.size() * 4) != 0) { std::fprintf(stderr, "SaveImage: %s\n", rtggx_last_error()); return false; }
+  const std::string name = fileName;
+  if (name.size() >= 4 && name.compare(name.size() - 4, 4, ".png") == 0) {      // RGB, as the sample's screenshot (comp = 3)
+    std::vector<uint8_t> rgb((size_t)m_width * m_height * 3);
+    for (size_t i = 0; i < px.size(); ++i) { rgb[3 * i] = (uint8_t)px[i]; rgb[3 * i + 1] = (uint8_t)(px[i] >> 8); rgb[3 * i + 2] = (uint8_t)(px[i] >> 16); }
+    return WritePng(fileName, m_width, m_height, 3, rgb.data());
+  }
   FILE* f = std::fopen(fileName, "wb");
   if (!f) return false;
   std::fprintf(f, "P6\n%u %u\n255\n", m_width, m_height);

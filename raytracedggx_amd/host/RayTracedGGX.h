@@ -11,6 +11,8 @@
 #include "RayTracer.h"
 #include "XMath.h"
 
+bool WritePng(const char* fileName, uint32_t w, uint32_t h, uint32_t comp, const uint8_t* pixels);   // comp 3 (RGB) or 4 (RGBA), 8 bits
+
 class RayTracedGGX {
  public:
   RayTracedGGX(uint32_t width, uint32_t height, std::string name);
@@ -32,7 +34,7 @@ class RayTracedGGX {
   RayTracer* GetRayTracer() const { return m_rayTracer.get(); }
   rtggx_context* GetContext() const { return m_rayTracer ? m_rayTracer->GetContext() : nullptr; }
   void SetFixedTimeStep(float dt) { m_fixedTimeStep = dt; }
-  bool SaveImage(const char* fileName);   // tone-mapped back buffer as binary PPM (screenshot, RayTracedGGX.cpp:719-739)
+  bool SaveImage(const char* fileName);   // tone-mapped back buffer as PNG (name ends in .png) or binary PPM (screenshot, RayTracedGGX.cpp:719-739)
 
  protected:
   static const uint8_t FrameCount = RayTracer::FrameCount;

@@ -32,6 +32,8 @@ void rtggx_app_size(void* h, uint32_t* w, uint32_t* ht) { *w = ((RayTracedGGX*)h
 void rtggx_app_frame_constants(void* h, void* out768) { std::memcpy(out768, &((RayTracedGGX*)h)->GetRayTracer()->GetFrameConstants(), sizeof(RtggxFrameConstants)); }
 int rtggx_app_save_image(void* h, const char* path) { return ((RayTracedGGX*)h)->SaveImage(path) ? 0 : -1; }
 
+int rtggx_host_write_png(const char* path, uint32_t w, uint32_t h, uint32_t comp, const uint8_t* pixels) { return WritePng(path, w, h, comp, pixels) ? 0 : -1; }
+
 // Host-only pieces, usable without a GPU: the OBJ importer and the Halton sequence.
 static ObjLoader g_obj;
 int rtggx_host_obj_import(const char* path, uint32_t* numVerts, uint32_t* numIndices, float* aabb6) {

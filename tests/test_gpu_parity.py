@@ -2,6 +2,8 @@
 inputs.  Bar (BASELINE.json north_star): integer visibility / G-buffer words bit-exact; denoised HDR
 within 1e-3 relative L2.  The tolerance exists because exp/exp2/log2/pow come from libm on the CPU and
 from the device math library on the GPU; everything else is the same fp32 arithmetic, unfused."""
+import os
+
 import numpy as np
 import pytest
 
@@ -522,6 +524,28 @@ def test_strip_exchange_through_rccl_send_recv(built):
         full.close()
         for s in strips:
             s.close()
+
+
+def test_frame_dump_png_and_ppm_equal_the_back_buffer(built, tmp_path):
+    """RayTracedGGX::SaveImage (the sample's screenshot, RayTracedGGX.cpp:719-739): PNG and PPM dumps hold the back buffer."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import imgdiff
+    from raytracedggx_amd import app, capi
+    a = app.RayTracedGGX(["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 333, "-height", 217])
+    try:
+        for _ in range(2):
+            a.OnUpdate(); a.OnRender()
+        a.context.sync()
+        bb = a.context.readback(capi.BUF_BACKBUFFER)
+        want = np.stack([bb & 255, (bb >> 8) & 255, (bb >> 16) & 255], axis=-1).astype(np.uint8)
+        assert want.std() > 10                        # a picture, not a constant
+        for ext in ("png", "ppm"):
+            path = str(tmp_path / ("shot." + ext))
+            assert a.save_image(path)
+            np.testing.assert_array_equal(imgdiff.load(path), want)
+    finally:
+        a.OnDestroy()
 
 
 def test_c_abi_error_behaviour(built):

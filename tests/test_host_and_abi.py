@@ -121,3 +121,42 @@ def test_headless_executable_refuses_gpus_flag_with_instructions(built):
     exe = os.path.join(ROOT, "raytracedggx_amd", "RayTracedGGX")
     r = subprocess.run([exe, "-gpus", "8", "-mesh", assets.path("triangle.obj")], capture_output=True, text=True)
     assert r.returncode == 1 and "one process per GPU" in r.stderr and "bench.py --gpus N" in r.stderr
+
+
+def test_png_writer_and_image_diff_tool(built, tmp_path):
+    """the host's PNG writer (the sample's screenshot container) read back by tools/imgdiff.py's own
+    reader, byte for byte; the reader against PNGs with real scanline filters; the tool's verdicts and exit codes."""
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import imgdiff
+    L = ctypes.CDLL(os.path.join(ROOT, "raytracedggx_amd", "libRayTracedGGX.so"))
+    rng = np.random.default_rng(3)
+    for w, h, c in ((7, 5, 3), (300, 250, 4), (1, 1, 3), (256, 257, 3)):          # 300x250x4 needs several stored deflate blocks
+        a = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        path = str(tmp_path / ("w%d.png" % w))
+        assert L.rtggx_host_write_png(path.encode(), w, h, c, a.ctypes.data_as(ctypes.c_void_p)) == 0
+        np.testing.assert_array_equal(imgdiff.load(path), a)
+    assert L.rtggx_host_write_png(str(tmp_path / "bad.png").encode(), 4, 4, 2, None) != 0
+    # filters 1-4: zlib-compressed PNGs from another encoder, when one is importable
+    yy, xx = np.mgrid[0:97, 0:131]
+    smooth = np.stack([(xx * 2) % 256, (yy * 3 + xx) % 256, ((xx * yy) // 7) % 256], axis=-1).astype(np.uint8)
+    try:
+        from PIL import Image
+        Image.fromarray(smooth).save(str(tmp_path / "pil.png"))
+        np.testing.assert_array_equal(imgdiff.load(str(tmp_path / "pil.png")), smooth)
+    except ImportError:
+        pass
+    imgdiff.save_png(str(tmp_path / "a.png"), smooth)
+    np.testing.assert_array_equal(imgdiff.load(str(tmp_path / "a.png")), smooth)
+    b = smooth.copy(); b[10, 20, 1] ^= 1
+    open(str(tmp_path / "b.ppm"), "wb").write(b"P6\n# comment\n131 97\n255\n" + b.tobytes())
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "imgdiff.py")] + list(a), capture_output=True, text=True)
+    r = run(str(tmp_path / "a.png"), str(tmp_path / "b.ppm"), "--out", str(tmp_path / "d.png"))
+    assert r.returncode == 0 and "max difference 1 codes" in r.stdout
+    assert imgdiff.load(str(tmp_path / "d.png"))[10, 20, 1] == 255
+    b[0, 0, 0] = (int(b[0, 0, 0]) + 9) % 256
+    imgdiff.save_png(str(tmp_path / "c.png"), b)
+    assert run(str(tmp_path / "a.png"), str(tmp_path / "c.png")).returncode == 1
+    imgdiff.save_png(str(tmp_path / "e.png"), b[:50])
+    assert run(str(tmp_path / "a.png"), str(tmp_path / "e.png")).returncode == 2
