@@ -76,7 +76,7 @@ typedef struct RtggxFrameConstants {      /* 768 bytes */
 } RtggxFrameConstants;
 
 /* Environment texel formats accepted by rtggx_set_env (DXGI numbering). */
-enum { RTGGX_FORMAT_RGBA32F = 2, RTGGX_FORMAT_RGBA16F = 10, RTGGX_FORMAT_BC6H_UF16 = 95 };
+enum { RTGGX_FORMAT_RGBA32F = 2, RTGGX_FORMAT_RGBA16F = 10, RTGGX_FORMAT_BC6H_UF16 = 95, RTGGX_FORMAT_BC6H_SF16 = 96 };
 
 /* Buffers readable with rtggx_readback (one element per pixel unless noted). */
 enum {

@@ -84,10 +84,10 @@ def obj_import(path):
     return verts, idx, aabb
 
 
-def bc6h_decode_block(block16):
+def bc6h_decode_block(block16, signed=False):
     out = np.zeros((16, 3), np.uint16)
     b = np.frombuffer(bytes(block16), np.uint8).copy()
-    lib().orc_bc6h_decode_block(_fp(b), _fp(out))
+    (lib().orc_bc6h_decode_block_sf16 if signed else lib().orc_bc6h_decode_block)(_fp(b), _fp(out))
     return out
 
 

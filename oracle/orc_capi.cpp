@@ -92,6 +92,7 @@ void orc_env_copy(void* h, uint16_t* out) {   // mip-major, 6 faces per mip
   for (auto& l : e.level) { std::memcpy(out + off, l.data(), l.size() * 2); off += l.size(); }
 }
 void orc_bc6h_decode_block(const uint8_t* block16, uint16_t* outRgb48) { bc6h::decodeBlock(block16, (uint16_t(*)[3])outRgb48); }
+void orc_bc6h_decode_block_sf16(const uint8_t* block16, uint16_t* outRgb48) { bc6h::decodeBlock(block16, (uint16_t(*)[3])outRgb48, true); }
 
 // ---- acceleration structure ------------------------------------------------------------------------
 void orc_build_as(void* h) { Ctx* c = (Ctx*)h; for (int i = 0; i < 2; ++i) build_bvh(c->mesh[i]); }

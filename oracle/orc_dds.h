@@ -4,7 +4,7 @@
 // in texture hardware, so neither is in the reference tree: "parity unpinned" (SURVEY.md 8c).
 // BC6H is a public bit-exact format; this is a restatement of its published decode procedure
 // (Direct3D 11 "BC6H format" documentation / Khronos Data Format Specification, BPTC float):
-// 14 modes, 1 or 2 regions, 32 two-region partitions, unsigned unquantisation,
+// 14 modes, 1 or 2 regions, 32 two-region partitions, unsigned (UF16) and signed (SF16) unquantisation,
 // 6-bit interpolation weights, final * 31/64 scaling to a binary16 bit pattern.
 #pragma once
 #include <cstdint>
@@ -85,8 +85,20 @@ static inline int unquantize(int c, int bits) {
   return ((c << 16) + 0x8000) >> bits;
 }
 
+// BC6H_SF16 ("BC6H format", signed): endpoints are two's-complement numbers of wbits bits; magnitudes unquantise to 15 bits
+static inline int unquantizeSigned(int c, int bits) {
+  if (bits >= 16) return c;
+  const bool neg = c < 0;
+  if (neg) c = -c;
+  int u;
+  if (c == 0) u = 0;
+  else if (c >= (1 << (bits - 1)) - 1) u = 0x7FFF;
+  else u = ((c << 15) + 0x4000) >> (bits - 1);
+  return neg ? -u : u;
+}
+
 // Decode one 16-byte block into 16 texels x 3 binary16 bit patterns (row-major 4x4).
-static inline void decodeBlock(const uint8_t* blk, uint16_t out[16][3]) {
+static inline void decodeBlock(const uint8_t* blk, uint16_t out[16][3], bool isSigned = false) {
   int modeBits = blk[0] & 3;
   if (modeBits >= 2) modeBits = blk[0] & 31;
   const Mode* md = nullptr;
@@ -107,8 +119,10 @@ static inline void decodeBlock(const uint8_t* blk, uint16_t out[16][3]) {
       e[1][0][c] = (w + signExtend(y, delta[c])) & mask;
       e[1][1][c] = (w + signExtend(z, delta[c])) & mask;
     } else { e[0][1][c] = x; e[1][0][c] = y; e[1][1][c] = z; }
+    if (isSigned) for (int r = 0; r < 2; ++r) for (int k = 0; k < 2; ++k) e[r][k][c] = signExtend(e[r][k][c] & ((1 << md->wbits) - 1), md->wbits);
   }
-  for (int r = 0; r < 2; ++r) for (int k = 0; k < 2; ++k) for (int c = 0; c < 3; ++c) e[r][k][c] = unquantize(e[r][k][c], md->wbits);
+  for (int r = 0; r < 2; ++r) for (int k = 0; k < 2; ++k) for (int c = 0; c < 3; ++c)
+    e[r][k][c] = isSigned ? unquantizeSigned(e[r][k][c], md->wbits) : unquantize(e[r][k][c], md->wbits);
   const int part = md->regions == 2 ? fld[D] : 0;
   const int ibits = md->regions == 2 ? 3 : 4;
   int pos = md->regions == 2 ? 82 : 65;
@@ -122,7 +136,8 @@ static inline void decodeBlock(const uint8_t* blk, uint16_t out[16][3]) {
     const int w = ibits == 3 ? kW3[idx] : kW4[idx];
     for (int c = 0; c < 3; ++c) {
       const int v = (e[region][0][c] * (64 - w) + e[region][1][c] * w + 32) >> 6;
-      out[i][c] = (uint16_t)((v * 31) >> 6);
+      if (!isSigned) out[i][c] = (uint16_t)((v * 31) >> 6);
+      else { const int m = v < 0 ? ((-v) * 31) >> 5 : (v * 31) >> 5; out[i][c] = (uint16_t)(v < 0 ? (0x8000 | m) : m); }
     }
   }
 }
@@ -135,11 +150,11 @@ struct EnvMap {
 };
 
 // Decode a BC6H_UF16 mip (w x h texels, ceil(w/4) x ceil(h/4) blocks) to RGBA16F.
-static inline void bc6h_decode_image(const uint8_t* blocks, uint32_t w, uint32_t h, uint16_t* rgba) {
+static inline void bc6h_decode_image(const uint8_t* blocks, uint32_t w, uint32_t h, uint16_t* rgba, bool isSigned = false) {
   const uint32_t bw = (w + 3) / 4, bh = (h + 3) / 4;
   for (uint32_t by = 0; by < bh; ++by) for (uint32_t bx = 0; bx < bw; ++bx) {
     uint16_t px[16][3];
-    bc6h::decodeBlock(blocks + 16 * ((size_t)by * bw + bx), px);
+    bc6h::decodeBlock(blocks + 16 * ((size_t)by * bw + bx), px, isSigned);
     for (uint32_t y = 0; y < 4; ++y) for (uint32_t x = 0; x < 4; ++x) {
       const uint32_t X = bx * 4 + x, Y = by * 4 + y;
       if (X >= w || Y >= h) continue;
@@ -178,7 +193,7 @@ static inline bool dds_load_cube(const char* path, EnvMap& env, char* err, size_
     std::vector<uint16_t>& img = env.level[(size_t)m * 6 + face];
     img.resize((size_t)s * s * 4);
     size_t bytes;
-    if (dxgi == 95) { bytes = (size_t)((s + 3) / 4) * ((s + 3) / 4) * 16; if (off + bytes > d.size()) { snprintf(err, errLen, "truncated"); return false; } bc6h_decode_image(&d[off], s, s, img.data()); }
+    if (dxgi == 95 || dxgi == 96) { bytes = (size_t)((s + 3) / 4) * ((s + 3) / 4) * 16; if (off + bytes > d.size()) { snprintf(err, errLen, "truncated"); return false; } bc6h_decode_image(&d[off], s, s, img.data(), dxgi == 96); }
     else if (dxgi == 10) { bytes = (size_t)s * s * 8; if (off + bytes > d.size()) { snprintf(err, errLen, "truncated"); return false; } std::memcpy(img.data(), &d[off], bytes); }
     else if (dxgi == 2) { bytes = (size_t)s * s * 16; if (off + bytes > d.size()) { snprintf(err, errLen, "truncated"); return false; }
       for (size_t i = 0; i < (size_t)s * s * 4; ++i) { float v; std::memcpy(&v, &d[off + 4 * i], 4); img[i] = f32_to_f16(v); } }

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librtggx.so")
 BUF_VISIBILITY, BUF_DEPTH, BUF_NORMAL, BUF_ROUGH_METAL, BUF_VELOCITY, BUF_RT_REFL, BUF_RT_DIFF, BUF_TSS0, BUF_TSS1, \
     BUF_FLT_RFL, BUF_FLT_DFF, BUF_BACKBUFFER, BUF_SH_COEFFS, BUF_BVH_NODES0, BUF_BVH_TRIS0, BUF_BVH_NODES1, BUF_BVH_TRIS1, \
     BUF_TLAS, BUF_ENV, BUF_BVH4_NODES0, BUF_BVH4_NODES1 = range(21)
-FORMAT_RGBA32F, FORMAT_RGBA16F, FORMAT_BC6H_UF16 = 2, 10, 95
+FORMAT_RGBA32F, FORMAT_RGBA16F, FORMAT_BC6H_UF16, FORMAT_BC6H_SF16 = 2, 10, 95, 96
 
 _BUF_DTYPE = {BUF_VISIBILITY: np.uint32, BUF_DEPTH: np.uint32, BUF_NORMAL: np.uint32, BUF_ROUGH_METAL: np.uint16,
               BUF_VELOCITY: np.uint32, BUF_RT_REFL: np.uint32, BUF_RT_DIFF: np.uint32, BUF_TSS0: np.uint64, BUF_TSS1: np.uint64,

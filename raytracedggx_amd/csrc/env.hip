@@ -4,7 +4,7 @@
 //
 // D3D samples BC6H in texture hardware; CDNA4 has no BC6H unit, so the blocks are decoded once
 // into an RGBA16F mip pyramid (mip-major, six faces per mip) that the trace kernel filters by
-// hand.  BC6H_UF16 decode follows the published format (Direct3D 11 "BC6H format" / Khronos Data
+// hand.  BC6H_UF16 / BC6H_SF16 decode follows the published format (Direct3D 11 "BC6H format" / Khronos Data
 // Format Specification, BPTC float): one lane per 4x4 block.
 // SH projection: one lane per mip-0 texel, solid-angle weighted, real orthonormal basis in the
 // consumer's axis convention (SHIrradianceTypeless.hlsli:23-25: x=-n.x, y=-n.y, z=n.z),
@@ -84,9 +84,22 @@ RT_DEV int unquantizeU(int c, int bits) {
   return ((c << 16) + 0x8000) >> bits;
 }
 
+// BC6H_SF16: endpoints are two's-complement numbers of wbits bits; magnitudes unquantise to 15 bits, the sign is carried
+RT_DEV int signExtendBits(int v, int bits) { const int m = 1 << (bits - 1); return ((v & ((1 << bits) - 1)) ^ m) - m; }
+RT_DEV int unquantizeS(int c, int bits) {
+  if (bits >= 16) return c;
+  const bool neg = c < 0;
+  if (neg) c = -c;
+  int u;
+  if (c == 0) u = 0;
+  else if (c >= (1 << (bits - 1)) - 1) u = 0x7FFF;
+  else u = ((c << 15) + 0x4000) >> (bits - 1);
+  return neg ? -u : u;
+}
+
 // One lane decodes one block of one mip of one face and writes up to 16 RGBA16F texels.
 __global__ void bc6hDecodeKernel(const uint32_t* __restrict__ blocks, const Bc6Mode* __restrict__ modes, uint2* __restrict__ dst,
-                                 uint32_t size, uint32_t blocksPerRow, uint32_t numBlocks) {
+                                 uint32_t size, uint32_t blocksPerRow, uint32_t numBlocks, int isSigned) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= numBlocks) return;
   uint32_t blk[4];
@@ -113,8 +126,10 @@ __global__ void bc6hDecodeKernel(const uint32_t* __restrict__ blocks, const Bc6M
         e[1][0][c] = (w + ((y ^ sb) - sb)) & mask;
         e[1][1][c] = (w + ((z ^ sb) - sb)) & mask;
       } else { e[0][1][c] = x; e[1][0][c] = y; e[1][1][c] = z; }
+      if (isSigned) for (int r = 0; r < 2; ++r) for (int k = 0; k < 2; ++k) e[r][k][c] = signExtendBits(e[r][k][c], md.wbits);
     }
-    for (int r = 0; r < 2; ++r) for (int k = 0; k < 2; ++k) for (int c = 0; c < 3; ++c) e[r][k][c] = unquantizeU(e[r][k][c], md.wbits);
+    for (int r = 0; r < 2; ++r) for (int k = 0; k < 2; ++k) for (int c = 0; c < 3; ++c)
+      e[r][k][c] = isSigned ? unquantizeS(e[r][k][c], md.wbits) : unquantizeU(e[r][k][c], md.wbits);
     const int part = md.regions == 2 ? fld[1] : 0;
     const int ibits = md.regions == 2 ? 3 : 4;
     int pos = md.regions == 2 ? 82 : 65;
@@ -128,7 +143,8 @@ __global__ void bc6hDecodeKernel(const uint32_t* __restrict__ blocks, const Bc6M
       const int wgt = ibits == 3 ? kWeight3[idx] : kWeight4[idx];
       for (int c = 0; c < 3; ++c) {
         const int v = (e[region][0][c] * (64 - wgt) + e[region][1][c] * wgt + 32) >> 6;
-        px[i][c] = (uint16_t)((v * 31) >> 6);
+        if (!isSigned) px[i][c] = (uint16_t)((v * 31) >> 6);
+        else { const int m = v < 0 ? ((-v) * 31) >> 5 : (v * 31) >> 5; px[i][c] = (uint16_t)(v < 0 ? (0x8000 | m) : m); }
       }
     }
   }
@@ -149,11 +165,11 @@ int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const 
   size_t perFace = 0; uint64_t texels = 0;
   for (uint32_t m = 0; m < mips; ++m) {
     const uint32_t sz = size >> m;
-    perFace += format == RTGGX_FORMAT_BC6H_UF16 ? (size_t)((sz + 3) / 4) * ((sz + 3) / 4) * 16 : (size_t)sz * sz * (format == RTGGX_FORMAT_RGBA16F ? 8 : 16);
+    perFace += (format == RTGGX_FORMAT_BC6H_UF16 || format == RTGGX_FORMAT_BC6H_SF16) ? (size_t)((sz + 3) / 4) * ((sz + 3) / 4) * 16 : (size_t)sz * sz * (format == RTGGX_FORMAT_RGBA16F ? 8 : 16);
     c->env.mipOffset[m] = (uint32_t)texels;
     texels += 6ull * sz * sz;
   }
-  if (format != RTGGX_FORMAT_BC6H_UF16 && format != RTGGX_FORMAT_RGBA16F && format != RTGGX_FORMAT_RGBA32F) { setError("rtggx_set_env: unsupported format %d", format); return -1; }
+  if (format != RTGGX_FORMAT_BC6H_UF16 && format != RTGGX_FORMAT_BC6H_SF16 && format != RTGGX_FORMAT_RGBA16F && format != RTGGX_FORMAT_RGBA32F) { setError("rtggx_set_env: unsupported format %d", format); return -1; }
   if (bytes < perFace * 6) { setError("rtggx_set_env: %zu bytes given, %zu needed", bytes, perFace * 6); return -1; }
   if (c->env.texels) { RT_HIP(hipFree(c->env.texels)); c->env.texels = nullptr; }
   RT_HIP(hipMalloc(&c->env.texels, texels * sizeof(uint2)));
@@ -162,7 +178,8 @@ int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const 
   RT_HIP(hipMalloc(&dSrc, perFace * 6));
   RT_HIP(hipMemcpyAsync(dSrc, hostData, perFace * 6, hipMemcpyHostToDevice, s));
   Bc6Mode* dModes = nullptr;
-  if (format == RTGGX_FORMAT_BC6H_UF16) {
+  const bool bc6h = format == RTGGX_FORMAT_BC6H_UF16 || format == RTGGX_FORMAT_BC6H_SF16;
+  if (bc6h) {
     std::vector<Bc6Mode> modes; buildModeTable(modes);
     RT_HIP(hipMalloc(&dModes, sizeof(Bc6Mode) * 14));
     RT_HIP(hipMemcpyAsync(dModes, modes.data(), sizeof(Bc6Mode) * 14, hipMemcpyHostToDevice, s));
@@ -173,9 +190,9 @@ int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const 
     for (uint32_t m = 0; m < mips; ++m) {
       const uint32_t sz = size >> m;
       uint2* dst = c->env.texels + c->env.mipOffset[m] + (size_t)face * sz * sz;
-      if (format == RTGGX_FORMAT_BC6H_UF16) {
+      if (bc6h) {
         const uint32_t bpr = (sz + 3) / 4, nb = bpr * bpr;
-        hipLaunchKernelGGL(bc6hDecodeKernel, dim3((nb + 63) / 64), dim3(64), 0, s, (const uint32_t*)((const char*)dSrc + off), dModes, dst, sz, bpr, nb);
+        hipLaunchKernelGGL(bc6hDecodeKernel, dim3((nb + 63) / 64), dim3(64), 0, s, (const uint32_t*)((const char*)dSrc + off), dModes, dst, sz, bpr, nb, format == RTGGX_FORMAT_BC6H_SF16 ? 1 : 0);
         off += (size_t)nb * 16;
       } else if (format == RTGGX_FORMAT_RGBA16F) {
         RT_HIP(hipMemcpyAsync(dst, (const char*)dSrc + off, (size_t)sz * sz * 8, hipMemcpyDeviceToDevice, s));

@@ -1,6 +1,6 @@
 // DDS container parse for cube maps: the host half of DDS::Loader::CreateTextureFromFile as used at
 // RayTracedGGX/Content/RayTracer.cpp:143-150 (maxsize 8192, forceSRGB=false).  Only the container
-// is read here; the texel payload (BC6H_UF16 blocks, RGBA16F or RGBA32F) is handed to
+// is read here; the texel payload (BC6H_UF16 / BC6H_SF16 blocks, RGBA16F or RGBA32F) is handed to
 // rtggx_set_env() untouched and decoded on the device.
 #pragma once
 #include <cstdint>
@@ -12,7 +12,7 @@
 namespace DDS {
 
 struct CubeImage {
-  int format = 0;            // DXGI_FORMAT number: 95 BC6H_UF16, 10 R16G16B16A16_FLOAT, 2 R32G32B32A32_FLOAT
+  int format = 0;            // DXGI_FORMAT number: 95 BC6H_UF16, 96 BC6H_SF16, 10 R16G16B16A16_FLOAT, 2 R32G32B32A32_FLOAT
   uint32_t size = 0, mips = 0;
   std::vector<uint8_t> payload;   // face-major, full mip chain per face (+X -X +Y -Y +Z -Z)
 };
@@ -41,11 +41,11 @@ class Loader {
     else { error = "unsupported DDS pixel format"; return false; }
     if (!cube || width != height) { error = "not a cube map"; return false; }
     if (width > 8192) { error = "cube map larger than 8192"; return false; }
-    if (format != 95 && format != 10 && format != 2) { error = "unsupported DXGI format " + std::to_string(format); return false; }
+    if (format != 95 && format != 96 && format != 10 && format != 2) { error = "unsupported DXGI format " + std::to_string(format); return false; }
     size_t perFace = 0;
     for (uint32_t m = 0; m < mips; ++m) {
       const uint32_t s = (width >> m) ? (width >> m) : 1;
-      perFace += format == 95 ? (size_t)((s + 3) / 4) * ((s + 3) / 4) * 16 : (size_t)s * s * (format == 10 ? 8 : 16);
+      perFace += (format == 95 || format == 96) ? (size_t)((s + 3) / 4) * ((s + 3) / 4) * 16 : (size_t)s * s * (format == 10 ? 8 : 16);
     }
     if (d.size() < offset + perFace * 6) { error = "truncated payload"; return false; }
     out.format = format; out.size = width; out.mips = mips;

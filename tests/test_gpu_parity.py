@@ -600,6 +600,21 @@ def test_environment_upload_formats(built):
         np.testing.assert_array_equal(ctx.readback(capi.BUF_ENV), want)
         ctx.set_env(capi.FORMAT_RGBA16F, size, mips, dds32.astype(np.float16))
         np.testing.assert_array_equal(ctx.readback(capi.BUF_ENV), want)
+        # BC6H, unsigned and signed: random blocks (every mode id, reserved ones included) against the oracle's decoder
+        size, mips = 8, 2                                          # 2x2 blocks + 1 block per face
+        blocks = rng.integers(0, 256, (6, 5, 16), dtype=np.uint8)   # per face: its mip chain, 4 + 1 blocks
+        for fmt, signed in ((capi.FORMAT_BC6H_UF16, False), (capi.FORMAT_BC6H_SF16, True)):
+            ctx.set_env(fmt, size, mips, blocks.reshape(-1))
+            got = ctx.readback(capi.BUF_ENV).reshape(-1, 4)
+            want = np.zeros((6 * 64 + 6 * 16, 4), np.uint16); want[:, 3] = 0x3C00
+            for f in range(6):
+                for b in range(4):
+                    px = O.bc6h_decode_block(blocks[f, b].tobytes(), signed=signed).reshape(4, 4, 3)
+                    face = want[f * 64:(f + 1) * 64].reshape(8, 8, 4)
+                    face[(b // 2) * 4:(b // 2) * 4 + 4, (b % 2) * 4:(b % 2) * 4 + 4, :3] = px
+                want[6 * 64 + f * 16:6 * 64 + (f + 1) * 16, :3] = O.bc6h_decode_block(blocks[f, 4].tobytes(), signed=signed)
+            np.testing.assert_array_equal(got, want, err_msg="BC6H %s" % ("SF16" if signed else "UF16"))
+        size, mips = 4, 3
         with pytest.raises(capi.RtggxError):
             ctx.set_env(capi.FORMAT_RGBA32F, size, mips, dds32[:-4])
         with pytest.raises(capi.RtggxError, match="unsupported format"):

@@ -157,6 +157,44 @@ def test_bc6h_hand_assembled_blocks(built):
         assert out[5, c] == (unq11((base[c] + delta[c]) & 0x7FF) * 31) >> 6  # index 15 -> second endpoint
 
 
+def test_bc6h_signed_hand_assembled_blocks(built):
+    """BC6H_SF16: endpoints are two's-complement, magnitudes unquantise to 15 bits, the half carries the
+    sign -- restated here from the format description, independently of the decoder, for the untransformed mode 11 and
+    the transformed mode 12."""
+    def sx(v, bits):
+        v &= (1 << bits) - 1
+        return v - (1 << bits) if v >> (bits - 1) else v
+    def unq(c, bits):
+        neg, c = c < 0, abs(c)
+        u = 0 if c == 0 else (0x7FFF if c >= (1 << (bits - 1)) - 1 else ((c << 15) + 0x4000) >> (bits - 1))
+        return -u if neg else u
+    def fin(v):
+        return (0x8000 | (((-v) * 31) >> 5)) if v < 0 else (v * 31) >> 5
+    w4 = [0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64]
+    e0, e1 = (-100, 200, -512), (511, -511, 0)          # 10-bit two's complement, extremes included
+    idx = [3, 0, 15, 7, 1, 2, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14]
+    fields = [(0x03, 5)] + [(c, 10) for c in e0] + [(c, 10) for c in e1] + [(idx[0], 3)] + [(i, 4) for i in idx[1:]]
+    out = O.bc6h_decode_block(_bc6h_block(fields), signed=True)
+    for t in range(16):
+        for c in range(3):
+            a, b = unq(e0[c], 10), unq(e1[c], 10)
+            v = (a * (64 - w4[idx[t]]) + b * w4[idx[t]] + 32) >> 6
+            assert out[t, c] == fin(v), (t, c)
+    assert out[1, 0] == fin(unq(-100, 10)) and out[1, 0] & 0x8000        # index 0: the first endpoint, negative
+    # Mode 12 (0x07): 11-bit base (two's complement), 9-bit signed deltas, the sum wraps in 11 bits
+    base, delta = (-700, 0x155, 1023), (-5, 17, 255)
+    fields = [(0x07, 5)] + [(b & 0x3FF, 10) for b in base]
+    for b, d in zip(base, delta):
+        fields += [(d & 0x1FF, 9), ((b >> 10) & 1, 1)]
+    fields += [(0, 3)] + [(15, 4)] * 15
+    out = O.bc6h_decode_block(_bc6h_block(fields), signed=True)
+    for c in range(3):
+        assert out[0, c] == fin(unq(sx(base[c], 11), 11))
+        assert out[5, c] == fin(unq(sx(base[c] + delta[c], 11), 11))      # 1023 + 255 wraps to a negative endpoint
+    # the same block read as unsigned differs: the flag matters
+    assert not np.array_equal(out, O.bc6h_decode_block(_bc6h_block(fields)))
+
+
 def test_bc6h_mip_chain_is_consistent(built):
     # every used mode decodes sensibly: each mip is close to the 2x2 box filter of the previous one
     o = O.Oracle(8, 8, threads=1)
