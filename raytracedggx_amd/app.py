@@ -14,7 +14,8 @@ HOST_LIB_PATH = os.path.join(_HERE, "libRayTracedGGX.so")
 HOST_EXPORTS = ["rtggx_app_last_error", "rtggx_app_create", "rtggx_app_destroy", "rtggx_app_on_update", "rtggx_app_on_render",
                 "rtggx_app_on_key_up", "rtggx_app_set_time_step", "rtggx_app_context", "rtggx_app_size",
                 "rtggx_app_frame_constants", "rtggx_app_save_image", "rtggx_host_obj_import", "rtggx_host_obj_copy",
-                "rtggx_host_halton", "rtggx_host_frame_constants", "rtggx_host_write_png"]
+                "rtggx_host_halton", "rtggx_host_frame_constants", "rtggx_host_write_png", "rtggx_host_camera",
+                "rtggx_app_on_lbutton_down", "rtggx_app_on_lbutton_up", "rtggx_app_on_mouse_move", "rtggx_app_on_mouse_wheel", "rtggx_app_load_track"]
 
 _lib = None
 
@@ -43,6 +44,15 @@ def load():
         L.rtggx_host_obj_copy.argtypes = [C.c_void_p, C.c_void_p]
         L.rtggx_host_halton.argtypes = [C.c_uint32, C.c_void_p]
         L.rtggx_host_frame_constants.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p]
+        for n in ("rtggx_app_on_lbutton_down", "rtggx_app_on_lbutton_up", "rtggx_app_on_mouse_move"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_float, C.c_float]
+            getattr(L, n).restype = None
+        L.rtggx_app_on_mouse_wheel.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.rtggx_app_on_mouse_wheel.restype = None
+        L.rtggx_app_load_track.argtypes = [C.c_void_p, C.c_char_p]
+        L.rtggx_host_camera.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rtggx_host_camera.restype = None
+        L.rtggx_host_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -58,6 +68,15 @@ def obj_import(path):
     i = np.zeros(ni.value, np.uint32)
     L.rtggx_host_obj_copy(v.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p))
     return v, i, aabb
+
+
+def camera(width, height, events):
+    """The camera handlers on their own: events = [(type, a, b)], type 1 down, 2 up, 3 move, 4 wheel -> (eye[3], view[4, 4])."""
+    ev = np.ascontiguousarray(np.asarray(events, np.float32).reshape(-1, 3))
+    eye, view = np.zeros(3, np.float32), np.zeros((4, 4), np.float32)
+    load().rtggx_host_camera(C.c_uint32(width), C.c_uint32(height), ev.ctypes.data_as(C.c_void_p), C.c_uint32(len(ev)),
+                             eye.ctypes.data_as(C.c_void_p), view.ctypes.data_as(C.c_void_p))
+    return eye, view
 
 
 def halton(n):
@@ -110,6 +129,22 @@ class RayTracedGGX:
 
     def OnKeyUp(self, key):
         self.L.rtggx_app_on_key_up(self.h, int(key))
+
+    # the sample's camera interactions (RayTracedGGX.cpp:400-455), positions in pixels
+    def OnLButtonDown(self, x, y):
+        self.L.rtggx_app_on_lbutton_down(self.h, x, y)
+
+    def OnLButtonUp(self, x, y):
+        self.L.rtggx_app_on_lbutton_up(self.h, x, y)
+
+    def OnMouseMove(self, x, y):
+        self.L.rtggx_app_on_mouse_move(self.h, x, y)
+
+    def OnMouseWheel(self, dz, x=0.0, y=0.0):
+        self.L.rtggx_app_on_mouse_wheel(self.h, dz, x, y)
+
+    def load_track(self, path):
+        return self.L.rtggx_app_load_track(self.h, path.encode()) == 0
 
     def set_time_step(self, dt):
         self.L.rtggx_app_set_time_step(self.h, dt)

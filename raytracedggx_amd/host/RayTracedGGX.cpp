@@ -1,3 +1,4 @@
+#include <cmath>
 #include <cstring>
 #include "RayTracedGGX.h"
 
@@ -31,17 +32,34 @@ void RayTracedGGX::OnInit() {
   if (!m_rayTracer->Postinit()) throw std::runtime_error("Postinit failed");
   if (m_hasMetallicOverride) for (uint32_t i = 0; i < RayTracer::NUM_MESH; ++i) m_rayTracer->SetMetallic(i, m_metallics[i]);
 
-  // Projection and view (RayTracedGGX.cpp:262-277)
+  InitCamera();
+  if (!m_trackFileName.empty() && !LoadTrack(m_trackFileName)) throw std::runtime_error("cannot read track " + m_trackFileName);
+  m_initialized = true;
+}
+
+// Projection and view (RayTracedGGX.cpp:262-277)
+void RayTracedGGX::InitCamera() {
   const float aspectRatio = (float)m_width / (float)m_height;
   m_proj = xm::PerspectiveFovLH(g_FOVAngleY, aspectRatio, g_zNear, g_zFar);
   m_focusPt = {0.0f, 3.0f, 0.0f};
   m_eyePt = {10.0f, 10.0f, -24.0f};
   m_view = xm::LookAtLH(m_eyePt, m_focusPt, xm::Float3{0.0f, 1.0f, 0.0f});
-  m_initialized = true;
 }
 
 // RayTracedGGX.cpp:282-299
 void RayTracedGGX::OnUpdate() {
+  for (; m_trackNext < m_track.size() && m_track[m_trackNext].frame <= m_frameNumber; ++m_trackNext) {
+    const TrackEvent& e = m_track[m_trackNext];
+    switch (e.type) {
+      case 0: OnKeyUp((uint8_t)e.a); break;
+      case 1: OnLButtonDown(e.a, e.b); break;
+      case 2: OnLButtonUp(e.a, e.b); break;
+      case 3: OnMouseMove(e.a, e.b); break;
+      case 4: OnMouseWheel(e.a, 0.0f, 0.0f); break;
+      default: OnMouseLeave(); break;
+    }
+  }
+  ++m_frameNumber;
   const float timeStep = m_isPaused ? 0.0f : m_fixedTimeStep;
   m_rayTracer->UpdateFrame(m_frameIndex, m_eyePt, m_view * m_proj, timeStep);
 }
@@ -79,6 +97,61 @@ void RayTracedGGX::OnKeyUp(uint8_t key) {
   }
 }
 
+// RayTracedGGX.cpp:400-455: orbit about the focus point while the left button is held, dolly with the wheel
+void RayTracedGGX::OnLButtonDown(float posX, float posY) { m_tracking = true; m_mousePt[0] = posX; m_mousePt[1] = posY; }
+void RayTracedGGX::OnLButtonUp(float, float) { m_tracking = false; }
+void RayTracedGGX::OnMouseLeave() { m_tracking = false; }
+static float distance(const xm::Float3& a, const xm::Float3& b) { const xm::Float3 d = xm::Sub(a, b); return std::sqrt(xm::Dot(d, d)); }
+void RayTracedGGX::OnMouseMove(float posX, float posY) {
+  if (!m_tracking) return;
+  const float dx = m_mousePt[0] - posX, dy = m_mousePt[1] - posY;
+  const float twoPi = 6.283185307f;                                     // XM_2PI
+  const float pitch = twoPi * dy / (float)m_height, yaw = twoPi * dx / (float)m_width;
+  const float len = distance(m_focusPt, m_eyePt);
+  xm::Matrix transform = xm::Translation(0.0f, 0.0f, -len);
+  transform = transform * xm::RotationRollPitchYaw(pitch, yaw, 0.0f);
+  transform = transform * xm::Translation(0.0f, 0.0f, len);
+  m_view = m_view * transform;
+  const xm::Matrix viewInv = xm::Inverse(m_view);
+  m_eyePt = {viewInv.r[3][0], viewInv.r[3][1], viewInv.r[3][2]};
+  m_mousePt[0] = posX; m_mousePt[1] = posY;
+}
+void RayTracedGGX::OnMouseWheel(float deltaZ, float, float) {
+  const float len = distance(m_focusPt, m_eyePt);
+  m_view = m_view * xm::Translation(0.0f, 0.0f, -len * deltaZ / 16.0f);
+  const xm::Matrix viewInv = xm::Inverse(m_view);
+  m_eyePt = {viewInv.r[3][0], viewInv.r[3][1], viewInv.r[3][2]};
+}
+
+bool RayTracedGGX::LoadTrack(const std::string& fileName) {
+  FILE* f = std::fopen(fileName.c_str(), "r");
+  if (!f) return false;
+  m_track.clear(); m_trackNext = 0;
+  char line[256];
+  while (std::fgets(line, sizeof line, f)) {
+    unsigned frame; char cmd[32], arg[32]; float a = 0.0f, b = 0.0f;
+    if (line[0] == '#' || std::sscanf(line, "%u %31s", &frame, cmd) != 2) continue;
+    const std::string c = cmd;
+    TrackEvent e{frame, 5, 0.0f, 0.0f};
+    if (c == "key") {
+      if (std::sscanf(line, "%u %*s %31s", &frame, arg) != 2) continue;
+      const std::string k = arg;
+      const int code = k == "SPACE" ? ' ' : k == "LEFT" ? 0x25 : k == "UP" ? 0x26 : k == "RIGHT" ? 0x27 : k == "DOWN" ? 0x28 : k.size() == 1 ? std::toupper((unsigned char)k[0]) : std::atoi(arg);
+      e.type = 0; e.a = (float)code;
+    } else if (c == "down" || c == "up" || c == "move") {
+      if (std::sscanf(line, "%u %*s %f %f", &frame, &a, &b) != 3) continue;
+      e.type = c == "down" ? 1 : c == "up" ? 2 : 3; e.a = a; e.b = b;
+    } else if (c == "wheel") {
+      if (std::sscanf(line, "%u %*s %f", &frame, &a) != 2) continue;
+      e.type = 4; e.a = a;
+    } else if (c != "leave") continue;
+    m_track.push_back(e);
+  }
+  std::fclose(f);
+  std::stable_sort(m_track.begin(), m_track.end(), [](const TrackEvent& x, const TrackEvent& y) { return x.frame < y.frame; });
+  return true;
+}
+
 // RayTracedGGX.cpp:462-511: '-' or '/' prefix, case-insensitive names; a following token is a value
 // unless it starts with '/' or with '-' not followed by a digit or '.'.
 void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
@@ -88,7 +161,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     return (arg[0] == '-' || arg[0] == '/') && lower(arg + 1) == lower(name);
   };
   // On POSIX an absolute path also starts with '/': such a token is a flag only when it names one.
-  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus"};
+  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus", "track"};
   const auto isFlagName = [&](const char* name) { for (const char* f : kFlags) if (lower(name) == f) return true; return false; };
   const auto hasNextArgValue = [&](int i) {
     if (i + 1 >= argc) return false;
@@ -113,6 +186,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     else if (isArgMatched(i, "sync")) m_asyncCompute = 0;
     else if (isArgMatched(i, "device")) { if (hasNextArgValue(i)) m_device = std::atoi(argv[++i]); }
     else if (isArgMatched(i, "dump")) { if (hasNextArgValue(i)) m_dumpPrefix = argv[++i]; }
+    else if (isArgMatched(i, "track")) { if (hasNextArgValue(i)) m_trackFileName = argv[++i]; }
     else if (isArgMatched(i, "gpus")) {
       // One process drives one GPU.  Several GPUs = one process per GPU, each rendering a strip of rows and exchanging the
       // temporal history over RCCL (raytracedggx_amd/strips.py; bench.py under torch.distributed.run): say so, loudly.

@@ -4,6 +4,7 @@
 // (RayTracedGGX.cpp:37-39, camera :19-23, 267-277).  What the window supplied interactively is
 // supplied by extra flags: -width -height -frames -dt -metallic -sharedmem -sync -device -dump.
 #pragma once
+#include <vector>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -23,6 +24,18 @@ class RayTracedGGX {
   virtual void OnRender();
   virtual void OnDestroy();
   virtual void OnKeyUp(uint8_t key);
+  // camera interactions of the sample's window (RayTracedGGX.h:58-63, .cpp:400-455): positions in pixels
+  virtual void OnLButtonDown(float posX, float posY);
+  virtual void OnLButtonUp(float posX, float posY);
+  virtual void OnMouseMove(float posX, float posY);
+  virtual void OnMouseWheel(float deltaZ, float posX, float posY);
+  virtual void OnMouseLeave();
+  void InitCamera();                                 // projection and view of LoadAssets (RayTracedGGX.cpp:262-277)
+  const xm::Float3& GetEyePt() const { return m_eyePt; }
+  const xm::Matrix& GetView() const { return m_view; }
+  // Scripted input (replaces the message loop): a text file, one event per line, applied by OnUpdate before the frame
+  // with that number:  <frame> key <code | SPACE LEFT RIGHT UP DOWN V A> | down x y | up x y | move x y | wheel dz | leave
+  bool LoadTrack(const std::string& fileName);
 
   void ParseCommandLineArgs(char* argv[], int argc);
 
@@ -56,6 +69,13 @@ class RayTracedGGX {
   // camera (RayTracedGGX.h:100-104)
   xm::Matrix m_proj, m_view;
   xm::Float3 m_focusPt, m_eyePt;
+  bool m_tracking = false;
+  float m_mousePt[2] = {0.0f, 0.0f};
+  struct TrackEvent { uint32_t frame; int type; float a, b; };   // type: 0 key, 1 down, 2 up, 3 move, 4 wheel, 5 leave
+  std::vector<TrackEvent> m_track;
+  size_t m_trackNext = 0;
+  uint32_t m_frameNumber = 0;
+  std::string m_trackFileName;
 
   // command line
   std::string m_meshFileName = "Assets/dragon.obj";

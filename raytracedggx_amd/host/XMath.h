@@ -38,6 +38,17 @@ inline Matrix RotationY(float angle) {
   m.r[0][0] = c; m.r[0][2] = -s; m.r[2][0] = s; m.r[2][2] = c;
   return m;
 }
+// XMMatrixRotationRollPitchYaw(pitch, yaw, roll): roll about z first, then pitch about x, then yaw about y (row vectors)
+inline Matrix RotationRollPitchYaw(float pitch, float yaw, float roll) {
+  const float cp = (float)std::cos((double)pitch), sp = (float)std::sin((double)pitch);
+  const float cy = (float)std::cos((double)yaw), sy = (float)std::sin((double)yaw);
+  const float cr = (float)std::cos((double)roll), sr = (float)std::sin((double)roll);
+  Matrix m = Identity();
+  m.r[0][0] = cr * cy + sr * sp * sy; m.r[0][1] = sr * cp; m.r[0][2] = sr * sp * cy - cr * sy;
+  m.r[1][0] = cr * sp * sy - sr * cy; m.r[1][1] = cr * cp; m.r[1][2] = sr * sy + cr * sp * cy;
+  m.r[2][0] = cp * sy; m.r[2][1] = -sp; m.r[2][2] = cp * cy;
+  return m;
+}
 inline float Dot(Float3 a, Float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 inline Float3 Cross(Float3 a, Float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline Float3 Sub(Float3 a, Float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }

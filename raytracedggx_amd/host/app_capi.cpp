@@ -26,6 +26,24 @@ void rtggx_app_destroy(void* h) { RayTracedGGX* app = (RayTracedGGX*)h; if (app)
 void rtggx_app_on_update(void* h) { ((RayTracedGGX*)h)->OnUpdate(); }
 void rtggx_app_on_render(void* h) { ((RayTracedGGX*)h)->OnRender(); }
 void rtggx_app_on_key_up(void* h, int key) { ((RayTracedGGX*)h)->OnKeyUp((uint8_t)key); }
+void rtggx_app_on_lbutton_down(void* h, float x, float y) { ((RayTracedGGX*)h)->OnLButtonDown(x, y); }
+void rtggx_app_on_lbutton_up(void* h, float x, float y) { ((RayTracedGGX*)h)->OnLButtonUp(x, y); }
+void rtggx_app_on_mouse_move(void* h, float x, float y) { ((RayTracedGGX*)h)->OnMouseMove(x, y); }
+void rtggx_app_on_mouse_wheel(void* h, float dz, float x, float y) { ((RayTracedGGX*)h)->OnMouseWheel(dz, x, y); }
+int rtggx_app_load_track(void* h, const char* path) { return ((RayTracedGGX*)h)->LoadTrack(path) ? 0 : -1; }
+// The camera handlers on their own (no device): events = n x (type, a, b) with type 1 down, 2 up, 3 move, 4 wheel;
+// returns the eye point and the view matrix (row-major) they lead to from the sample's initial camera.
+void rtggx_host_camera(uint32_t width, uint32_t height, const float* events, uint32_t n, float* eye3, float* view16) {
+  RayTracedGGX app(width, height, "");
+  app.InitCamera();
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* e = events + 3 * i;
+    switch ((int)e[0]) { case 1: app.OnLButtonDown(e[1], e[2]); break; case 2: app.OnLButtonUp(e[1], e[2]); break;
+                         case 3: app.OnMouseMove(e[1], e[2]); break; case 4: app.OnMouseWheel(e[1], 0.0f, 0.0f); break; default: app.OnMouseLeave(); }
+  }
+  eye3[0] = app.GetEyePt().x; eye3[1] = app.GetEyePt().y; eye3[2] = app.GetEyePt().z;
+  std::memcpy(view16, app.GetView().r, 64);
+}
 void rtggx_app_set_time_step(void* h, float dt) { ((RayTracedGGX*)h)->SetFixedTimeStep(dt); }
 void* rtggx_app_context(void* h) { return ((RayTracedGGX*)h)->GetContext(); }
 void rtggx_app_size(void* h, uint32_t* w, uint32_t* ht) { *w = ((RayTracedGGX*)h)->GetWidth(); *ht = ((RayTracedGGX*)h)->GetHeight(); }

@@ -526,6 +526,28 @@ def test_strip_exchange_through_rccl_send_recv(built):
             s.close()
 
 
+def test_scripted_camera_and_material_track(built, tmp_path):
+    """SURVEY 8f rank 3: the sample's interactions as a script (-track file / RayTracedGGX::LoadTrack): an orbit with the
+    left button held, a dolly, [DOWN] lowering the ground's metallic (diffuse rays appear), [V] switching the filter
+    variant -- disocclusion and reprojection stress for the temporal pass, every frame against the oracle."""
+    track = tmp_path / "orbit.track"
+    track.write_text("# frame command args\n1 down 160 90\n1 move 150 86\n2 move 128 80\n2 key DOWN\n3 move 100 84\n3 wheel 2\n4 up 0 0\n4 move 10 10\n4 key V\n5 key DOWN\n")
+    p = Pair(320, 180)
+    try:
+        assert p.app.load_track(str(track))
+        eyes = []
+        for f in range(6):
+            if f == 2: p.o.set_metallic(0, 0.75)                  # what [DOWN] does to mesh 0 in frame 2 ...
+            if f == 5: p.o.set_metallic(0, 0.5)                   # ... and again in frame 5
+            p.frame()
+            p.check_frame("track frame %d" % f)
+            eyes.append(p.app.frame_constants().tobytes())
+        assert len(set(eyes[1:4])) == 3 and eyes[4][:704] != eyes[3][:704]      # the camera moved while the button was held
+        assert p.ctx.ray_count() > 1.5 * 320 * 180 * 0.2                        # diffuse rays are being traced by now
+    finally:
+        p.close()
+
+
 def test_frame_dump_png_and_ppm_equal_the_back_buffer(built, tmp_path):
     """RayTracedGGX::SaveImage (the sample's screenshot, RayTracedGGX.cpp:719-739): PNG and PPM dumps hold the back buffer."""
     import sys

@@ -160,3 +160,38 @@ def test_png_writer_and_image_diff_tool(built, tmp_path):
     assert run(str(tmp_path / "a.png"), str(tmp_path / "c.png")).returncode == 1
     imgdiff.save_png(str(tmp_path / "e.png"), b[:50])
     assert run(str(tmp_path / "a.png"), str(tmp_path / "e.png")).returncode == 2
+
+
+def test_camera_handlers_orbit_and_dolly(built):
+    """OnLButtonDown / OnMouseMove / OnMouseWheel (RayTracedGGX.cpp:400-455), restated here with numpy: orbiting keeps the
+    distance to the focus point and the focus on the view axis; the wheel scales the distance by 1 - dz/16; nothing
+    moves while the button is up."""
+    from raytracedggx_amd import app
+    W, H = 1280, 720
+    focus = np.array([0.0, 3.0, 0.0])
+    eye0, view0 = app.camera(W, H, [])
+    np.testing.assert_allclose(eye0, [10.0, 10.0, -24.0])
+    d0 = np.linalg.norm(eye0 - focus)
+    eye, view = app.camera(W, H, [(3, 500, 300)])                       # move without the button: ignored
+    np.testing.assert_array_equal(eye, eye0); np.testing.assert_array_equal(view, view0)
+    ev = [(1, 640, 360), (3, 600, 330), (3, 520, 345), (2, 0, 0), (3, 0, 0)]
+    eye, view = app.camera(W, H, ev)
+    assert abs(np.linalg.norm(eye - focus) - d0) < 2e-4 * d0 and np.linalg.norm(eye - eye0) > 1.0
+    f = np.append(focus, 1.0) @ view.astype(np.float64)                  # the focus point in view space: on the +z axis
+    assert abs(f[0]) < 1e-3 and abs(f[1]) < 1e-3 and abs(f[2] - d0) < 2e-4 * d0
+    np.testing.assert_allclose(np.append(eye, 1.0) @ view.astype(np.float64), [0, 0, 0, 1], atol=2e-4)
+    # the same orbit restated: view' = view * T(0,0,-len) * R(pitch, yaw) * T(0,0,len), one step per move
+    def T(z):
+        m = np.eye(4); m[3, 2] = z; return m
+    def R(p, y):
+        cp, sp, cy, sy = np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+        return np.array([[cy, 0, -sy, 0], [sp * sy, cp, sp * cy, 0], [cp * sy, -sp, cp * cy, 0], [0, 0, 0, 1]])
+    v, e, last = view0.astype(np.float64), eye0.astype(np.float64), (640.0, 360.0)
+    for x, y in ((600, 330), (520, 345)):
+        dx, dy = last[0] - x, last[1] - y
+        ln = np.linalg.norm(focus - e)
+        v = v @ T(-ln) @ R(2 * np.pi * dy / H, 2 * np.pi * dx / W) @ T(ln)
+        e = np.linalg.inv(v)[3, :3]; last = (x, y)
+    np.testing.assert_allclose(view, v, atol=5e-5); np.testing.assert_allclose(eye, e, atol=5e-4)
+    eye2, _ = app.camera(W, H, ev + [(4, 4.0, 0)])                       # wheel +4: a quarter closer
+    assert abs(np.linalg.norm(eye2 - focus) - 0.75 * d0) < 1e-3
