@@ -104,12 +104,14 @@ def main():
         k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         # HBM bytes per launch from hardware counters: collected in separate rocprofv3 --pmc runs of this same workload
         # (tools/pmc.sh), committed under profiles/; null for other workloads
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu = None, None, None
         import glob
         tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
         if tfiles and (W, H, args.mesh, world) == (1920, 1080, "bunny.obj", 1):
             with open(tfiles[-1]) as f:
-                traffic = json.load(f)["kernels"].get("rt::traceKernel", {}).get("traffic_bytes")
+                pmc = json.load(f)
+            traffic = pmc["kernels"].get("rt::traceKernel", {}).get("traffic_bytes")
+            valu = pmc.get("valu_instructions_per_frame")
             traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)" % os.path.basename(tfiles[-1])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
         out = {
@@ -128,6 +130,10 @@ def main():
                                    "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
             "passes_ms": r.last_timings(),
         }
+        if valu:      # what actually bounds the frame: VALU issue (wave-level instructions x 4 cycles over 1024 SIMDs at 2.4 GHz)
+            issue_ms = valu * 4.0 / 1024.0 / 2.4e9 * 1e3
+            out["roofline"]["frame"]["valu_issue"] = {"instructions": valu, "issue_ms": round(issue_ms, 4), "frac_of_frame": round(issue_ms / ms_per_step, 4),
+                                                       "source": traffic_source.replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(r, args, W, H)
         print(json.dumps(out), flush=True)

@@ -32,6 +32,18 @@ for block in re.split(r"\n(?=\S)", txt):
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and name.startswith(("rt::", "void rt::")):
         out["kernels"][name] = {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                                 "traffic_bytes": int(1024 * (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]))}
+# wave-level VALU instructions of the frame's kernels (SQ_INSTS_VALU per dispatch, one dispatch of each per frame): the frame is
+# bound by VALU issue, and bench.py reports the fraction of the issue slots (4 cycles per instruction, 1024 SIMDs, 2.4 GHz)
+frame_kernels = ("rt::clearVisDepth", "rt::rasterSmall", "rt::rasterLarge", "rt::rayGenKernel", "rt::traceKernel", "rt::shadeKernel",
+                 "void rt::spatialTiledKernel<0>", "void rt::spatialTiledKernel<1>", "void rt::spatialTiledKernel<2>", "void rt::spatialTiledKernel<3>",
+                 "rt::temporalKernel", "rt::toneMapKernel")
+valu = 0.0
+for block in re.split(r"\n(?=\S)", txt):
+    name = block.split("\n")[0].strip()
+    m = re.search(r"^\s+SQ_INSTS_VALU\s+([0-9.]+) per dispatch", block, re.M)
+    if m and name.split("(")[0] in frame_kernels:
+        valu += float(m.group(1))
+out["valu_instructions_per_frame"] = int(valu)
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 print("trace kernel traffic:", out["kernels"].get("rt::traceKernel"))
 EOF
