@@ -526,6 +526,21 @@ def test_strip_exchange_through_rccl_send_recv(built):
             s.close()
 
 
+def test_long_run_past_the_frame_index_wrap(built):
+    """C5-style run: 264 consecutive frames at dt = 1/60 (the model turns by 70 degrees; CBGlobal::FrameIndex wraps at
+    256, the Halton counter does not, the constant slots and input sets cycle many times), the oracle carried along
+    the whole way; full parity check at the start, around the wrap and at the end."""
+    p = Pair(160, 90, metallic=(1.0, 0.5))
+    try:
+        for f in range(264):
+            p.frame()
+            if f in (0, 1, 2, 127, 254, 255, 256, 257, 263):
+                p.check_frame("long run frame %d" % f)
+        assert p.app.frame_constants().view(np.uint32)[111] == 263 % 256      # CBGlobal::FrameIndex at byte 444
+    finally:
+        p.close()
+
+
 def test_scripted_camera_and_material_track(built, tmp_path):
     """SURVEY 8f rank 3: the sample's interactions as a script (-track file / RayTracedGGX::LoadTrack): an orbit with the
     left button held, a dolly, [DOWN] lowering the ground's metallic (diffuse rays appear), [V] switching the filter
