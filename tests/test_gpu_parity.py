@@ -476,11 +476,13 @@ def test_free_running_frames_equal_synchronised_frames(built):
             a.OnDestroy(); b.OnDestroy()
 
 
-def test_strip_exchange_through_rccl_send_recv(built):
+@pytest.mark.parametrize("world", [2, 8], ids=["2 strips", "8 strips"])
+def test_strip_exchange_through_rccl_send_recv(built, world):
     """The direct RCCL path of the strip exchange (raytracedggx_amd/rccl.py: ncclSend/ncclRecv in one group on the
     renderer's stream, pointers from StripRenderer.raw_ops) on the one GPU of the box: a single-rank communicator whose
     sends and receives pair up with each other, moving the rows between two strips of one process -- against the
-    single-context frame.  (Across processes the only difference is the peer number.)"""
+    single-context frame.  (Across processes the only difference is the peer number.)  With 8 strips the middle ones have two
+    neighbours and strip 0 assembles seven others -- the shape of the 8-GPU run."""
     import torch
     from raytracedggx_amd import capi, rccl
     from raytracedggx_amd.strips import StripRenderer
@@ -501,7 +503,7 @@ def test_strip_exchange_through_rccl_send_recv(built):
         comm.exchange(ops, r.stream.cuda_stream)
 
     full = StripRenderer(W, H, mesh, env, extra_args=("-sharedmem",))
-    strips += [StripRenderer(W, H, mesh, env, rank=r, world=2, transport=transport, torch_buffers=True, extra_args=("-sharedmem",)) for r in range(2)]
+    strips += [StripRenderer(W, H, mesh, env, rank=r, world=world, transport=transport, torch_buffers=True, extra_args=("-sharedmem",)) for r in range(world)]
     try:
         for f in range(3):
             full.frame()
@@ -514,7 +516,6 @@ def test_strip_exchange_through_rccl_send_recv(built):
                     s.stream.wait_stream(t.stream)
             torch.cuda.synchronize(); full.context.sync()
             np.testing.assert_array_equal(strips[0].context.readback(capi.BUF_BACKBUFFER), full.context.readback(capi.BUF_BACKBUFFER), err_msg="frame %d" % f)
-            b1, e1 = strips[1].b, strips[1].e
             for k, s in enumerate(strips):          # each strip's history, with the apron rows it received, equals the full frame's
                 lo, hi = max(s.b - 17, 0), min(s.e + 17, H)
                 bid = capi.BUF_TSS1 if s.context.frame_parity() else capi.BUF_TSS0
