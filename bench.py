@@ -61,7 +61,7 @@ def main():
 
     W, H = args.width, args.height
     r = StripRenderer(W, H, assets.path(args.mesh), assets.path("rnl_cross.dds"), rank=rank, world=world, device=local_rank,
-                      dist=dist if world > 1 else None,
+                      dist=dist if world > 1 else None, balance=world > 1,
                       extra_args=("-sharedmem",) + (("-metallic", args.metallic[0], args.metallic[1]) if args.metallic else ()))
     ctx = r.context
 
@@ -121,7 +121,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: %s + rnl_cross env, %dx%d, 1spp GGX reflection + full denoise chain (refl H,V; diff H,V, shared-memory variant; temporal; tone map), "
                                    "%s, dt=1/60" % (args.mesh, W, H, "metallic %g %g" % tuple(args.metallic) if args.metallic else "all-metal default materials"),
-                       "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world},
+                       "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world, "strip_bounds": r.bounds},
             "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),

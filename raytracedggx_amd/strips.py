@@ -32,16 +32,38 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 3}
 
 
-def strip_rows(height, rank, world):
+def strip_rows(height, rank, world, bounds=None):
+    """Rows [begin, end) of `rank`: equal strips, or the boundaries `bounds` (world + 1 ascending row numbers, 0 .. height)."""
+    if bounds is not None:
+        return int(bounds[rank]), int(bounds[rank + 1])
     return (rank * height) // world, ((rank + 1) * height) // world
 
 
-def exchange_plan(height, rank, world, apron=HISTORY_APRON):
+def balanced_bounds(row_cost, world, min_rows=HISTORY_APRON):
+    """Strip boundaries that even out sum(row_cost) per strip: boundary k at the row where the running cost passes k/world of
+    the total, every strip at least `min_rows` rows (the history apron must fit).  Deterministic in its inputs: every
+    rank computes the same boundaries from the same profile."""
+    cost = np.asarray(row_cost, np.float64)
+    height = len(cost)
+    if height < world * min_rows:
+        raise ValueError("%d rows cannot hold %d strips of at least %d rows" % (height, world, min_rows))
+    csum = np.concatenate([[0.0], np.cumsum(cost)])
+    bounds = [0]
+    for k in range(1, world):
+        b = int(np.searchsorted(csum, csum[-1] * k / world, side="left"))
+        b = max(b, bounds[-1] + min_rows)                       # room for this strip ...
+        b = min(b, height - (world - k) * min_rows)             # ... and for the ones that follow
+        bounds.append(b)
+    bounds.append(height)
+    return bounds
+
+
+def exchange_plan(height, rank, world, apron=HISTORY_APRON, bounds=None):
     """The point-to-point transfers of one frame for `rank`: a list of (op, buffer, row_begin, row_end, peer) with op in
     {"send", "recv"} and buffer in {"history", "backbuffer"}.  Rows are frame rows: every rank allocates full-size
     targets, so a transfer reads and writes the same rows on both sides.  Ops between a pair of ranks appear in the same
     order on both (history first, then the back-buffer strip), which is what tag-less send/recv matching needs."""
-    b, e = strip_rows(height, rank, world)
+    b, e = strip_rows(height, rank, world, bounds)
     ops = []
     if rank > 0:                       # upper neighbour owns [.., b)
         ops.append(("send", "history", b, min(b + apron, e), rank - 1))
@@ -51,7 +73,7 @@ def exchange_plan(height, rank, world, apron=HISTORY_APRON):
         ops.append(("recv", "history", e, min(e + apron, height), rank + 1))
     if rank == 0:                      # frame assembly on rank 0 (the reference presents one back buffer)
         for r in range(1, world):
-            rb, re = strip_rows(height, r, world)
+            rb, re = strip_rows(height, r, world, bounds)
             ops.append(("recv", "backbuffer", rb, re, r))
     else:
         ops.append(("send", "backbuffer", b, e, 0))
@@ -80,18 +102,29 @@ def run_exchange(dist, plan, buffers, ops=None):
 
 
 class StripRenderer:
+    PROFILE_FRAMES = 2         # full frames every rank renders first when it balances the strips itself
+    SKY_ROW_WEIGHT = 0.3       # cost of a row = covered pixels + this x width (rows without a surface are not free); 0.05 .. 0.6 tried
+
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
-                 transport=None, torch_buffers=None):
+                 transport=None, torch_buffers=None, balance=False):
         """dist: torch.distributed (one process per GPU).  transport: instead of dist, a callable
         transport(renderer, plan) that carries out the plan some other way (tests drive several strips from one process).
         torch_buffers: wrap the exchanged targets as torch tensors and render on torch's current stream (default: only
-        when dist is used); with a transport it lets a test move the rows with torch copies on that stream."""
+        when dist is used); with a transport it lets a test move the rows with torch copies on that stream.
+        balance: False = equal strips; a list of world + 1 row numbers = these boundaries; True = every rank first renders
+        PROFILE_FRAMES full frames and cuts the frame where the covered pixels (= rays, the expensive rows) balance --
+        rendering is deterministic, so all ranks arrive at the same boundaries without talking to each other."""
         self.W, self.H, self.rank, self.world, self.dist, self.transport = width, height, rank, world, dist, transport
         args = ["-mesh", mesh_path] + ([str(x) for x in pos_scale] if pos_scale else []) + \
                ["-env", env_path, "-width", width, "-height", height, "-device", device] + list(extra_args)
         self.app = app.RayTracedGGX(args)
         self.context = self.app.context
-        self.b, self.e = strip_rows(height, rank, world)
+        self.bounds = None
+        if world > 1 and balance is not False and balance is not None:
+            self.bounds = self.profile_bounds(world) if balance is True else [int(x) for x in balance]
+            if len(self.bounds) != world + 1 or self.bounds[0] != 0 or self.bounds[-1] != height:
+                raise ValueError("balance: %d boundaries from 0 to %d expected, got %s" % (world + 1, height, self.bounds))
+        self.b, self.e = strip_rows(height, rank, world, self.bounds)
         if world > 1:
             if self.e - self.b < HISTORY_APRON:
                 raise ValueError("strips of %d rows are thinner than the %d-row history apron" % (self.e - self.b, HISTORY_APRON))
@@ -124,6 +157,14 @@ class StripRenderer:
         t = self.torch.as_tensor(_DeviceArray(self.context.buffer_ptr(bid), (self.H, self.W), typestr), device="cuda")
         return t.view(self.torch.int64 if typestr == "<u8" else self.torch.int32)
 
+    def profile_bounds(self, world):
+        """Renders PROFILE_FRAMES whole frames and returns the boundaries that balance covered pixels (+ a per-row constant)."""
+        for _ in range(self.PROFILE_FRAMES):
+            self.render()
+        self.context.sync()
+        covered = (self.context.readback(capi.BUF_VISIBILITY) != 0).sum(axis=1)
+        return balanced_bounds(covered + self.SKY_ROW_WEIGHT * self.W, world)
+
     # -- one frame --------------------------------------------------------------------------------------
     def frame(self):
         self.render()
@@ -137,16 +178,16 @@ class StripRenderer:
         if self.world == 1:
             return
         if self.transport is not None:
-            self.transport(self, exchange_plan(self.H, self.rank, self.world))
+            self.transport(self, exchange_plan(self.H, self.rank, self.world, bounds=self.bounds))
             return
         parity = self.context.frame_parity()
         if self._comm is not None:
             if self._ops[parity] is None:      # (is_send, pointer, bytes, peer), built once per history target
-                self._ops[parity] = self.raw_ops(exchange_plan(self.H, self.rank, self.world), parity)
+                self._ops[parity] = self.raw_ops(exchange_plan(self.H, self.rank, self.world, bounds=self.bounds), parity)
             self._comm.exchange(self._ops[parity], self.stream.cuda_stream)
             return
         if self._ops[parity] is None:          # built once per history target: the per-frame host cost is the batch call alone
-            self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world), self.exchange_buffers())
+            self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world, bounds=self.bounds), self.exchange_buffers())
         with self.torch.cuda.stream(self.stream):
             run_exchange(self.dist, None, None, ops=self._ops[parity])
 

@@ -476,13 +476,15 @@ def test_free_running_frames_equal_synchronised_frames(built):
             a.OnDestroy(); b.OnDestroy()
 
 
-@pytest.mark.parametrize("world", [2, 8], ids=["2 strips", "8 strips"])
-def test_strip_exchange_through_rccl_send_recv(built, world):
+@pytest.mark.parametrize("world,balance", [(2, False), (8, False), (8, True), (5, [0, 40, 57, 120, 190, 272])],
+                         ids=["2 strips", "8 strips", "8 balanced strips", "5 uneven strips"])
+def test_strip_exchange_through_rccl_send_recv(built, world, balance):
     """The direct RCCL path of the strip exchange (raytracedggx_amd/rccl.py: ncclSend/ncclRecv in one group on the
     renderer's stream, pointers from StripRenderer.raw_ops) on the one GPU of the box: a single-rank communicator whose
     sends and receives pair up with each other, moving the rows between two strips of one process -- against the
     single-context frame.  (Across processes the only difference is the peer number.)  With 8 strips the middle ones have two
-    neighbours and strip 0 assembles seven others -- the shape of the 8-GPU run."""
+    neighbours and strip 0 assembles seven others -- the shape of the 8-GPU run; `balanced`: every strip first profiles
+    two whole frames and cuts the frame where the covered pixels balance, as bench.py does for N > 1."""
     import torch
     from raytracedggx_amd import capi, rccl
     from raytracedggx_amd.strips import StripRenderer
@@ -503,7 +505,11 @@ def test_strip_exchange_through_rccl_send_recv(built, world):
         comm.exchange(ops, r.stream.cuda_stream)
 
     full = StripRenderer(W, H, mesh, env, extra_args=("-sharedmem",))
-    strips += [StripRenderer(W, H, mesh, env, rank=r, world=world, transport=transport, torch_buffers=True, extra_args=("-sharedmem",)) for r in range(world)]
+    strips += [StripRenderer(W, H, mesh, env, rank=r, world=world, transport=transport, torch_buffers=True, extra_args=("-sharedmem",), balance=balance) for r in range(world)]
+    if balance is True:
+        assert all(s.bounds == strips[0].bounds for s in strips) and strips[0].bounds != [(r * H) // world for r in range(world + 1)]
+        for _ in range(StripRenderer.PROFILE_FRAMES):          # the strips have rendered these as whole frames: the reference follows
+            full.frame()
     try:
         for f in range(3):
             full.frame()

@@ -123,3 +123,42 @@ def test_raw_send_recv_lists_move_the_right_rows(world):
         b, e = strips.strip_rows(H, r, world)
         lo, hi = max(b - strips.HISTORY_APRON, 0), min(e + strips.HISTORY_APRON, H)
         np.testing.assert_array_equal(hist[r][lo:hi], truth_h[lo:hi])
+
+
+def test_balanced_bounds_and_uneven_plans():
+    """strips.balanced_bounds: boundaries where the running row cost passes k/N of the total, every strip at least the
+    history apron high; exchange plans over such boundaries stay pairwise consistent and move the right rows."""
+    import ctypes
+    from raytracedggx_amd import strips
+    rng = np.random.default_rng(11)
+    H, W = 300, 4
+    cost = np.concatenate([np.full(120, 0.3), rng.uniform(5.0, 9.0, 100), np.full(80, 1.0)])     # cheap sky, expensive middle
+    for world in (2, 3, 8):
+        b = strips.balanced_bounds(cost, world)
+        assert b[0] == 0 and b[-1] == H and len(b) == world + 1
+        assert all(b[k + 1] - b[k] >= strips.HISTORY_APRON for k in range(world))
+        sums = [cost[b[k]:b[k + 1]].sum() for k in range(world)]
+        if world <= 3:
+            assert max(sums) < 1.25 * cost.sum() / world           # balanced where the minimum height does not bind
+        assert strips.balanced_bounds(cost, world) == b            # deterministic
+        # the plans of all ranks over these boundaries pair up, and carried out they deliver aprons and the whole back buffer
+        hist = [np.zeros((H, W), np.uint64) for _ in range(world)]
+        bb = [np.zeros((H, W), np.uint32) for _ in range(world)]
+        truth_h = (np.arange(H * W, dtype=np.uint64).reshape(H, W) + 1) * 1000003
+        truth_b = ((np.arange(H * W, dtype=np.uint64).reshape(H, W) + 7) * 2654435761 % (2 ** 32)).astype(np.uint32)
+        for r in range(world):
+            hist[r][b[r]:b[r + 1]] = truth_h[b[r]:b[r + 1]]; bb[r][b[r]:b[r + 1]] = truth_b[b[r]:b[r + 1]]
+        raw = [strips.plan_to_raw(strips.exchange_plan(H, r, world, bounds=b), hist[r].ctypes.data, bb[r].ctypes.data, W) for r in range(world)]
+        for a in range(world):
+            for c in range(world):
+                sends = [op for op in raw[a] if op[0] and op[3] == c]
+                recvs = [op for op in raw[c] if not op[0] and op[3] == a]
+                assert [x[2] for x in sends] == [x[2] for x in recvs]
+                for (_, sp, sn, _), (_, rp, rn, _) in zip(sends, recvs):
+                    ctypes.memmove(rp, sp, sn)
+        np.testing.assert_array_equal(bb[0], truth_b)
+        for r in range(world):
+            lo, hi = max(b[r] - strips.HISTORY_APRON, 0), min(b[r + 1] + strips.HISTORY_APRON, H)
+            np.testing.assert_array_equal(hist[r][lo:hi], truth_h[lo:hi])
+    with pytest.raises(ValueError):
+        strips.balanced_bounds(np.ones(100), 8)                   # 8 strips of 17 rows do not fit in 100
