@@ -133,7 +133,7 @@ def main():
         if valu:      # what actually bounds the frame: VALU issue (wave-level instructions x 4 cycles over 1024 SIMDs at 2.4 GHz)
             issue_ms = valu * 4.0 / 1024.0 / 2.4e9 * 1e3
             out["roofline"]["frame"]["valu_issue"] = {"instructions": valu, "issue_ms": round(issue_ms, 4), "frac_of_frame": round(issue_ms / ms_per_step, 4),
-                                                       "source": traffic_source.replace("FETCH_SIZE / WRITE_SIZE", "SQ_INSTS_VALU")}
+                                                       "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU, summed over the kernels of one frame)" % os.path.basename(tfiles[-1])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(r, args, W, H)
         print(json.dumps(out), flush=True)
