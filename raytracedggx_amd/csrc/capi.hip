@@ -65,6 +65,12 @@ static void invert4x4(const float* a /*row-major*/, float* out) {
 }
 
 static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
+static hipError_t syncStreams(rtggx_context* c) {
+  hipError_t e = c->streamVis ? hipStreamSynchronize(c->streamVis) : hipSuccess;
+  if (e == hipSuccess) e = hipStreamSynchronize(c->streamAS);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->streamMain);
+  return e;
+}
 // Constants reach the device in rtggx_update_as; a caller that skips it still gets them, on the main stream.
 // The constants go up on stream B (which also runs the visibility pass); everything on the main stream that
 // consumes them is ordered behind the event.
@@ -140,6 +146,9 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipStreamCreateWithPriority(&c->streamAS, hipStreamNonBlocking, prioMode == 0 ? prioGreatest : prioMode == 2 ? prioLeast : prioMid));
   c->streamMain = c->ownMain;
   c->attachEvents = !(getenv("RTGGX_ATTACH_EVENTS") && atoi(getenv("RTGGX_ATTACH_EVENTS")) == 0);
+  if (!(getenv("RTGGX_VIS_STREAM") && atoi(getenv("RTGGX_VIS_STREAM")) == 0))
+    RT_HIP(hipStreamCreateWithPriority(&c->streamVis, hipStreamNonBlocking, prioMid));
+  RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -224,7 +233,8 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
   hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
-  hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS);
+  hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS); if (c->streamVis) hipStreamDestroy(c->streamVis);
+  hipEventDestroy(c->evVis);
   delete c;
 }
 
@@ -237,7 +247,7 @@ int rtggx_set_strip(rtggx_context* c, uint32_t rowBegin, uint32_t rowEnd) {
 
 int rtggx_set_stream(rtggx_context* c, void* stream) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   if (stream) { c->streamMain = (hipStream_t)stream; c->externalStream = true; }
   else { c->streamMain = c->ownMain; c->externalStream = false; }
   return 0;
@@ -252,7 +262,7 @@ int rtggx_set_mesh(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
 int rtggx_set_env(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* data, size_t bytes) {
   RT_CHECK_CTX(c);
   if (!data) { setError("rtggx_set_env: null data"); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   return decodeEnv(c, format, size, mips, data, bytes, c->streamMain);
 }
 
@@ -272,7 +282,7 @@ int rtggx_set_metallic(rtggx_context* c, uint32_t mesh, float metallic) {   // R
 
 int rtggx_build_as(rtggx_context* c) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   for (uint32_t i = 0; i < 2; ++i) { const int r = buildLbvh(c, i, c->streamAS); if (r) return r; }
   c->asBuilt = true; c->sceneDirty = true;
   return 0;
@@ -333,9 +343,17 @@ int rtggx_render_visibility(rtggx_context* c) {
     if (gpuSideWait) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
     else if (hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
   }
-  if (c->timing) hipEventRecord(c->tev[2], c->streamAS);
-  const int r = launchVisibility(c, c->slots[c->slot], c->streamAS);
-  if (c->timing) hipEventRecord(c->tev[13], c->streamAS);
+  // Where the pass runs: on stream C when the launches are small (rtggx_context.h) and the previous frame's traversal does
+  // not use the split list (this pass's first kernel empties it); on stream B otherwise.  Either way the pass follows
+  // the previous one (shared large-triangle list) and ray generation follows it: both through evVis.
+  const bool small = c->streamVis && !c->lastTraceAdaptive && chooseSliceShift(c, true, c->numBinsMax) != 0u;
+  const hipStream_t s = small ? c->streamVis : c->streamAS;
+  if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on the other stream
+  if (c->timing) hipEventRecord(c->tev[2], s);
+  const int r = launchVisibility(c, c->slots[c->slot], s, c->streamVis ? c->evVis : nullptr);
+  if (c->streamVis) c->evVisStream = s;
+  if (c->timing) hipEventRecord(c->tev[13], s);
+  if (small) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evVis, 0));
   return r;
 }
 
@@ -377,14 +395,14 @@ int rtggx_tone_map(rtggx_context* c) {
 
 int rtggx_sync(rtggx_context* c) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   return 0;
 }
 
 int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
   RT_CHECK_CTX(c);
   uint32_t h[256];
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   RT_HIP(hipMemcpy(h, c->rayCounter32, sizeof h, hipMemcpyDeviceToHost));
   uint64_t s = 0; for (auto v : h) s += v;
   *rays = s;
@@ -396,7 +414,7 @@ int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
 int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset) {
   RT_CHECK_CTX(c);
   if (n > 768) { setError("rtggx_debug_counters: at most 768 words"); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   RT_HIP(hipMemcpy(out, c->rayCounter32 + 256, (size_t)n * 4, hipMemcpyDeviceToHost));
   if (reset) RT_HIP(hipMemset(c->rayCounter32 + 256, 0, 768 * 4));
   return 0;
@@ -406,7 +424,7 @@ int rtggx_debug_trace_split(rtggx_context* c, uint32_t workPerWave, uint32_t max
   RT_CHECK_CTX(c);
   if (maxShift > 3u) { setError("rtggx_debug_trace_split: max_shift %u > 3", maxShift); return -1; }
   if (capacity > (int)RT_SPLIT_CAP) { setError("rtggx_debug_trace_split: capacity %d > %u", capacity, RT_SPLIT_CAP); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   if (lastDemand) RT_HIP(hipMemcpy(lastDemand, c->largeCount + 1, 4, hipMemcpyDeviceToHost));
   c->splitWork = workPerWave; c->splitMaxShift = maxShift;
   c->splitCapForced = capacity < 0 ? 0xFFFFFFFFu : ((uint32_t)capacity / 32u) * 32u;
@@ -416,7 +434,7 @@ int rtggx_debug_trace_split(rtggx_context* c, uint32_t workPerWave, uint32_t max
 int rtggx_ray_total(rtggx_context* c, uint64_t* rays, int reset) {
   RT_CHECK_CTX(c);
   unsigned long long h[256];
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   RT_HIP(hipMemcpy(h, c->rayCounter + 256, sizeof h, hipMemcpyDeviceToHost));
   uint64_t s = 0; for (auto v : h) s += v;
   *rays = s;
@@ -438,7 +456,7 @@ int rtggx_enable_timing(rtggx_context* c, int mode) {
 }
 int rtggx_kernel_times(rtggx_context* c, float* ms, uint32_t capacity, uint32_t* count) {
   RT_CHECK_CTX(c);
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   const uint32_t n = c->kevCount < capacity ? c->kevCount : capacity;
   for (uint32_t i = 0; i < n; ++i) RT_HIP(hipEventElapsedTime(&ms[i], c->kevBegin[i], c->kevEnd[i]));
   *count = n;
@@ -448,7 +466,7 @@ int rtggx_kernel_times(rtggx_context* c, float* ms, uint32_t capacity, uint32_t*
 int rtggx_get_timings(rtggx_context* c, RtggxTimings* out) {
   RT_CHECK_CTX(c);
   if (!c->timing || !c->timingsPending) { setError("rtggx_get_timings: timing not enabled or no complete frame"); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   auto ms = [&](int a, int b) { float t = 0.0f; hipEventElapsedTime(&t, c->tev[a], c->tev[b]); return t; };
   RtggxTimings t;
   t.update_as = ms(0, 1); t.visibility = ms(2, 13); t.ray_trace = ms(3, 14); t.spatial_refl_h = ms(9, 4); t.spatial_refl_v = ms(4, 5);
@@ -500,7 +518,7 @@ int rtggx_readback(rtggx_context* c, int id, void* dst, size_t bytes) {
   int r = bufferInfo(c, id, &p, &need);
   if (r) return r;
   if (bytes < need) { setError("rtggx_readback: buffer %d needs %zu bytes, %zu given", id, need, bytes); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   if (id == RTGGX_BUF_TLAS) { memcpy(dst, c->invWorld, 128); return 0; }
   if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) {
     uint32_t *dVis, *dDepth;
@@ -522,7 +540,7 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
   int r = bufferInfo(c, id, &p, &need);
   if (r) return r;
   if (bytes != need) { setError("rtggx_upload: buffer %d is %zu bytes, %zu given", id, need, bytes); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));
+  RT_HIP(syncStreams(c));
   if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) {
     // replace one half of the packed buffer
     uint32_t *dVis, *dDepth;
@@ -547,7 +565,7 @@ int rtggx_bvh_root(rtggx_context* c, uint32_t slot, int32_t* root) { RT_CHECK_CT
 int rtggx_trace_rays(rtggx_context* c, const float* rays, uint32_t n, float* out) {
   RT_CHECK_CTX(c);
   if (!c->asBuilt || !c->haveConstants) { setError("rtggx_trace_rays: build_as / update_frame / update_as first"); return -1; }
-  RT_HIP(hipStreamSynchronize(c->streamAS)); RT_HIP(hipStreamSynchronize(c->streamMain));   // the ray bins are shared with the frame path on stream B
+  RT_HIP(syncStreams(c));   // the ray bins are shared with the frame path on stream B
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamMain); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
   float *dR, *dO;

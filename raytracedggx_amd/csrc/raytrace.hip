@@ -449,6 +449,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEv
   const uint32_t splitWork = c->splitWork, splitMaxShift = c->splitMaxShift;
   const uint32_t sliceShift = chooseSliceShift(c, true, G.numTiles * 4u);
   const bool adaptive = splitWork != 0u && sliceShift == 0u;
+  c->lastTraceAdaptive = adaptive;
   // the split list is sized from the demand of an earlier frame (copied back asynchronously, like the ray counters)
   const uint32_t splitCap = !adaptive ? 0u : c->splitCapForced != 0xFFFFFFFFu ? c->splitCapForced
                           : c->splitDemand == 0u ? 0u : ((c->splitDemand + c->splitDemand / 8u + 64u + 31u) / 32u) * 32u;

@@ -73,6 +73,13 @@ struct rtggx_context {
   uint32_t W = 0, H = 0;
   uint32_t rowBegin = 0, rowEnd = 0;
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
+  // Launches with few rays (thin strips, small frames) leave most of the machine idle and last as long as stream B's chain
+  // of dependent kernels: there the visibility pass of frame f+1 runs on a stream of its own (C), beside the traversal
+  // of frame f, instead of behind it.  (On full frames the machine is saturated and this gains nothing.)
+  hipStream_t streamVis = nullptr;
+  hipEvent_t evVis = nullptr;           // completes with the last kernel of the most recent visibility pass, on either stream
+  hipStream_t evVisStream = nullptr;    // the stream the most recent visibility pass ran on (null: none yet)
+  bool lastTraceAdaptive = false;
   bool attachEvents = true;             // RTGGX_ATTACH_EVENTS=0: record the cross-stream events with hipEventRecord instead
   hipEvent_t evAS = nullptr;      // constants uploaded (stream B -> main)
   hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
@@ -172,7 +179,7 @@ void setError(const char* fmt, ...);
 // kernels / launchers implemented in the .hip files
 int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s);
 int uploadScene(rtggx_context* c, hipStream_t s);
-int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s);
+int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
 int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);   // ray generation + traversal
 // `done` (may be null) on the launch functions below: an event that completes with the pass's last kernel.  It rides on that

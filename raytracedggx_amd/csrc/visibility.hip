@@ -14,6 +14,7 @@
 // rasterLarge -- one 64x4 pixel tile per workgroup, one pixel per lane, loops over the queued
 // large triangles (the ground slab's faces) and merges with a plain read-min-write.
 // Roofline: HBM; algorithmic bytes 8 B/pixel (clear) + 8 B/covered fragment.
+#include <hip/hip_ext.h>
 #include "rtggx_context.h"
 
 namespace rt {
@@ -244,7 +245,7 @@ __global__ void packVisDepthKernel(unsigned long long* __restrict__ vd, const ui
   if (i < n) vd[i] = ((unsigned long long)depth[i] << 32) | vis[i];
 }
 
-int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
+int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done) {
   uint32_t rb, re;
   passRows(fp, ROWS_GBUFFER, rb, re);
   const uint32_t begin = rb * fp.W, end = re * fp.W;
@@ -256,9 +257,15 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   if (nt) {
     hipLaunchKernelGGL(rasterSmall, dim3((nt + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->mesh[0].verts, c->mesh[0].indices, c->mesh[0].numTris,
                        c->mesh[1].verts, c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
-    hipLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (re - rb + 3) / 4), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->visDepth,
-                       (const LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
+    if (done && c->attachEvents) {      // the event rides on the pass's last kernel (rtggx_context.h)
+      hipExtLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (re - rb + 3) / 4), dim3(256), 0, s, nullptr, done, 0, (const FrameParams*)(c->dParams + c->slot), rb, re, c->visDepth,
+                            (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity);
+      done = nullptr;
+    } else
+      hipLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (re - rb + 3) / 4), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->visDepth,
+                         (const LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
   }
+  if (done) hipEventRecord(done, s);
   RT_HIP(hipGetLastError());
   return 0;
 }
