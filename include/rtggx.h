@@ -101,7 +101,9 @@ enum {
   RTGGX_BUF_ENV = 18,        /* decoded RGBA16F environment, mip-major, 6 faces per mip */
   RTGGX_BUF_BVH4_NODES0 = 19, /* 128-byte 4-wide nodes of mesh 0, indexed like the binary nodes (odd-depth slots unused, zero): */
   RTGGX_BUF_BVH4_NODES1 = 20, /*   minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4]; ref: >=0 node, <0 ~leaf slot, 0x7FFFFFFF none */
-  RTGGX_BUF_COUNT = 21
+  RTGGX_BUF_BIN_WORK = 21,    /* uint32 per ray bin (8x8-pixel sub-tile; bin = 4 * (tileY * tilesX + tileX) + 2 * subY + subX over 16x16 tiles):
+                                 lane-steps the last traversal spent on the bin's rays; zero unless that launch recorded them (full-size frames) */
+  RTGGX_BUF_COUNT = 22
 };
 
 /* Per-pass GPU timings of the last completed frame, in milliseconds (hipEvent based). */

@@ -15,14 +15,14 @@ LIB_PATH = os.path.join(_HERE, "librtggx.so")
 # buffer ids (rtggx.h)
 BUF_VISIBILITY, BUF_DEPTH, BUF_NORMAL, BUF_ROUGH_METAL, BUF_VELOCITY, BUF_RT_REFL, BUF_RT_DIFF, BUF_TSS0, BUF_TSS1, \
     BUF_FLT_RFL, BUF_FLT_DFF, BUF_BACKBUFFER, BUF_SH_COEFFS, BUF_BVH_NODES0, BUF_BVH_TRIS0, BUF_BVH_NODES1, BUF_BVH_TRIS1, \
-    BUF_TLAS, BUF_ENV, BUF_BVH4_NODES0, BUF_BVH4_NODES1 = range(21)
+    BUF_TLAS, BUF_ENV, BUF_BVH4_NODES0, BUF_BVH4_NODES1, BUF_BIN_WORK = range(22)
 FORMAT_RGBA32F, FORMAT_RGBA16F, FORMAT_BC6H_UF16, FORMAT_BC6H_SF16 = 2, 10, 95, 96
 
 _BUF_DTYPE = {BUF_VISIBILITY: np.uint32, BUF_DEPTH: np.uint32, BUF_NORMAL: np.uint32, BUF_ROUGH_METAL: np.uint16,
               BUF_VELOCITY: np.uint32, BUF_RT_REFL: np.uint32, BUF_RT_DIFF: np.uint32, BUF_TSS0: np.uint64, BUF_TSS1: np.uint64,
               BUF_FLT_RFL: np.uint64, BUF_FLT_DFF: np.uint64, BUF_BACKBUFFER: np.uint32, BUF_SH_COEFFS: np.float32,
               BUF_BVH_NODES0: np.uint32, BUF_BVH_TRIS0: np.uint32, BUF_BVH_NODES1: np.uint32, BUF_BVH_TRIS1: np.uint32,
-              BUF_TLAS: np.float32, BUF_ENV: np.uint16, BUF_BVH4_NODES0: np.uint32, BUF_BVH4_NODES1: np.uint32}
+              BUF_TLAS: np.float32, BUF_ENV: np.uint16, BUF_BVH4_NODES0: np.uint32, BUF_BVH4_NODES1: np.uint32, BUF_BIN_WORK: np.uint32}
 
 EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip", "rtggx_set_stream", "rtggx_set_mesh",
            "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",

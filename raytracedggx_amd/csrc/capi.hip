@@ -495,6 +495,7 @@ static int bufferInfo(rtggx_context* c, int id, void** ptr, size_t* bytes) {
     case RTGGX_BUF_BVH_TRIS0: case RTGGX_BUF_BVH_TRIS1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_TRIS1]; *ptr = m.tris; *bytes = m.tris ? (size_t)m.numTris * 64 : 0; return 0; }
     case RTGGX_BUF_TLAS: *ptr = nullptr; *bytes = 128; return 0;
     case RTGGX_BUF_BVH4_NODES0: case RTGGX_BUF_BVH4_NODES1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH4_NODES1]; *ptr = m.nodes4; *bytes = m.numTris > 1 && m.nodes4 ? (size_t)(m.numTris - 1) * 128 : 0; return 0; }
+    case RTGGX_BUF_BIN_WORK: *ptr = c->binWork; *bytes = (size_t)(((c->W + 15) / 16) * ((c->H + 15) / 16)) * 4u * 4u; return 0;
     case RTGGX_BUF_ENV: *ptr = c->env.texels; *bytes = (size_t)c->env.totalTexels * 8; return 0;
     default: setError("unknown buffer id %d", id); return -1;
   }
