@@ -667,6 +667,31 @@ def test_environment_upload_formats(built):
         ctx.close()
 
 
+def test_bc6h_sf16_dds_file_through_the_host_loader(built, tmp_path):
+    """A BC6H_SF16 cube map file (the blocks of rnl_cross.dds with the DX10 header's format field set to 96: the same bits
+    read as the signed variant) through the host's DDS reader and the GPU decoder, against the oracle's reader and
+    decoder: every texel of all nine mips."""
+    from raytracedggx_amd import app, capi
+    raw = bytearray(open(assets.path("rnl_cross.dds"), "rb").read())
+    assert int.from_bytes(raw[128:132], "little") == 95
+    raw[128:132] = (96).to_bytes(4, "little")
+    dds = tmp_path / "signed_cross.dds"
+    dds.write_bytes(bytes(raw))
+    a = app.RayTracedGGX(["-mesh", assets.path("triangle.obj"), "-env", str(dds), "-width", 64, "-height", 64])
+    o = O.Oracle(64, 64)
+    try:
+        o.set_env_dds(str(dds))
+        _, _, want = o.env_texels()
+        got = a.context.readback(capi.BUF_ENV)
+        np.testing.assert_array_equal(got, want)
+        assert (got[:, :3] & 0x8000).any()               # negative halves do occur: it is the signed decode
+        o2 = O.Oracle(64, 64); o2.set_env_dds(assets.path("rnl_cross.dds"))
+        assert not np.array_equal(o2.env_texels()[2], want)
+        o2.close()
+    finally:
+        a.OnDestroy(); o.close()
+
+
 def test_context_lifecycle_and_mode_changes(built):
     """Contexts can be created and destroyed repeatedly, and the per-frame switches of the sample (the [V] shared-memory
     toggle, metallic changes) can flip between frames without disturbing parity."""
