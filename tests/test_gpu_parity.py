@@ -548,6 +548,30 @@ def test_long_run_past_the_frame_index_wrap(built):
         p.close()
 
 
+def test_deforming_mesh_by_reupload_and_rebuild(built):
+    """SURVEY 8f rank 4, the functional part: a mesh that changes shape every frame (a travelling sine wave through the
+    bunny's vertices) by re-uploading it and rebuilding its acceleration structure (rtggx_set_mesh + rtggx_build_as,
+    both synchronous) -- every frame against the oracle given the same vertices and the same tree."""
+    p = Pair(320, 180, metallic=(1.0, 0.5))
+    try:
+        v0, idx, _ = O.obj_import(assets.path("bunny.obj"))
+        for f in range(4):
+            v = v0.copy()
+            if f:                                                    # frame 0: the mesh as loaded
+                v[:, 0] += 0.35 * np.sin(1.3 * v0[:, 1] + 0.9 * f)
+                v[:, 2] += 0.25 * np.cos(0.8 * v0[:, 1] - 0.7 * f)
+                p.ctx.set_mesh(p.capi.MODEL_OBJ if hasattr(p.capi, "MODEL_OBJ") else 1, v, idx)
+                p.ctx.build_as()
+                p.o.set_mesh(1, v, idx)
+                p.o.set_bvh(1, p.ctx.readback(p.capi.BUF_BVH_NODES1), p.ctx.readback(p.capi.BUF_BVH_TRIS1), p.ctx.bvh_root(1))
+            p.frame()
+            p.check_frame("deforming frame %d" % f)
+        vis0 = p.ctx.readback(p.capi.BUF_VISIBILITY)
+        assert (vis0 >> 24 == 1).sum() > 1000                        # the (deformed) model is on screen
+    finally:
+        p.close()
+
+
 def test_scripted_camera_and_material_track(built, tmp_path):
     """SURVEY 8f rank 3: the sample's interactions as a script (-track file / RayTracedGGX::LoadTrack): an orbit with the
     left button held, a dolly, [DOWN] lowering the ground's metallic (diffuse rays appear), [V] switching the filter
