@@ -85,7 +85,7 @@ static int uploadParamsStreamB(rtggx_context* c) {
 static int ensureParams(rtggx_context* c) { return c->slotUploaded ? 0 : uploadParamsStreamB(c); }
 static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t ni) {
   MeshDev& m = c->mesh[slot];
-  RT_HIP(hipStreamSynchronize(mainStream(c)));
+  RT_HIP(syncStreams(c));       // frames in flight on any of the streams still read the buffers freed below
   if (m.verts) { hipFree(m.verts); m.verts = nullptr; }
   if (m.indices) { hipFree(m.indices); m.indices = nullptr; }
   if (m.nodes) { hipFree(m.nodes); m.nodes = nullptr; }
