@@ -167,7 +167,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
   RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
   c->largeCapacity = 1u << 16;
-  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 8));
+  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 4 * (1 + RT_SETS))); RT_HIP(hipMemset(c->largeCount, 0, 4 * (1 + RT_SETS)));
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
   RT_HIP(hipMalloc(&c->rayCounter32, 1024 * 4)); RT_HIP(hipMemset(c->rayCounter32, 0, 1024 * 4));
   RT_HIP(hipHostMalloc(&c->hostRayCounters, 257 * 4)); c->hostRayCounters[256] = 0; RT_HIP(hipEventCreateWithFlags(&c->evRayCounters, hipEventDisableTiming));   // [0..255] rays; [256..] RT_TRACE_STATS
@@ -186,7 +186,8 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     }
     c->selectSet(0);
     RT_HIP(hipMalloc(&c->binWork, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binWork, 0, (size_t)c->numBinsMax * 4));
-    RT_HIP(hipMalloc(&c->splitList, (size_t)RT_SPLIT_CAP * 4));
+    for (int i = 0; i < RT_SETS; ++i) RT_HIP(hipMalloc(&c->splitListBuf[i], (size_t)RT_SPLIT_CAP * 4));
+    c->selectSet(0);
     c->splitWork = getenv("RTGGX_SPLIT_WORK") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_WORK")) : RT_SPLIT_WORK;
     c->splitMaxShift = getenv("RTGGX_SPLIT_MAX_SHIFT") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_MAX_SHIFT")) : RT_SPLIT_MAX_SHIFT;
     if (c->splitMaxShift > 3u) c->splitMaxShift = 3u;
@@ -226,7 +227,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
-  hipFree(c->binWork); hipFree(c->splitList);
+  hipFree(c->binWork); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
   hipFree(c->stackOverflow); hipFree(c->dummyRecord);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
@@ -343,10 +344,11 @@ int rtggx_render_visibility(rtggx_context* c) {
     if (gpuSideWait) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
     else if (hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
   }
-  // Where the pass runs: on stream C when the launches are small (rtggx_context.h) and the previous frame's traversal does
-  // not use the split list (this pass's first kernel empties it); on stream B otherwise.  Either way the pass follows
-  // the previous one (shared large-triangle list) and ray generation follows it: both through evVis.
-  const bool small = c->streamVis && !c->lastTraceAdaptive && chooseSliceShift(c, true, c->numBinsMax) != 0u;
+  // Where the pass runs: on stream C when the launches are small (rtggx_context.h: few enough rays that the machine is not
+  // saturated), on stream B otherwise.  Either way the pass follows the previous one (shared large-triangle list) and ray
+  // generation follows it: both through evVis.  (The split list the pass's first kernel empties is this set's own.)
+  static const uint32_t visRays = getenv("RTGGX_VIS_STREAM_RAYS") ? (uint32_t)atoi(getenv("RTGGX_VIS_STREAM_RAYS")) : RT_VIS_STREAM_RAYS;
+  const bool small = c->streamVis && (chooseSliceShift(c, true, c->numBinsMax) != 0u || c->lastFrameRays < visRays);
   const hipStream_t s = small ? c->streamVis : c->streamAS;
   if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on the other stream
   if (c->timing) hipEventRecord(c->tev[2], s);
@@ -425,7 +427,7 @@ int rtggx_debug_trace_split(rtggx_context* c, uint32_t workPerWave, uint32_t max
   if (maxShift > 3u) { setError("rtggx_debug_trace_split: max_shift %u > 3", maxShift); return -1; }
   if (capacity > (int)RT_SPLIT_CAP) { setError("rtggx_debug_trace_split: capacity %d > %u", capacity, RT_SPLIT_CAP); return -1; }
   RT_HIP(syncStreams(c));
-  if (lastDemand) RT_HIP(hipMemcpy(lastDemand, c->largeCount + 1, 4, hipMemcpyDeviceToHost));
+  if (lastDemand) RT_HIP(hipMemcpy(lastDemand, c->splitCount, 4, hipMemcpyDeviceToHost));
   c->splitWork = workPerWave; c->splitMaxShift = maxShift;
   c->splitCapForced = capacity < 0 ? 0xFFFFFFFFu : ((uint32_t)capacity / 32u) * 32u;
   return 0;

@@ -453,7 +453,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEv
   // the split list is sized from the demand of an earlier frame (copied back asynchronously, like the ray counters)
   const uint32_t splitCap = !adaptive ? 0u : c->splitCapForced != 0xFFFFFFFFu ? c->splitCapForced
                           : c->splitDemand == 0u ? 0u : ((c->splitDemand + c->splitDemand / 8u + 64u + 31u) / 32u) * 32u;
-  G.binWork = adaptive ? c->binWork : nullptr; G.splitList = c->splitList; G.splitCount = c->largeCount + 1;
+  G.binWork = adaptive ? c->binWork : nullptr; G.splitList = c->splitList; G.splitCount = c->splitCount;
   static const uint32_t frontWork = getenv("RTGGX_SPLIT_FRONT") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_FRONT")) : RT_SPLIT_FRONT;
   G.frontWork = frontWork < splitWork ? frontWork : splitWork;
   G.splitWork = splitWork; G.splitMaxShift = splitMaxShift < 3u ? splitMaxShift : 3u; G.splitCap = splitCap < RT_SPLIT_CAP ? splitCap : RT_SPLIT_CAP;

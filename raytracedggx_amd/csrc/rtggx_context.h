@@ -107,16 +107,19 @@ struct rtggx_context {
   void selectSet(uint32_t i) {
     setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
+    splitList = splitListBuf[i]; splitCount = largeCount ? largeCount + 1 + i : nullptr;
   }
   uint2 *tss[2] = {nullptr, nullptr}, *fltRfl = nullptr, *fltDff = nullptr;
   uint32_t frameParity = 0;
 
   // visibility scratch
   void* largeTris = nullptr;     // LargeTri records
-  uint32_t* largeCount = nullptr;       // [0] entries of largeTris, [1] entries of splitList (both zeroed by clearVisDepth)
+  uint32_t* largeCount = nullptr;       // [0] entries of largeTris, [1 + set] entries of splitList[set] (zeroed by that set's clearVisDepth)
   // Bins whose traversal was expensive in the previous frame are traced by 2, 4 or 8 waves (trace.hip "adaptive split"):
   uint32_t* binWork = nullptr;          // [numBinsMax] lane-steps the trace kernel spent on the bin (read and zeroed by rayGenKernel)
-  uint32_t* splitList = nullptr;        // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a split bin
+  // per input set (the visibility pass of the next frame, which empties its set's list, may run beside this frame's traversal):
+  uint32_t* splitListBuf[RT_SETS] = {}; // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a listed bin
+  uint32_t* splitList = nullptr; uint32_t* splitCount = nullptr;     // the current set's (selectSet)
   uint32_t splitDemand = 0;             // entries the most recent frame whose count has arrived wanted (hostRayCounters[256])
   uint32_t splitCapForced = 0xFFFFFFFFu;   // rtggx_debug_trace_split: fixed capacity instead of the demand-driven one
   uint32_t splitWork = 0, splitMaxShift = 0;   // set at creation (RT_SPLIT_WORK, or RTGGX_SPLIT_WORK / RTGGX_SPLIT_MAX_SHIFT)

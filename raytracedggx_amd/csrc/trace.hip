@@ -382,7 +382,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.tilesX = tilesX; T.tilesY = tilesY;
   T.sliceShift = sliceShift;
   const bool adaptive = splitCap >= 0 && sliceShift == 0u && tilesX != 0u;
-  T.splitList = c->splitList; T.splitCount = c->largeCount + 1;
+  T.splitList = c->splitList; T.splitCount = c->splitCount;
   T.binWork = adaptive ? c->binWork : nullptr; T.splitBlocks = adaptive ? (uint32_t)splitCap / 4u : 0u;
   const uint32_t superTiles = ((tilesX + 7u) / 8u) * ((tilesY + 7u) / 8u);
   const uint32_t grid = T.splitBlocks + ((tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (((numBins + 3u) / 4u + 7u) / 8u) * 8u) << T.sliceShift);   // virtual blocks, a multiple of 8
@@ -390,7 +390,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   else hipLaunchKernelGGL(traceKernel, dim3(grid * (4u / RT_TRACE_WAVES)), dim3(64 * RT_TRACE_WAVES), 0, s, c->dParams + c->slot, T);
   if (countRays && !c->rayCountersInFlight && (c->traceLaunches < 8u || (c->traceLaunches & 15u) == 0u)) {     // the first frames, then every 16th: ray counters and split demand, for later launches
     RT_HIP(hipMemcpyAsync(c->hostRayCounters, c->rayCounter32, 256 * 4, hipMemcpyDeviceToHost, s));
-    RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->largeCount + 1, 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->splitCount, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipEventRecord(c->evRayCounters, s));
     c->rayCountersInFlight = true;
   }

@@ -69,9 +69,9 @@ RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
 
 // First kernel of the pass: clears the target, empties the large-triangle list and -- when the frame's constants have
 // not been uploaded yet -- copies them (912 bytes, passed by value) into their device slot for the kernels that follow.
-__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount,
+__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount, uint32_t* __restrict__ splitCount,
                               FrameParams src, FrameParams* __restrict__ dst) {
-  if (blockIdx.x == 0 && threadIdx.x < 2) largeCount[threadIdx.x] = 0;      // the large-triangle list of rasterSmall and the split list of rayGenKernel start empty
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *largeCount = 0; *splitCount = 0; }      // the large-triangle list of rasterSmall and this set's split list (rayGenKernel) start empty
   if (blockIdx.x == 0 && dst) {
     const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
     uint32_t* d = reinterpret_cast<uint32_t*>(dst);
@@ -250,7 +250,7 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   passRows(fp, ROWS_GBUFFER, rb, re);
   const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
-  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount,
+  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount, c->splitCount,
                      fp, c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot);
   c->slotUploaded = true;
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
