@@ -348,7 +348,11 @@ int rtggx_render_visibility(rtggx_context* c) {
   // saturated), on stream B otherwise.  Either way the pass follows the previous one (shared large-triangle list) and ray
   // generation follows it: both through evVis.  (The split list the pass's first kernel empties is this set's own.)
   static const uint32_t visRays = getenv("RTGGX_VIS_STREAM_RAYS") ? (uint32_t)atoi(getenv("RTGGX_VIS_STREAM_RAYS")) : RT_VIS_STREAM_RAYS;
-  const bool small = c->streamVis && (chooseSliceShift(c, true, c->numBinsMax) != 0u || c->lastFrameRays < visRays);
+  // (with diffuse rays the main stream also runs the two diffuse filter passes and is the longer chain: there the extra
+  //  stream costs 1-2 % at 0.6-0.9 M rays, so beyond small launches it is used for all-metal frames only)
+  const FrameParams& cur = c->slots[c->slot];
+  const bool allMetal = !(cur.mat.RoughMetals[0][1] < 1.0f || cur.mat.RoughMetals[1][1] < 1.0f);
+  const bool small = c->streamVis && (chooseSliceShift(c, true, c->numBinsMax) != 0u || (allMetal && c->lastFrameRays < visRays));
   const hipStream_t s = small ? c->streamVis : c->streamAS;
   if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on the other stream
   if (c->timing) hipEventRecord(c->tev[2], s);
