@@ -458,10 +458,12 @@ def test_free_running_frames_equal_synchronised_frames(built):
     """The host may run ahead of the GPU (three input sets, four constant slots, the fence in rtggx_render_visibility;
     the ray counters and the split-list demand come back asynchronously): 40 frames issued without a single
     synchronisation against the same 40 frames with a sync after each -- every target bit-identical at the end, at a
-    size where the trace launch uses one wave per bin and the adaptive split (1280x720), and at a thin one (1920x64)."""
+    size where the trace launch uses one wave per bin and the adaptive split (1280x720), at a thin one (1920x64) and at the
+    full all-metal frame (three streams at work)."""
     from raytracedggx_amd import app, capi
-    for size in ((1280, 720), (1920, 64)):
-        args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", size[0], "-height", size[1], "-sharedmem", "-metallic", 1.0, 0.5]
+    for size, metallic in (((1280, 720), (1.0, 0.5)), ((1920, 64), (1.0, 0.5)), ((1920, 1080), (1.0, 1.0))):      # the last: all-metal, where the
+        # visibility pass of the next frame runs on its own stream beside a traversal that uses the adaptive split
+        args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", size[0], "-height", size[1], "-sharedmem", "-metallic", metallic[0], metallic[1]]
         a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
         try:
             for f in range(40):
