@@ -132,6 +132,11 @@ int  rtggx_set_strip(rtggx_context* ctx, uint32_t row_begin, uint32_t row_end);
  * to the main stream by events.  NULL (also the handle of the null stream) restores the context's own stream. */
 int  rtggx_set_stream(rtggx_context* ctx, void* hip_stream);
 
+/* The sample's asynchronous-compute toggle (m_asyncCompute, key [A]: RayTracedGGX.cpp:304-353 issues the frame over two
+ * queues, :513-556 as one command list).  enable = 0: every pass is issued to the main stream in submission order (no
+ * stream B / C, no overlap between frames); 1 (default): the multi-stream frame.  Results are bit-identical; synchronises. */
+int  rtggx_set_async_compute(rtggx_context* ctx, int enable);
+
 /* Vertex = {float3 Pos; float3 Nrm} (24 bytes), 32-bit indices, triangle list. */
 int  rtggx_set_mesh(rtggx_context* ctx, uint32_t slot, const float* verts, uint32_t num_verts,
                     const uint32_t* indices, uint32_t num_indices);
@@ -146,6 +151,9 @@ int  rtggx_build_as(rtggx_context* ctx);
 
 /* Per-frame constants; copied into the next slot of a ring of RayTracer::FrameCount + 1 (= 4). */
 int  rtggx_update_frame(rtggx_context* ctx, const RtggxFrameConstants* constants);
+/* Refreshes the TLAS (the two world->object matrices) from the constants of the current slot.  May be called before or
+ * after rtggx_render_visibility of the same frame (the sample overlaps the two on different queues); rtggx_ray_trace sends
+ * the refreshed constants to the device again when the visibility pass had already carried the slot there. */
 int  rtggx_update_as(rtggx_context* ctx);
 int  rtggx_transform_sh(rtggx_context* ctx);
 /* Starts a frame: advances to the next of RayTracer::FrameCount (= 3) input sets (G-buffer, traced images, ray bins).  All

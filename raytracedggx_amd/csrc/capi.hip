@@ -30,7 +30,7 @@ int uploadScene(rtggx_context* c, hipStream_t s) {
   Scene sc;
   for (int i = 0; i < 2; ++i) { sc.verts[i] = c->mesh[i].verts; sc.idx[i] = c->mesh[i].indices; sc.nodes[i] = c->mesh[i].nodes; sc.tris[i] = c->mesh[i].tris; sc.root[i] = c->mesh[i].root; }
   sc.env = c->env.texels; sc.envSize = c->env.size; sc.envMips = c->env.mips;
-  for (int m = 0; m < 12; ++m) sc.mipOffset[m] = c->env.mipOffset[m];
+  for (int m = 0; m < 16; ++m) sc.mipOffset[m] = c->env.mipOffset[m];
   sc.sh = c->sh; sc.cosSin = c->cosSinTab;
   RT_HIP(hipMemcpyAsync(c->dScene, &sc, sizeof sc, hipMemcpyHostToDevice, s));
   RT_HIP(hipStreamSynchronize(s));
@@ -66,8 +66,8 @@ static void invert4x4(const float* a /*row-major*/, float* out) {
 
 static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
 static hipError_t syncStreams(rtggx_context* c) {
-  hipError_t e = c->streamVis ? hipStreamSynchronize(c->streamVis) : hipSuccess;
-  if (e == hipSuccess) e = hipStreamSynchronize(c->streamAS);
+  hipError_t e = c->ownVis ? hipStreamSynchronize(c->ownVis) : hipSuccess;
+  if (e == hipSuccess) e = hipStreamSynchronize(c->ownAS);
   if (e == hipSuccess) e = hipStreamSynchronize(c->streamMain);
   return e;
 }
@@ -143,11 +143,11 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   const int prioMode = getenv("RTGGX_PRIORITY_MODE") ? atoi(getenv("RTGGX_PRIORITY_MODE")) : 1;      // 0: B high, main low; 1: equal; 2: main high, B low
   const int prioMid = (prioLeast + prioGreatest) / 2;
   RT_HIP(hipStreamCreateWithPriority(&c->ownMain, hipStreamNonBlocking, prioMode == 0 ? prioLeast : prioMode == 2 ? prioGreatest : prioMid));
-  RT_HIP(hipStreamCreateWithPriority(&c->streamAS, hipStreamNonBlocking, prioMode == 0 ? prioGreatest : prioMode == 2 ? prioLeast : prioMid));
-  c->streamMain = c->ownMain;
+  RT_HIP(hipStreamCreateWithPriority(&c->ownAS, hipStreamNonBlocking, prioMode == 0 ? prioGreatest : prioMode == 2 ? prioLeast : prioMid));
+  c->streamMain = c->ownMain; c->streamAS = c->ownAS;
   c->attachEvents = !(getenv("RTGGX_ATTACH_EVENTS") && atoi(getenv("RTGGX_ATTACH_EVENTS")) == 0);
   if (!(getenv("RTGGX_VIS_STREAM") && atoi(getenv("RTGGX_VIS_STREAM")) == 0))
-    RT_HIP(hipStreamCreateWithPriority(&c->streamVis, hipStreamNonBlocking, prioMid));
+    { RT_HIP(hipStreamCreateWithPriority(&c->ownVis, hipStreamNonBlocking, prioMid)); c->streamVis = c->ownVis; }
   RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
@@ -234,7 +234,7 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
   hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
-  hipStreamDestroy(c->ownMain); hipStreamDestroy(c->streamAS); if (c->streamVis) hipStreamDestroy(c->streamVis);
+  hipStreamDestroy(c->ownMain); hipStreamDestroy(c->ownAS); if (c->ownVis) hipStreamDestroy(c->ownVis);
   hipEventDestroy(c->evVis);
   delete c;
 }
@@ -251,6 +251,21 @@ int rtggx_set_stream(rtggx_context* c, void* stream) {
   RT_HIP(syncStreams(c));
   if (stream) { c->streamMain = (hipStream_t)stream; c->externalStream = true; }
   else { c->streamMain = c->ownMain; c->externalStream = false; }
+  if (!c->asyncCompute) c->streamAS = c->streamMain;
+  return 0;
+}
+
+// The sample's [A] toggle / m_asyncCompute (RayTracedGGX.cpp:304-353 vs the single command list of :513-556).  Off: every
+// pass of a frame is issued to ONE stream in submission order -- no stream B, no stream C, no overlap between the
+// ray-tracing half of one frame and the denoising half of the previous one.  Results are identical either way.
+int rtggx_set_async_compute(rtggx_context* c, int enable) {
+  RT_CHECK_CTX(c);
+  if ((enable != 0) == c->asyncCompute) return 0;
+  RT_HIP(syncStreams(c));
+  c->asyncCompute = enable != 0;
+  c->streamAS = c->asyncCompute ? c->ownAS : c->streamMain;
+  c->streamVis = c->asyncCompute ? c->ownVis : nullptr;
+  c->evVisStream = nullptr;
   return 0;
 }
 
@@ -313,6 +328,10 @@ int rtggx_update_as(rtggx_context* c) {
     invert4x4(&w.m[0][0], c->invWorld[i]);
   }
   memcpy(fp.invWorld, c->invWorld, sizeof fp.invWorld);
+  // Legal call order "render_visibility before update_as" (the sample's two queues overlap them, RayTracedGGX.cpp:304-339):
+  // the visibility pass has then carried this slot to the device with the PREVIOUS frame's TLAS.  Mark it stale, so that
+  // rtggx_ray_trace (ensureParams) sends it again, behind the visibility pass, before anything reads invWorld.
+  c->slotUploaded = false;
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   // The constants (with the refreshed TLAS) ride to the device with the first kernel of the visibility pass, which
   // follows on stream B (rtggx_render_visibility); a caller that traces without a visibility pass gets them through
@@ -355,6 +374,9 @@ int rtggx_render_visibility(rtggx_context* c) {
   const bool small = c->streamVis && (chooseSliceShift(c, true, c->numBinsMax) != 0u || (allMetal && c->lastFrameRays < visRays));
   const hipStream_t s = small ? c->streamVis : c->streamAS;
   if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on the other stream
+  // constants already on their way on stream B (timing mode uploads them in rtggx_update_as): a pass on stream C reads
+  // dParams[slot] and has to be ordered behind that upload (evAS); on stream B it follows it anyway
+  if (c->slotUploaded && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evAS, 0));
   if (c->timing) hipEventRecord(c->tev[2], s);
   const int r = launchVisibility(c, c->slots[c->slot], s, c->streamVis ? c->evVis : nullptr);
   if (c->streamVis) c->evVisStream = s;

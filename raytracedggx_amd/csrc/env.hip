@@ -161,7 +161,8 @@ __global__ void f32ToF16Kernel(const float* __restrict__ src, uint2* __restrict_
 }
 
 int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* hostData, size_t bytes, hipStream_t s) {
-  if (size == 0 || mips == 0 || mips > 12 || (size >> (mips - 1)) == 0) { setError("rtggx_set_env: bad size/mips"); return -1; }
+  // cubes up to 8192^2 (the reference's maxsize, RayTracer.cpp:146) with at most a full mip chain: log2(size) + 1 <= 14 levels
+  if (size == 0 || size > 8192 || mips == 0 || mips > 14 || (size >> (mips - 1)) == 0) { setError("rtggx_set_env: bad size/mips (size %u, %u mips)", size, mips); return -1; }
   size_t perFace = 0; uint64_t texels = 0;
   for (uint32_t m = 0; m < mips; ++m) {
     const uint32_t sz = size >> m;

@@ -54,7 +54,7 @@ struct FrameParams {
 struct Scene {
   const float* verts[2]; const uint32_t* idx[2];
   const BvhNode* nodes[2]; const BvhTri* tris[2]; int32_t root[2];
-  const uint2* env; uint32_t envSize, envMips; uint32_t mipOffset[12];
+  const uint2* env; uint32_t envSize, envMips; uint32_t mipOffset[16];
   const float* sh; const float* cosSin;
 };
 
@@ -73,6 +73,8 @@ struct rtggx_context {
   uint32_t W = 0, H = 0;
   uint32_t rowBegin = 0, rowEnd = 0;
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
+  hipStream_t ownAS = nullptr, ownVis = nullptr;   // the context's own stream B / stream C; streamAS / streamVis alias streamMain / null while
+  bool asyncCompute = true;                        // rtggx_set_async_compute(0) is in force (the sample's [A] toggle: one queue, submission order)
   // Launches with few rays (thin strips, small frames) leave most of the machine idle and last as long as stream B's chain
   // of dependent kernels: there the visibility pass of frame f+1 runs on a stream of its own (C), beside the traversal
   // of frame f, instead of behind it.  (On full frames the machine is saturated and this gains nothing.)

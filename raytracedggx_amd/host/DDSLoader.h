@@ -40,7 +40,9 @@ class Loader {
     else if ((pfFlags & 0x4u) && fourCC == 116) format = 2;      // D3DFMT_A32B32G32R32F
     else { error = "unsupported DDS pixel format"; return false; }
     if (!cube || width != height) { error = "not a cube map"; return false; }
-    if (width > 8192) { error = "cube map larger than 8192"; return false; }
+    if (width == 0 || width > 8192) { error = "cube map size out of range (1..8192)"; return false; }
+    // the header's mip count is untrusted: at most a full chain (size >> (mips - 1) must still be >= 1)
+    if (mips > 14 || (width >> (mips - 1)) == 0) { error = "mip count " + std::to_string(mips) + " exceeds the full chain of a " + std::to_string(width) + " cube"; return false; }
     if (format != 95 && format != 96 && format != 10 && format != 2) { error = "unsupported DXGI format " + std::to_string(format); return false; }
     size_t perFace = 0;
     for (uint32_t m = 0; m < mips; ++m) {

@@ -31,6 +31,7 @@ void RayTracedGGX::OnInit() {
   if (!m_rayTracer->BuildAccelerationStructures()) throw std::runtime_error("BuildAccelerationStructures failed: " + m_rayTracer->GetLastError());
   if (!m_rayTracer->Postinit()) throw std::runtime_error("Postinit failed");
   if (m_hasMetallicOverride) for (uint32_t i = 0; i < RayTracer::NUM_MESH; ++i) m_rayTracer->SetMetallic(i, m_metallics[i]);
+  m_rayTracer->SetAsyncCompute(m_asyncCompute != 0);   // -sync: one stream, submission order (the sample's single command list)
 
   InitCamera();
   if (!m_trackFileName.empty() && !LoadTrack(m_trackFileName)) throw std::runtime_error("cannot read track " + m_trackFileName);
@@ -92,7 +93,7 @@ void RayTracedGGX::OnKeyUp(uint8_t key) {
     case 0x26: metallic = std::min(metallic + 0.25f, 1.0f); m_rayTracer->SetMetallic(m_currentMesh, metallic); break;
     case 0x28: metallic = std::max(metallic - 0.25f, 0.0f); m_rayTracer->SetMetallic(m_currentMesh, metallic); break;
     case 'V': m_useSharedMem = !m_useSharedMem; break;
-    case 'A': m_asyncCompute = !m_asyncCompute; break;
+    case 'A': m_asyncCompute = !m_asyncCompute; m_rayTracer->SetAsyncCompute(m_asyncCompute != 0); break;   // RayTracedGGX.cpp:394-396
     default: break;
   }
 }

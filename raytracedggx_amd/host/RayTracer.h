@@ -35,6 +35,9 @@ class RayTracer {
   bool Postinit();
 
   void SetMetallic(uint32_t meshIdx, float metallic);
+  // m_asyncCompute of the sample (RayTracedGGX.h:118): true = the multi-stream frame (its two queues), false = one stream in
+  // submission order (its single command list, RayTracedGGX.cpp:513-556)
+  void SetAsyncCompute(bool asyncCompute);
   void UpdateFrame(uint8_t frameIndex, const xm::Float3& eyePt, const xm::Matrix& viewProj, float timeStep);
   void TransformSH();
   void Render(uint8_t frameIndex);

@@ -7,7 +7,7 @@ pass); nothing is exchanged for the spatial passes.  The ONE real exchange step 
 TemporalSSOut rows next to the strip boundary are produced by the neighbouring rank, and the next frame's
 reprojection reads them.  After each frame every rank sends its HISTORY_APRON boundary rows of
 TemporalSSOut[parity] to its two neighbours and receives theirs -- point-to-point over xGMI
-(RCCL send/recv, one group launch per frame, 2 x 17 rows x W x 8 B), together with the gather of the
+(RCCL send/recv, one group launch per frame, 2 x 18 rows x W x 8 B), together with the gather of the
 tone-mapped strips onto rank 0.  The exchange is issued right after the tone map and is only needed by
 the next frame's temporal pass, so it overlaps that frame's visibility, ray trace and spatial passes.
 torch.distributed makes the rendezvous; the per-frame sends and receives go to RCCL directly (rccl.py: the
@@ -22,7 +22,7 @@ import numpy as np
 
 from . import app, capi
 
-HISTORY_APRON = 17   # rows: bilinear footprint (1) + the largest vertical reprojection distance handled exactly (16 px/frame)
+HISTORY_APRON = 18   # rows: temporal apron (1: the pass also computes rows b-1 and e for the tone map) + the largest vertical reprojection handled exactly (16 px/frame) + bilinear footprint (1)
 
 
 class _DeviceArray:

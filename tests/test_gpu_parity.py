@@ -478,7 +478,7 @@ def test_free_running_frames_equal_synchronised_frames(built):
             a.OnDestroy(); b.OnDestroy()
 
 
-@pytest.mark.parametrize("world,balance", [(2, False), (8, False), (8, True), (5, [0, 40, 57, 120, 190, 272])],
+@pytest.mark.parametrize("world,balance", [(2, False), (8, False), (8, True), (5, [0, 40, 58, 120, 190, 272])],
                          ids=["2 strips", "8 strips", "8 balanced strips", "5 uneven strips"])
 def test_strip_exchange_through_rccl_send_recv(built, world, balance):
     """The direct RCCL path of the strip exchange (raytracedggx_amd/rccl.py: ncclSend/ncclRecv in one group on the
@@ -489,7 +489,7 @@ def test_strip_exchange_through_rccl_send_recv(built, world, balance):
     two whole frames and cuts the frame where the covered pixels balance, as bench.py does for N > 1."""
     import torch
     from raytracedggx_amd import capi, rccl
-    from raytracedggx_amd.strips import StripRenderer
+    from raytracedggx_amd.strips import HISTORY_APRON, StripRenderer
     W, H = 480, 272
     mesh, env = assets.path("bunny.obj"), assets.path("rnl_cross.dds")
     strips = []
@@ -525,7 +525,7 @@ def test_strip_exchange_through_rccl_send_recv(built, world, balance):
             torch.cuda.synchronize(); full.context.sync()
             np.testing.assert_array_equal(strips[0].context.readback(capi.BUF_BACKBUFFER), full.context.readback(capi.BUF_BACKBUFFER), err_msg="frame %d" % f)
             for k, s in enumerate(strips):          # each strip's history, with the apron rows it received, equals the full frame's
-                lo, hi = max(s.b - 17, 0), min(s.e + 17, H)
+                lo, hi = max(s.b - HISTORY_APRON, 0), min(s.e + HISTORY_APRON, H)
                 bid = capi.BUF_TSS1 if s.context.frame_parity() else capi.BUF_TSS0
                 np.testing.assert_array_equal(s.context.readback(bid)[lo:hi], full.context.readback(bid)[lo:hi], err_msg="history of strip %d, frame %d" % (k, f))
     finally:
