@@ -20,17 +20,21 @@ def _write_atomic(path, data, mode):
 
 
 def asset_dir():
-    """Directory laid out like the reference's Bin/: Assets/bunny.obj, Assets/dragon.obj, Assets/rnl_cross.dds."""
+    """Directory laid out like the reference's Bin/: Assets/bunny.obj, Assets/dragon.obj, Assets/TuringBowl.obj, Assets/rnl_cross.dds."""
     d = os.path.join(_CACHE, "Assets")
     os.makedirs(d, exist_ok=True)
-    need = [n for n in ("bunny.obj", "dragon.obj", "rnl_cross.dds", "triangle.obj") if not os.path.exists(os.path.join(d, n))]
+    need = [n for n in ("bunny.obj", "dragon.obj", "TuringBowl.obj", "rnl_cross.dds", "triangle.obj") if not os.path.exists(os.path.join(d, n))]
     if need:
         z = np.load(_NPZ)
-        for name in ("bunny", "dragon"):
+        for name in ("bunny", "dragon", "TuringBowl"):
             if name + ".obj" in need:
                 v, f = z[name + "_v"], z[name + "_f"]
                 lines = ["v %.9g %.9g %.9g" % tuple(float(x) for x in row) for row in v]
-                lines += ["f %d %d %d" % tuple(int(x) for x in row) for row in f]
+                if name + "_vn" in z.files:          # "f a//na b//nb c//nc" (TuringBowl: per-corner normals, vertex splitting)
+                    lines += ["vn %.9g %.9g %.9g" % tuple(float(x) for x in row) for row in z[name + "_vn"]]
+                    lines += ["f %d//%d %d//%d %d//%d" % tuple(int(x) for x in row.reshape(-1)) for row in f]
+                else:
+                    lines += ["f %d %d %d" % tuple(int(x) for x in row) for row in f]
                 _write_atomic(os.path.join(d, name + ".obj"), "\n".join(lines) + "\n", "w")
         if "rnl_cross.dds" in need:
             _write_atomic(os.path.join(d, "rnl_cross.dds"), z["rnl_cross_dds"].tobytes(), "wb")

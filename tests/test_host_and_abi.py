@@ -53,7 +53,7 @@ def test_product_fails_loudly_without_gpu(built):
 def test_host_obj_importer_matches_golden_and_oracle(built):
     from raytracedggx_amd import app
     facts = json.load(open(os.path.join(ROOT, "tests", "golden", "obj_import.json")))
-    for name in ("bunny", "dragon"):
+    for name in ("bunny", "dragon", "TuringBowl"):
         v, i, aabb = app.obj_import(assets.path(name + ".obj"))
         assert "%08x" % assets.fnv1a32(i.tobytes()) == facts[name]["fnv_indices"]
         assert "%08x" % assets.fnv1a32(v.tobytes()) == facts[name]["fnv_verts"]

@@ -57,7 +57,7 @@ def test_incremental_halton(built):
 def test_obj_import_golden_facts(built):
     # XUSGObjLoader.cpp:18-40, 72-431 -- facts recorded from the reference's own importer
     facts = json.load(open(os.path.join(HERE, "golden", "obj_import.json")))
-    for name in ("bunny", "dragon"):
+    for name in ("bunny", "dragon", "TuringBowl"):
         f = facts[name]
         v, i, aabb = O.obj_import(assets.path(name + ".obj"))
         assert v.shape == (f["num_verts"], 6) and i.size == f["num_indices"]
