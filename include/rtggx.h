@@ -126,6 +126,13 @@ void rtggx_destroy(rtggx_context* ctx);
  * filters need) are not touched.  Default: the whole frame. */
 int  rtggx_set_strip(rtggx_context* ctx, uint32_t row_begin, uint32_t row_end);
 
+/* Strips only.  The temporal pass reprojects last frame's TemporalSSOut; rows next to a strip edge come from the neighbouring
+ * rank, which the caller delivers between frames (`rows` beyond each edge; default 18 = 16 px of vertical motion per frame +
+ * the bilinear tap + the pass's own 1-row apron).  rtggx_history_overreach returns the largest number of rows by which a
+ * history tap read BEYOND the delivered rows since the last reset (0: every frame equals the single-GPU frame); synchronises. */
+int  rtggx_set_history_apron(rtggx_context* ctx, uint32_t rows);
+int  rtggx_history_overreach(rtggx_context* ctx, uint32_t* rows, int reset);
+
 /* Make an externally owned hipStream_t the context's MAIN stream: shading, denoise and tone map run on it, and
  * every result the caller may read (traced images, filtered images, back buffer) is produced in its order.  The
  * visibility pass, ray generation and traversal keep running ahead on the context's internal stream B, joined

@@ -29,7 +29,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split",
-           "rtggx_set_async_compute"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach"]
 
 
 class Timings(C.Structure):
@@ -57,6 +57,8 @@ def load():
     L.rtggx_set_strip.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.rtggx_set_stream.argtypes = [vp, vp]
     L.rtggx_set_async_compute.argtypes = [vp, C.c_int]
+    L.rtggx_set_history_apron.argtypes = [vp, C.c_uint32]
+    L.rtggx_history_overreach.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     L.rtggx_set_mesh.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
     L.rtggx_set_env.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp, C.c_size_t]
     L.rtggx_set_material.argtypes = [vp, C.c_uint32, vp, C.c_float, C.c_float]
@@ -120,6 +122,15 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._check(self.L.rtggx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def set_history_apron(self, rows):
+        self._check(self.L.rtggx_set_history_apron(self.h, int(rows)))
+
+    def history_overreach(self, reset=True):
+        """Rows by which a history tap read beyond the delivered apron since the last reset (strips; 0 = exact)."""
+        n = C.c_uint32()
+        self._check(self.L.rtggx_history_overreach(self.h, C.byref(n), int(reset)))
+        return n.value
 
     def set_async_compute(self, enable):
         self._check(self.L.rtggx_set_async_compute(self.h, int(bool(enable))))

@@ -194,6 +194,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     RT_HIP(hipMalloc(&c->dEnvMipOffset, 16 * 4)); RT_HIP(hipMemset(c->dEnvMipOffset, 0, 16 * 4));
     RT_HIP(hipMalloc(&c->dummyRecord, 128)); RT_HIP(hipMemset(c->dummyRecord, 0, 128));
   }
+  RT_HIP(hipMalloc(&c->histReach, 4)); RT_HIP(hipMemset(c->histReach, 0, 4));
   RT_HIP(hipMalloc(&c->sh, 27 * 4)); RT_HIP(hipMemset(c->sh, 0, 27 * 4));
   RT_HIP(hipMalloc(&c->cosSinTab, 512 * 4));
   RT_HIP(hipMalloc(&c->dParams, RT_SLOTS * sizeof(FrameParams)));
@@ -228,7 +229,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
   hipFree(c->binWork); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
-  hipFree(c->stackOverflow); hipFree(c->dummyRecord);
+  hipFree(c->stackOverflow); hipFree(c->dummyRecord); hipFree(c->histReach);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
@@ -243,6 +244,23 @@ int rtggx_set_strip(rtggx_context* c, uint32_t rowBegin, uint32_t rowEnd) {
   RT_CHECK_CTX(c);
   if (rowBegin > rowEnd || rowEnd > c->H) { setError("rtggx_set_strip: bad rows [%u,%u) for height %u", rowBegin, rowEnd, c->H); return -1; }
   c->rowBegin = rowBegin; c->rowEnd = rowEnd;
+  return 0;
+}
+
+// Multi-GPU strips: the caller exchanges `rows` rows of TemporalSSOut beyond each strip edge between frames.  The
+// temporal pass reports reprojections that read further than that (rtggx_history_overreach): such frames differ from the
+// single-GPU frame, and the caller widens the apron or reports it.
+int rtggx_set_history_apron(rtggx_context* c, uint32_t rows) {
+  RT_CHECK_CTX(c);
+  c->historyApron = rows;
+  return 0;
+}
+int rtggx_history_overreach(rtggx_context* c, uint32_t* rows, int reset) {
+  RT_CHECK_CTX(c);
+  if (!rows) { setError("rtggx_history_overreach: null result"); return -1; }
+  RT_HIP(syncStreams(c));
+  RT_HIP(hipMemcpy(rows, c->histReach, 4, hipMemcpyDeviceToHost));
+  if (reset) RT_HIP(hipMemset(c->histReach, 0, 4));
   return 0;
 }
 

@@ -58,6 +58,9 @@ struct Targets {
   const uint32_t* rtRefl; const uint32_t* rtDiff;
   uint2* scratch; const uint2* history; uint2* fltRfl; uint2* fltDff; uint32_t* backbuffer;
   int W, H, rowBegin, rowEnd;
+  // Strips of a multi-GPU frame: rows [histLo, histHi) of `history` are valid on this rank (its own rows + the apron its
+  // neighbours delivered).  A reprojection that reads beyond them records by how many rows (histReach; null on whole frames).
+  int histLo, histHi; uint32_t* histReach;
 };
 
 #define RT_LOG2E 1.44269504088896341f
@@ -318,6 +321,10 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     const int iy0 = y0 < 0.0f ? 0 : (y0 > (float)(H - 1) ? H - 1 : (int)y0);
     const int iy1 = y0 + 1.0f < 0.0f ? 0 : (y0 + 1.0f > (float)(H - 1) ? H - 1 : (int)(y0 + 1.0f));
     const float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+    if (T.histReach != nullptr) {      // history-apron guard (SURVEY 8e "clamp and report"): rows this rank does not hold
+      const int over = max(T.histLo - iy0, iy1 - (T.histHi - 1));
+      if (over > 0) atomicMax(T.histReach, (uint32_t)over);
+    }
     const uint2* h00 = T.history + (size_t)iy0 * W + ix0; const uint2* h10 = T.history + (size_t)iy0 * W + ix1;
     const uint2* h01 = T.history + (size_t)iy1 * W + ix0; const uint2* h11 = T.history + (size_t)iy1 * W + ix1;
     if (plain) {      // only the alpha (history length) is needed
@@ -450,6 +457,10 @@ static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass
   T.W = (int)fp.W; T.H = (int)fp.H;
   uint32_t rb, re; passRows(fp, pass, rb, re);
   T.rowBegin = (int)rb; T.rowEnd = (int)re;
+  const bool strip = fp.rowBegin > 0u || fp.rowEnd < fp.H;
+  T.histLo = (int)(fp.rowBegin > c->historyApron ? fp.rowBegin - c->historyApron : 0u);
+  T.histHi = (int)(fp.rowEnd + c->historyApron < fp.H ? fp.rowEnd + c->historyApron : fp.H);
+  T.histReach = strip ? c->histReach : nullptr;
   return T;
 }
 

@@ -72,6 +72,8 @@ struct rtggx_context {
   int device = 0;
   uint32_t W = 0, H = 0;
   uint32_t rowBegin = 0, rowEnd = 0;
+  uint32_t historyApron = 18;           // rows of TemporalSSOut beyond the strip the caller delivers between frames (rtggx_set_history_apron)
+  uint32_t* histReach = nullptr;        // device word: the furthest a history tap reached beyond them, in rows (temporalKernel)
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
   hipStream_t ownAS = nullptr, ownVis = nullptr;   // the context's own stream B / stream C; streamAS / streamVis alias streamMain / null while
   bool asyncCompute = true;                        // rtggx_set_async_compute(0) is in force (the sample's [A] toggle: one queue, submission order)

@@ -106,15 +106,19 @@ class StripRenderer:
     SKY_ROW_WEIGHT = 0.3       # cost of a row = covered pixels + this x width (rows without a surface are not free); 0.05 .. 0.6 tried
 
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
-                 transport=None, torch_buffers=None, balance=False):
+                 transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON):
         """dist: torch.distributed (one process per GPU).  transport: instead of dist, a callable
         transport(renderer, plan) that carries out the plan some other way (tests drive several strips from one process).
         torch_buffers: wrap the exchanged targets as torch tensors and render on torch's current stream (default: only
         when dist is used); with a transport it lets a test move the rows with torch copies on that stream.
         balance: False = equal strips; a list of world + 1 row numbers = these boundaries; True = every rank first renders
         PROFILE_FRAMES full frames and cuts the frame where the covered pixels (= rays, the expensive rows) balance --
-        rendering is deterministic, so all ranks arrive at the same boundaries without talking to each other."""
+        rendering is deterministic, so all ranks arrive at the same boundaries without talking to each other.
+        apron: history rows exchanged beyond each strip edge (HISTORY_APRON = 18 covers 16 px of vertical reprojection per
+        frame).  A faster motion -- an orbit drag of a -track script -- makes the strips differ from the single-GPU frame:
+        the temporal pass detects that (history_overreach() > 0), and a wider apron, the same on every rank, is the remedy."""
         self.W, self.H, self.rank, self.world, self.dist, self.transport = width, height, rank, world, dist, transport
+        self.apron = int(apron)
         args = ["-mesh", mesh_path] + ([str(x) for x in pos_scale] if pos_scale else []) + \
                ["-env", env_path, "-width", width, "-height", height, "-device", device] + list(extra_args)
         self.app = app.RayTracedGGX(args)
@@ -126,9 +130,10 @@ class StripRenderer:
                 raise ValueError("balance: %d boundaries from 0 to %d expected, got %s" % (world + 1, height, self.bounds))
         self.b, self.e = strip_rows(height, rank, world, self.bounds)
         if world > 1:
-            if self.e - self.b < HISTORY_APRON:
-                raise ValueError("strips of %d rows are thinner than the %d-row history apron" % (self.e - self.b, HISTORY_APRON))
+            if self.e - self.b < self.apron:
+                raise ValueError("strips of %d rows are thinner than the %d-row history apron" % (self.e - self.b, self.apron))
             self.context.set_strip(self.b, self.e)
+            self.context.set_history_apron(self.apron)
             if transport is None or torch_buffers:
                 import torch
                 self.torch = torch
@@ -163,7 +168,7 @@ class StripRenderer:
             self.render()
         self.context.sync()
         covered = (self.context.readback(capi.BUF_VISIBILITY) != 0).sum(axis=1)
-        return balanced_bounds(covered + self.SKY_ROW_WEIGHT * self.W, world)
+        return balanced_bounds(covered + self.SKY_ROW_WEIGHT * self.W, world, min_rows=self.apron)
 
     # -- one frame --------------------------------------------------------------------------------------
     def frame(self):
@@ -178,16 +183,16 @@ class StripRenderer:
         if self.world == 1:
             return
         if self.transport is not None:
-            self.transport(self, exchange_plan(self.H, self.rank, self.world, bounds=self.bounds))
+            self.transport(self, exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds))
             return
         parity = self.context.frame_parity()
         if self._comm is not None:
             if self._ops[parity] is None:      # (is_send, pointer, bytes, peer), built once per history target
-                self._ops[parity] = self.raw_ops(exchange_plan(self.H, self.rank, self.world, bounds=self.bounds), parity)
+                self._ops[parity] = self.raw_ops(exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds), parity)
             self._comm.exchange(self._ops[parity], self.stream.cuda_stream)
             return
         if self._ops[parity] is None:          # built once per history target: the per-frame host cost is the batch call alone
-            self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world, bounds=self.bounds), self.exchange_buffers())
+            self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds), self.exchange_buffers())
         with self.torch.cuda.stream(self.stream):
             run_exchange(self.dist, None, None, ops=self._ops[parity])
 
@@ -198,6 +203,11 @@ class StripRenderer:
     def exchange_buffers(self):
         """The torch views of the two exchanged targets (this frame's temporal result, the back buffer)."""
         return {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer}
+
+    def history_overreach(self, reset=True):
+        """Rows by which this rank's temporal pass read history beyond the exchanged apron since the last reset (synchronises).
+        0: every frame so far equals the single-GPU frame; otherwise the motion was faster than `apron` covers."""
+        return self.context.history_overreach(reset) if self.world > 1 else 0
 
     # -- statistics --------------------------------------------------------------------------------------
     def rays_traced_since_reset(self):
