@@ -3,20 +3,26 @@
 
   metric   : Mrays/s (+ ms/frame in `ms_per_step`), bunny + rnl env, 1920x1080, 1spp + full denoise chain
   step     : one frame = RayTracedGGX::OnUpdate + OnRender (visibility -> ray trace -> 4 spatial passes -> temporal -> tone map)
-  N GPUs   : the SAME 1920x1080 frame sharded by row strips, one process per GPU (torchrun), history-apron
-             exchange over RCCL + frame gather on rank 0 ("scaling": "strong")
+  N GPUs   : the SAME 1920x1080 frame sharded by row strips, one process per GPU, history-apron exchange over RCCL + frame
+             gather on rank 0 ("scaling": "strong").  Started by a launcher (torch.distributed.run sets RANK / LOCAL_RANK /
+             WORLD_SIZE / MASTER_*) this process is one rank; started plainly with --gpus N > 1 it becomes a LAUNCHER: it
+             starts N fresh child processes (one rank each) before anything here has touched the GPU, relays rank 0's JSON
+             line and exits with the worst child's code.
   value    : non-degenerate rays traced by all ranks in the K timed frames / max-over-ranks wall time
   roofline : the dominant kernel (rt::traceKernel: BVH traversal of the binned rays), algorithmic bytes per launch
              (DESIGN.md "Roofline accounting") / its average duration from HIP events recorded on the launching stream
              (stream B); `traffic` = HBM-side bytes per launch from the newest profiles/*_pmc_traffic.json;
-             `roofline.frame` = SURVEY 8(d)'s whole-frame bytes / frame time
-  cpu_baseline : the scalar C++ oracle re-tracing the SAME BVH arrays on the host cores, bounded sample (rank 0, N=1 only)
+             `peak_measured` = a float4 copy kernel on this box; `roofline.frame` = SURVEY 8(d)'s whole-frame bytes / frame time
+  cpu_baseline : the scalar C++ oracle re-tracing the SAME BVH arrays on the host cores, bounded sample (rank 0, N=1 only):
+             all threads, and one thread
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080 --mesh bunny.obj]
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,9 +31,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_CYCLES_PER_WAVE_INSTRUCTION = 2.0   # v_fma_f32 wave64 on a SIMD-32 with >= 2 waves resident (same guide; tools/microbench/valu_issue.hip measures it)
+SHADER_CLOCK_HZ = 2.4e9
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
@@ -36,9 +44,102 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--mesh", default="bunny.obj")
     ap.add_argument("--metallic", type=float, nargs=2, default=None, help="metallic of ground and model (default: the sample's 1 1 = no diffuse rays)")
+    ap.add_argument("--deform", type=float, default=0.0, help="amplitude of the breathing-model animation (-deform): new vertices and an asynchronous BVH refit every frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-frames", type=int, default=4, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
+    ap.add_argument("--no-balance", action="store_true", help="N > 1: equal strips instead of strips balanced by covered pixels")
+    ap.add_argument("--stub", action="store_true", help="no GPU: a stand-in renderer over gloo, to exercise the launcher and the multi-rank protocol (tests)")
+    return ap.parse_args(argv)
+
+
+# =====================================================================================================================
+# launcher: `python bench.py --gpus N` without a launcher's environment
+# =====================================================================================================================
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """Start args.gpus children -- fresh interpreters, one rank each, LOCAL_RANK = its GPU -- and relay rank 0's output.
+    This parent imports neither torch nor the HIP library: nothing here ever touches the GPU, and no process that has is
+    re-executed."""
+    port = _free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    line = next((l for l in reversed(out.splitlines()) if l.startswith("{")), None)
+    if line is not None:
+        print(line, flush=True)
+    else:
+        sys.stdout.write(out)
+    worst = max((abs(c) for c in codes), default=0)
+    if worst or line is None:
+        raise SystemExit("bench.py: ranks exited with %s%s" % (codes, "" if line else " and rank 0 printed no result line"))
+
+
+# =====================================================================================================================
+# stand-in renderer (--stub): the multi-rank protocol of this file without a GPU
+# =====================================================================================================================
+class StubRenderer:
+    """A strip "renderer" on the CPU: each frame fills its rows of a history and a back-buffer array with a function of
+    (row, frame), then runs the real exchange plan of raytracedggx_amd.strips over gloo.  What it checks is what the launcher
+    and the rank protocol must get right: every rank's apron rows arrive, rank 0 assembles the frame."""
+
+    def __init__(self, width, height, rank, world, dist):
+        import numpy as np
+        import torch
+        from raytracedggx_amd import strips
+        self.np, self.torch, self.strips, self.dist = np, torch, strips, dist
+        self.W, self.H, self.rank, self.world = width, height, rank, world
+        self.bounds = None
+        self.b, self.e = strips.strip_rows(height, rank, world)
+        if world > 1 and self.e - self.b < strips.HISTORY_APRON:          # as StripRenderer does
+            raise ValueError("strips of %d rows are thinner than the %d-row history apron" % (self.e - self.b, strips.HISTORY_APRON))
+        self.history = torch.zeros((height, width), dtype=torch.int64)
+        self.back = torch.zeros((height, width), dtype=torch.int32)
+        self.frames = 0
+        self.rays = 0
+        self.plan = strips.exchange_plan(height, rank, world)
+
+    def _truth(self, r0, r1, frame):
+        return (self.torch.arange(r0, r1, dtype=self.torch.int64)[:, None] * 1000 + self.torch.arange(self.W, dtype=self.torch.int64)[None, :]) + frame
+
+    def frame(self):
+        f = self.frames
+        self.history[self.b:self.e] = self._truth(self.b, self.e, f)
+        self.back[self.b:self.e] = self._truth(self.b, self.e, f + 7).to(self.torch.int32)
+        if self.world > 1:
+            self.strips.run_exchange(self.dist, self.plan, {"history": self.history, "backbuffer": self.back})
+            lo, hi = max(self.b - self.strips.HISTORY_APRON, 0), min(self.e + self.strips.HISTORY_APRON, self.H)
+            assert self.torch.equal(self.history[lo:hi], self._truth(lo, hi, f)), "rank %d: history apron of frame %d" % (self.rank, f)
+            if self.rank == 0:
+                assert self.torch.equal(self.back, self._truth(0, self.H, f + 7).to(self.torch.int32)), "frame assembly on rank 0, frame %d" % f
+        self.frames += 1
+        self.rays += (self.e - self.b) * self.W // 4
+
+    def rays_traced_since_reset(self):
+        r, self.rays = self.rays, 0
+        return r
+
+    def close(self):
+        pass
+
+
+# =====================================================================================================================
+# one rank
+# =====================================================================================================================
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)          # decided before torch is imported or any HIP call is made
 
     import numpy as np
     import torch
@@ -47,34 +148,47 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    import assets
-    from raytracedggx_amd import capi
-    from raytracedggx_amd.strips import StripRenderer
-
     W, H = args.width, args.height
-    r = StripRenderer(W, H, assets.path(args.mesh), assets.path("rnl_cross.dds"), rank=rank, world=world, device=local_rank,
-                      dist=dist if world > 1 else None, balance=world > 1,
-                      extra_args=("-sharedmem",) + (("-metallic", args.metallic[0], args.metallic[1]) if args.metallic else ()))
-    ctx = r.context
 
-    def barrier():
+    if args.stub:
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ctx.sync()
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        r = StubRenderer(W, H, rank, world, dist)
+        device = "cpu"
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        import assets
+        from raytracedggx_amd.strips import StripRenderer
+        r = StripRenderer(W, H, assets.path(args.mesh), assets.path("rnl_cross.dds"), rank=rank, world=world, device=local_rank,
+                          dist=dist if world > 1 else None, balance=world > 1 and not args.no_balance,
+                          extra_args=("-sharedmem",) + (("-metallic", args.metallic[0], args.metallic[1]) if args.metallic else ())
+                          + (("-deform", args.deform) if args.deform else ()))
+        ctx = r.context
+        device = "cuda"
+        # the box's attainable HBM bandwidth (float4 copy, 2 x 1 GiB): quoted beside the vendor peak
+        peak_measured = ctx.copy_bandwidth(1 << 30, 6) if rank == 0 else None
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ctx.sync()
 
     for _ in range(args.warmup):
         r.frame()
-    ctx.enable_timing(3)            # a HIP event pair around the ray-trace kernel of every 8th frame, no host sync
-    r.rays_traced_since_reset()     # zero the device-side running ray total
+    if not args.stub:
+        ctx.enable_timing(3)        # a HIP event pair around the ray-trace kernel of every 8th frame, no host sync
+    r.rays_traced_since_reset()     # zero the running ray total
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -83,59 +197,29 @@ def main():
     dt = time.perf_counter() - t0
     # per-frame ray counts and kernel durations were recorded without host synchronisation; collect them now
     rays_total = r.rays_traced_since_reset()
-    kernel_ms = r.ray_kernel_ms_since_reset()
     own_rays = rays_total
+    overreach = 0 if args.stub else r.history_overreach()
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        rt = torch.tensor([rays_total], dtype=torch.float64, device="cuda")
-        dist.all_reduce(rt, op=dist.ReduceOp.SUM)
-        rays_total = float(rt.item())
+        t = torch.tensor([dt, float(rays_total), float(overreach)], dtype=torch.float64, device=device)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, rays_total, overreach = float(tmax[0].item()), float(tsum[1].item()), int(tmax[2].item())
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         value = rays_total / dt / 1e6
-        rows = r.strip_rows_with_apron()
-        rays_per_launch = own_rays / max(args.steps, 1)     # rays of this rank's strip (apron rays of a strip are not counted)
-        alg_bytes = r.trace_kernel_algorithmic_bytes(rays_per_launch)
-        frame_bytes = r.frame_algorithmic_bytes(rows, metallic_lt_1=bool(args.metallic) and min(args.metallic) < 1.0)
-        k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
-        # HBM bytes per launch from hardware counters: collected in separate rocprofv3 --pmc runs of this same workload
-        # (tools/pmc.sh), committed under profiles/; null for other workloads
-        traffic, traffic_source, valu = None, None, None
-        import glob
-        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
-        if tfiles and (W, H, args.mesh, world) == (1920, 1080, "bunny.obj", 1):
-            with open(tfiles[-1]) as f:
-                pmc = json.load(f)
-            traffic = pmc["kernels"].get("rt::traceKernel", {}).get("traffic_bytes")
-            valu = pmc.get("valu_instructions_per_frame")
-            traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)" % os.path.basename(tfiles[-1])
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
         out = {
             "metric": "Mrays/s + ms/frame, bunny 1920x1080 1spp+denoise, 1/2/4/8 GPUs",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %s + rnl_cross env, %dx%d, 1spp GGX reflection + full denoise chain (refl H,V; diff H,V, shared-memory variant; temporal; tone map), "
-                                   "%s, dt=1/60" % (args.mesh, W, H, "metallic %g %g" % tuple(args.metallic) if args.metallic else "all-metal default materials"),
-                       "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world, "strip_bounds": r.bounds},
-            "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
-                         "note": "traversal is not bandwidth-shaped: with both streams busy the frame is bound by VALU issue (~80 % of the issue slots of 1024 SIMDs, profiles/*_pmc_report.txt; DESIGN.md 'Roofline')",
-                         "frame": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                                   "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}},
-            "passes_ms": r.last_timings(),
         }
-        if valu:      # what actually bounds the frame: VALU issue (wave-level instructions x 4 cycles over 1024 SIMDs at 2.4 GHz)
-            issue_ms = valu * 4.0 / 1024.0 / 2.4e9 * 1e3
-            out["roofline"]["frame"]["valu_issue"] = {"instructions": valu, "issue_ms": round(issue_ms, 4), "frac_of_frame": round(issue_ms / ms_per_step, 4),
-                                                       "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU, summed over the kernels of one frame)" % os.path.basename(tfiles[-1])}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(r, args, W, H)
+        if args.stub:
+            out["config"] = {"workload": "STUB: no rendering -- launcher / rank-protocol rehearsal over gloo, %dx%d" % (W, H), "parallelism": "row strips x%d" % world}
+            out["data"] = "none (stub)"
+        else:
+            out.update(report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, peak_measured, np))
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:
@@ -143,37 +227,102 @@ def main():
         dist.destroy_process_group()
 
 
+def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, peak_measured, np):
+    import glob
+    kernel_ms = r.ray_kernel_ms_since_reset()
+    rows = r.strip_rows_with_apron()
+    rays_per_launch = own_rays / max(args.steps, 1)     # rays of this rank's strip (apron rays of a strip are not counted)
+    alg_bytes = r.trace_kernel_algorithmic_bytes(rays_per_launch)
+    frame_bytes = r.frame_algorithmic_bytes(rows, metallic_lt_1=bool(args.metallic) and min(args.metallic) < 1.0)
+    k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+    # HBM bytes per launch from hardware counters: collected in separate rocprofv3 --pmc runs of this same workload
+    # (tools/pmc.sh), committed under profiles/; null for other workloads
+    traffic, traffic_source, valu, pmc_name = None, None, None, None
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if tfiles and (W, H, args.mesh, world, args.metallic, args.deform) == (1920, 1080, "bunny.obj", 1, None, 0.0):
+        with open(tfiles[-1]) as f:
+            pmc = json.load(f)
+        pmc_name = os.path.basename(tfiles[-1])
+        traffic = pmc["kernels"].get("rt::traceKernel", {}).get("traffic_bytes")
+        valu = pmc.get("valu_instructions_per_frame")
+        traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)" % pmc_name
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
+    frame_gbs = frame_bytes / (ms_per_step * 1e-3) / 1e9
+    out = {
+        "config": {"workload": "configs[1]: %s + rnl_cross env, %dx%d, 1spp GGX reflection + full denoise chain (refl H,V; diff H,V, shared-memory variant; temporal; tone map), "
+                               "%s, dt=1/60%s" % (args.mesh, W, H, "metallic %g %g" % tuple(args.metallic) if args.metallic else "all-metal default materials",
+                                                  ", model deforming every frame (amplitude %g, asynchronous BVH refit)" % args.deform if args.deform else ""),
+                   "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world, "strip_bounds": r.bounds,
+                   "history_apron_rows": r.apron, "history_overreach_rows": overreach},
+        "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
+                     "peak_measured": None if peak_measured is None else round(peak_measured, 1),
+                     "peak_measured_how": "float4 copy kernel, 2 x 1 GiB, read + written bytes (rtggx_copy_bandwidth) on this box, before the warm-up",
+                     "note": "traversal is a dependent gather from an L2-resident tree, not a stream: the fraction is reported because the contract asks for it; "
+                             "what bounds the kernel and the frame is in DESIGN.md 'Roofline' and profiles/r02_*_limiter.txt",
+                     "frame": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5),
+                               "frac_of_measured_peak": None if not peak_measured else round(frame_gbs / peak_measured, 5)}},
+        # one EXTRA, fully instrumented frame after the timed region: an event before and after every pass.  These are per-pass
+        # latencies of a single frame with nothing overlapping it (queueing included) -- not the throughput figures above.
+        "instrumented_frame_ms": dict(r.last_timings(), note="one extra frame with events around every pass, nothing overlapped: latencies, not throughput; 'frame' = first pass start to tone map end"),
+    }
+    if valu:      # share of the frame's VALU issue slots in use (wave-level instructions x cycles each over 1024 SIMDs at 2.4 GHz)
+        issue_ms = valu * VALU_CYCLES_PER_WAVE_INSTRUCTION / 1024.0 / SHADER_CLOCK_HZ * 1e3
+        out["roofline"]["frame"]["valu_issue"] = {"instructions": valu, "cycles_per_instruction": VALU_CYCLES_PER_WAVE_INSTRUCTION, "issue_ms": round(issue_ms, 4),
+                                                   "frac_of_frame": round(issue_ms / ms_per_step, 4),
+                                                   "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU, summed over the kernels of one frame); cycles per instruction: MI355X_MICROARCH.md constants table, confirmed by tools/microbench/valu_issue.hip" % pmc_name}
+    if world == 1 and not args.no_cpu_baseline and not args.deform:
+        out["cpu_baseline"] = cpu_baseline(r, args, W, H)
+    return out
+
+
 def cpu_baseline(r, args, W, H):
-    """The oracle (scalar C++ restatement, `port`) on the host cores: same inputs, same BVH arrays, same frames 0..n-1."""
+    """The oracle (scalar C++ restatement, `port`) on the host cores: same inputs, same BVH arrays, same frames 0..n-1.
+    Two legs: all hardware threads (row-interleaved pool), then one thread."""
     import assets
     from oracle import oracle as O
     from raytracedggx_amd import app, capi
     cores = min(os.cpu_count() or 1, 16)
-    o = O.Oracle(W, H, threads=cores)
-    v, i, _ = O.obj_import(assets.path(args.mesh))
-    o.set_mesh(1, v, i)
-    o.set_env_dds(assets.path("rnl_cross.dds"))
-    if args.metallic:
-        o.set_metallic(0, args.metallic[0]); o.set_metallic(1, args.metallic[1])
-    for slot, (bn, bt) in enumerate(((capi.BUF_BVH_NODES0, capi.BUF_BVH_TRIS0), (capi.BUF_BVH_NODES1, capi.BUF_BVH_TRIS1))):
-        o.set_bvh(slot, r.context.readback(bn), r.context.readback(bt), r.context.bvh_root(slot))
-    o.transform_sh()
-    fc = app.frame_constants(W, H, 1 + args.cpu_frames)
-    rays, t_total, t_trace = 0, 0.0, 0.0
-    for f in range(1 + args.cpu_frames):
-        o.set_frame_constants(fc[f].tobytes()[:704] + o.get_frame_constants().tobytes()[704:])
-        t0 = time.perf_counter()
-        o.update_as(); o.render_visibility()
-        t1 = time.perf_counter()
-        n = o.ray_trace()
-        t2 = time.perf_counter()
-        o.denoise(); o.tone_map()
-        t3 = time.perf_counter()
-        if f > 0:   # frame 0 is the warm-up
-            rays += n; t_total += t3 - t0; t_trace += t2 - t1
-    return {"value": round(rays / t_total / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "ms_per_frame": round(t_total * 1e3 / args.cpu_frames, 2), "trace_only_mrays": round(rays / t_trace / 1e6, 4),
-            "sample": "%d frames (after 1 warm-up) of the same %dx%d workload, oracle on %d threads, same BVH arrays as the GPU" % (args.cpu_frames, W, H, cores)}
+
+    def leg(threads, frames):
+        o = O.Oracle(W, H, threads=threads)
+        v, i, _ = O.obj_import(assets.path(args.mesh))
+        o.set_mesh(1, v, i)
+        o.set_env_dds(assets.path("rnl_cross.dds"))
+        if args.metallic:
+            o.set_metallic(0, args.metallic[0]); o.set_metallic(1, args.metallic[1])
+        for slot, (bn, bt) in enumerate(((capi.BUF_BVH_NODES0, capi.BUF_BVH_TRIS0), (capi.BUF_BVH_NODES1, capi.BUF_BVH_TRIS1))):
+            o.set_bvh(slot, r.context.readback(bn), r.context.readback(bt), r.context.bvh_root(slot))
+        o.transform_sh()
+        fc = app.frame_constants(W, H, 1 + frames)
+        rays, t_total, t_trace = 0, 0.0, 0.0
+        for f in range(1 + frames):
+            o.set_frame_constants(fc[f].tobytes()[:704] + o.get_frame_constants().tobytes()[704:])
+            t0 = time.perf_counter()
+            o.update_as(); o.render_visibility()
+            t1 = time.perf_counter()
+            n = o.ray_trace()
+            t2 = time.perf_counter()
+            o.denoise(); o.tone_map()
+            t3 = time.perf_counter()
+            if f > 0:   # frame 0 is the warm-up
+                rays += n; t_total += t3 - t0; t_trace += t2 - t1
+        o.close()
+        return {"value": round(rays / t_total / 1e6, 4), "ms_per_frame": round(t_total * 1e3 / frames, 2), "trace_only_mrays": round(rays / t_trace / 1e6, 4)}
+
+    multi = leg(cores, args.cpu_frames)
+    single = leg(1, 1)
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": multi["value"], "unit": "Mrays/s", "cores": cores, "kind": "port", "ms_per_frame": multi["ms_per_frame"],
+            "trace_only_mrays": multi["trace_only_mrays"], "cpu": cpu, "host_threads_available": os.cpu_count(),
+            "single_thread": dict(single, cores=1, sample="1 frame after 1 warm-up frame"),
+            "sample": "%d frames (after 1 warm-up) of the same %dx%d workload, oracle on %d threads, same BVH arrays as the GPU; then 1 frame on 1 thread" % (args.cpu_frames, W, H, cores)}
 
 
 if __name__ == "__main__":

@@ -156,6 +156,17 @@ int  rtggx_set_metallic(rtggx_context* ctx, uint32_t mesh, float metallic);
 /* LBVH build of both bottom-level structures on the context's build stream. */
 int  rtggx_build_as(rtggx_context* ctx);
 
+/* Deforming mesh: `num_verts` new vertices (same layout, same count, same indices as the last rtggx_set_mesh) for mesh `slot`.
+ * Replaces, for shape changes, what RayTracer::UpdateAccelerationStructure (RayTracer.cpp:326-341) does for the rigid instance
+ * motion of the sample: the acceleration structure follows the new positions WITHOUT a rebuild and without a synchronisation.
+ * The vertices are copied (staged) before the call returns; the upload, the new leaf triangles and the bottom-up box refit of
+ * the existing tree run on the context's stream B at the start of the next frame (rtggx_render_visibility), overlapping the
+ * previous frame's shading and denoising.  When the refitted tree's cost exceeds 1.6 x that of the last build, the call
+ * rebuilds instead (synchronous, like rtggx_build_as).  rtggx_refit_stats: cost of the current tree relative to the last
+ * build, refits and rebuilds so far; synchronises. */
+int  rtggx_refit_as(rtggx_context* ctx, uint32_t slot, const float* verts, uint32_t num_verts);
+int  rtggx_refit_stats(rtggx_context* ctx, uint32_t slot, float* cost_ratio, uint32_t* refits, uint32_t* rebuilds);
+
 /* Per-frame constants; copied into the next slot of a ring of RayTracer::FrameCount + 1 (= 4). */
 int  rtggx_update_frame(rtggx_context* ctx, const RtggxFrameConstants* constants);
 /* Refreshes the TLAS (the two world->object matrices) from the constants of the current slot.  May be called before or
@@ -193,6 +204,10 @@ int  rtggx_get_timings(rtggx_context* ctx, RtggxTimings* out);
 int  rtggx_enable_timing(rtggx_context* ctx, int mode);
 /* Durations (ms) of the ray-trace kernel launches recorded in mode 2 or 3 since the last call; synchronises. */
 int  rtggx_kernel_times(rtggx_context* ctx, float* ms, uint32_t capacity, uint32_t* count);
+
+/* Attainable HBM bandwidth of the device (GB/s, read + written bytes): a float4 copy kernel over two buffers of `bytes` each,
+ * `iterations` timed launches.  For the measured peak bench.py quotes beside the vendor figure; synchronises. */
+int  rtggx_copy_bandwidth(rtggx_context* ctx, size_t bytes, int iterations, double* gbytes_per_s);
 
 /* Size in bytes of a buffer / synchronous copy into caller memory / raw device pointer. */
 int  rtggx_buffer_size(rtggx_context* ctx, int buffer_id, size_t* bytes);

@@ -29,7 +29,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats"]
 
 
 class Timings(C.Structure):
@@ -58,6 +58,9 @@ def load():
     L.rtggx_set_stream.argtypes = [vp, vp]
     L.rtggx_set_async_compute.argtypes = [vp, C.c_int]
     L.rtggx_set_history_apron.argtypes = [vp, C.c_uint32]
+    L.rtggx_refit_as.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
+    L.rtggx_refit_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.rtggx_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.rtggx_history_overreach.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     L.rtggx_set_mesh.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32]
     L.rtggx_set_env.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp, C.c_size_t]
@@ -123,6 +126,12 @@ class Context:
     def set_stream(self, stream_handle):
         self._check(self.L.rtggx_set_stream(self.h, C.c_void_p(stream_handle)))
 
+    def copy_bandwidth(self, nbytes=1 << 30, iterations=8):
+        """GB/s (read + written) of a float4 copy kernel over two buffers of nbytes each: the attainable HBM peak on this box."""
+        g = C.c_double()
+        self._check(self.L.rtggx_copy_bandwidth(self.h, int(nbytes), int(iterations), C.byref(g)))
+        return g.value
+
     def set_history_apron(self, rows):
         self._check(self.L.rtggx_set_history_apron(self.h, int(rows)))
 
@@ -139,6 +148,16 @@ class Context:
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 6)
         i = np.ascontiguousarray(indices, np.uint32).reshape(-1)
         self._check(self.L.rtggx_set_mesh(self.h, slot, _p(v), v.shape[0], _p(i), i.size))
+
+    def refit_as(self, slot, verts):
+        """New vertex positions / normals for an unchanged topology: staged now, uploaded and refitted on stream B by the next frame."""
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 6)
+        self._check(self.L.rtggx_refit_as(self.h, slot, _p(v), v.shape[0]))
+
+    def refit_stats(self, slot=1):
+        ratio, refits, rebuilds = C.c_float(), C.c_uint32(), C.c_uint32()
+        self._check(self.L.rtggx_refit_stats(self.h, slot, C.byref(ratio), C.byref(refits), C.byref(rebuilds)))
+        return {"cost_ratio": ratio.value, "refits": refits.value, "rebuilds": rebuilds.value}
 
     def set_env(self, fmt, size, mips, data):
         b = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)

@@ -21,6 +21,9 @@ __global__ void uploadParamsKernel(FrameParams src, FrameParams* dst) {
   uint32_t* d = reinterpret_cast<uint32_t*>(dst);
   for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4; i += blockDim.x) d[i] = s[i];
 }
+__global__ void __launch_bounds__(256) copyKernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
 int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s) {
   hipLaunchKernelGGL(uploadParamsKernel, dim3(1), dim3(64), 0, s, c->slots[slot], c->dParams + slot);
   RT_HIP(hipGetLastError());
@@ -83,10 +86,19 @@ static int uploadParamsStreamB(rtggx_context* c) {
   return 0;
 }
 static int ensureParams(rtggx_context* c) { return c->slotUploaded ? 0 : uploadParamsStreamB(c); }
+// Vertex storage of a mesh: one allocation aliased by all input sets, or one per set once the mesh deforms; the staging ring.
+static void freeMeshVerts(MeshDev& m) {
+  for (int i = 0; i < RT_SETS; ++i) { bool dup = false; for (int j = 0; j < i; ++j) dup = dup || m.vertsBuf[j] == m.vertsBuf[i]; if (!dup && m.vertsBuf[i]) hipFree(m.vertsBuf[i]); }
+  for (auto& b : m.vertsBuf) b = nullptr;
+  for (auto& st : m.stage) { if (st) hipHostFree(st); st = nullptr; }
+  m.verts = nullptr; m.deforming = false; m.pendingStage = -1; m.version = 0; m.latestSet = 0;
+  for (auto& v : m.vertsVersion) v = 0;
+}
 static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t ni) {
   MeshDev& m = c->mesh[slot];
   RT_HIP(syncStreams(c));       // frames in flight on any of the streams still read the buffers freed below
-  if (m.verts) { hipFree(m.verts); m.verts = nullptr; }
+  freeMeshVerts(m);
+  freeBuildProducts(m);
   if (m.indices) { hipFree(m.indices); m.indices = nullptr; }
   if (m.nodes) { hipFree(m.nodes); m.nodes = nullptr; }
   if (m.nodes4) { hipFree(m.nodes4); m.nodes4 = nullptr; }
@@ -95,6 +107,7 @@ static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint
   for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) { setError("rtggx_set_mesh: index %u out of range (%u vertices)", idx[i], nv); m.numVerts = m.numIndices = m.numTris = 0; return -1; }
   if (nv && ni) {
     RT_HIP(hipMalloc(&m.verts, sizeof(float) * 6 * (size_t)nv));
+    for (auto& b : m.vertsBuf) b = m.verts;      // static until rtggx_refit_as: one allocation for all input sets
     RT_HIP(hipMalloc(&m.indices, sizeof(uint32_t) * (size_t)ni));
     RT_HIP(hipMemcpy(m.verts, verts, sizeof(float) * 6 * (size_t)nv, hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(m.indices, idx, sizeof(uint32_t) * (size_t)ni, hipMemcpyHostToDevice));
@@ -149,6 +162,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   if (!(getenv("RTGGX_VIS_STREAM") && atoi(getenv("RTGGX_VIS_STREAM")) == 0))
     { RT_HIP(hipStreamCreateWithPriority(&c->ownVis, hipStreamNonBlocking, prioMid)); c->streamVis = c->ownVis; }
   RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&c->evRefit, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -222,7 +236,10 @@ void rtggx_destroy(rtggx_context* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipDeviceSynchronize();
-  for (auto& m : c->mesh) { hipFree(m.verts); hipFree(m.indices); hipFree(m.nodes); hipFree(m.nodes4); hipFree(m.tris); }
+  for (auto& m : c->mesh) {
+    freeMeshVerts(m); freeBuildProducts(m);
+    hipFree(m.indices); hipFree(m.nodes); hipFree(m.nodes4); hipFree(m.tris); hipFree(m.dCost); if (m.hCost) hipHostFree(m.hCost); if (m.evCost) hipEventDestroy(m.evCost);
+  }
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->backbuffer);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
   hipFree(c->tss[0]); hipFree(c->tss[1]);
@@ -236,7 +253,7 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->tev) hipEventDestroy(e);
   hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->ownAS); if (c->ownVis) hipStreamDestroy(c->ownVis);
-  hipEventDestroy(c->evVis);
+  hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit);
   delete c;
 }
 
@@ -322,6 +339,83 @@ int rtggx_build_as(rtggx_context* c) {
   return 0;
 }
 
+// Deforming meshes (the sample itself only turns a rigid instance, RayTracer.cpp:326-341): new vertices for an
+// unchanged topology.  The call only STAGES them (one copy into pinned memory); the upload and the refit of the acceleration
+// structure are issued by the next rtggx_render_visibility on stream B -- behind the previous frame's traversal, beside that
+// frame's shading and denoising on the main stream -- without a synchronisation.  The topology stays the one the last build
+// chose; when the tree's cost has grown by RT_REFIT_REBUILD_RATIO since that build, this call rebuilds instead (synchronous).
+#ifndef RT_REFIT_REBUILD_RATIO
+#define RT_REFIT_REBUILD_RATIO 1.6f
+#endif
+int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv) {
+  RT_CHECK_CTX(c);
+  if (slot >= RTGGX_NUM_MESH || !verts) { setError("rtggx_refit_as: bad arguments"); return -1; }
+  MeshDev& m = c->mesh[slot];
+  if (!c->asBuilt || !m.tris) { setError("rtggx_refit_as: rtggx_build_as has not been called"); return -1; }
+  if (nv != m.numVerts) { setError("rtggx_refit_as: %u vertices given, the mesh has %u (a new topology needs rtggx_set_mesh + rtggx_build_as)", nv, m.numVerts); return -1; }
+  const size_t bytes = sizeof(float) * 6 * (size_t)nv;
+  if (!m.deforming) {        // first time: one vertex buffer per input set (rtggx_context.h), a staging ring
+    RT_HIP(syncStreams(c));
+    for (int i = 1; i < RT_SETS; ++i) { RT_HIP(hipMalloc(&m.vertsBuf[i], bytes)); RT_HIP(hipMemcpy(m.vertsBuf[i], m.vertsBuf[0], bytes, hipMemcpyDeviceToDevice)); }
+    for (auto& st : m.stage) RT_HIP(hipHostMalloc(&st, bytes));
+    m.deforming = true; m.verts = m.vertsBuf[c->setIndex]; m.latestSet = c->setIndex;
+  }
+  // the cost of the tree after an earlier refit has arrived: has the shape drifted too far from the one the topology was built for?
+  if (m.costInFlight && hipEventQuery(m.evCost) == hipSuccess) { m.lastCost = *m.hCost; m.costInFlight = false; }
+  if (m.builtCost > 0.0f && m.lastCost > RT_REFIT_REBUILD_RATIO * m.builtCost) {
+    RT_HIP(syncStreams(c));
+    for (int i = 0; i < RT_SETS; ++i) { RT_HIP(hipMemcpy(m.vertsBuf[i], verts, bytes, hipMemcpyHostToDevice)); m.vertsVersion[i] = m.version + 1; }
+    ++m.version; m.pendingStage = -1; m.costInFlight = false;
+    for (int k = 0; k < 3; ++k) { m.bmin[k] = 3.4e38f; m.bmax[k] = -3.4e38f; }
+    for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; if (x < m.bmin[k]) m.bmin[k] = x; if (x > m.bmax[k]) m.bmax[k] = x; }
+    const uint32_t refits = m.refits, rebuilds = m.rebuilds;
+    const int r = buildLbvh(c, slot, c->streamAS);
+    m.refits = refits; m.rebuilds = rebuilds + 1;
+    return r;
+  }
+  const uint32_t st = m.stageNext; m.stageNext = (m.stageNext + 1u) % RT_SLOTS;
+  // a staging buffer is reused RT_SLOTS calls later; its copy was issued before the frame RT_SETS frames back was fenced
+  memcpy(m.stage[st], verts, bytes);
+  m.pendingStage = (int)st;
+  return 0;
+}
+int rtggx_refit_stats(rtggx_context* c, uint32_t slot, float* costRatio, uint32_t* refits, uint32_t* rebuilds) {
+  RT_CHECK_CTX(c);
+  if (slot >= RTGGX_NUM_MESH) { setError("rtggx_refit_stats: bad mesh"); return -1; }
+  MeshDev& m = c->mesh[slot];
+  RT_HIP(syncStreams(c));
+  if (m.costInFlight) { m.lastCost = *m.hCost; m.costInFlight = false; }
+  if (costRatio) *costRatio = m.builtCost > 0.0f ? m.lastCost / m.builtCost : 1.0f;
+  if (refits) *refits = m.refits;
+  if (rebuilds) *rebuilds = m.rebuilds;
+  return 0;
+}
+
+// Issued by rtggx_render_visibility once the new input set is selected and fenced: bring the set's vertex buffer up to date and
+// refit.  Everything on stream B; returns true in *touched when stream B was given work the visibility pass must follow.
+static int issuePendingRefits(rtggx_context* c, bool* touched) {
+  *touched = false;
+  for (uint32_t slot = 0; slot < RTGGX_NUM_MESH; ++slot) {
+    MeshDev& m = c->mesh[slot];
+    if (!m.deforming) continue;
+    const size_t bytes = sizeof(float) * 6 * (size_t)m.numVerts;
+    const uint32_t set = c->setIndex;
+    if (m.pendingStage >= 0) {
+      RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.stage[m.pendingStage], bytes, hipMemcpyHostToDevice, c->streamAS));
+      m.pendingStage = -1; ++m.version; m.vertsVersion[set] = m.version; m.latestSet = set;
+      m.verts = m.vertsBuf[set];
+      const int r = refitLbvh(c, slot, c->streamAS);
+      if (r) return r;
+      *touched = true;
+    } else if (m.vertsVersion[set] != m.version) {      // no new shape this frame: this set still holds an older one
+      RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.vertsBuf[m.latestSet], bytes, hipMemcpyDeviceToDevice, c->streamAS));
+      m.vertsVersion[set] = m.version;
+      *touched = true;
+    }
+  }
+  return 0;
+}
+
 int rtggx_update_frame(rtggx_context* c, const RtggxFrameConstants* k) {
   RT_CHECK_CTX(c);
   if (!k) { setError("rtggx_update_frame: null constants"); return -1; }
@@ -381,6 +475,9 @@ int rtggx_render_visibility(rtggx_context* c) {
     if (gpuSideWait) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
     else if (hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
   }
+  bool refitIssued = false;
+  { const int r = issuePendingRefits(c, &refitIssued); if (r) return r; }
+  if (refitIssued) RT_HIP(hipEventRecord(c->evRefit, c->streamAS));
   // Where the pass runs: on stream C when the launches are small (rtggx_context.h: few enough rays that the machine is not
   // saturated), on stream B otherwise.  Either way the pass follows the previous one (shared large-triangle list) and ray
   // generation follows it: both through evVis.  (The split list the pass's first kernel empties is this set's own.)
@@ -395,6 +492,7 @@ int rtggx_render_visibility(rtggx_context* c) {
   // constants already on their way on stream B (timing mode uploads them in rtggx_update_as): a pass on stream C reads
   // dParams[slot] and has to be ordered behind that upload (evAS); on stream B it follows it anyway
   if (c->slotUploaded && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evAS, 0));
+  if (refitIssued && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evRefit, 0));       // the rasteriser reads this set's vertices
   if (c->timing) hipEventRecord(c->tev[2], s);
   const int r = launchVisibility(c, c->slots[c->slot], s, c->streamVis ? c->evVis : nullptr);
   if (c->streamVis) c->evVisStream = s;
@@ -603,6 +701,33 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
   if (id == RTGGX_BUF_SH_COEFFS) c->shDone = true;
   if (!p || id >= RTGGX_BUF_BVH_NODES0) { setError("rtggx_upload: buffer %d is not writable", id); return -1; }
   RT_HIP(hipMemcpy(p, src, need, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// Attainable HBM bandwidth of the device, for the roofline's "peak measured beside the vendor figure" (SURVEY 8d): a float4
+// copy kernel over two buffers of `bytes` each (far larger than the 256 MiB Infinity Cache when bytes >= 1 GiB), timed with
+// events on the main stream; gbytes_per_s = (bytes read + bytes written) / time.
+int rtggx_copy_bandwidth(rtggx_context* c, size_t bytes, int iterations, double* gbytesPerS) {
+  RT_CHECK_CTX(c);
+  if (!gbytesPerS || bytes < 1024 || iterations < 1) { setError("rtggx_copy_bandwidth: bad arguments"); return -1; }
+  RT_HIP(syncStreams(c));
+  const size_t n = bytes / 16;
+  float4 *src = nullptr, *dst = nullptr;
+  RT_HIP(hipMalloc(&src, n * 16));
+  if (hipMalloc(&dst, n * 16) != hipSuccess) { hipFree(src); setError("rtggx_copy_bandwidth: out of device memory"); return -2; }
+  hipMemsetAsync(src, 0x3C, n * 16, c->streamMain);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const uint32_t blocks = c->numCUs * 16u;
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
+  hipEventRecord(e0, c->streamMain);
+  for (int i = 0; i < iterations; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
+  hipEventRecord(e1, c->streamMain);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.0f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(src); hipFree(dst);
+  if (e != hipSuccess || !(ms > 0.0f)) { setError("rtggx_copy_bandwidth: %s", hipGetErrorString(e)); return -2; }
+  *gbytesPerS = 2.0 * (double)(n * 16) * iterations / ((double)ms * 1e-3) / 1e9;
   return 0;
 }
 

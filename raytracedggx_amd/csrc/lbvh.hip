@@ -6,8 +6,9 @@
 // LBVH (Karras 2012): 30-bit Morton codes of triangle-box centres -> stable LSD radix sort
 // (4 x 8 bits, wave64 ballot ranking) -> radix-tree hierarchy, one lane per internal node ->
 // bottom-up box fit with one arrival counter per node -> 64-byte nodes that carry both child
-// boxes, and 64-byte leaf triangles in Morton order.  Runs on the context's build stream; nothing
-// here is on the per-frame path (the BLAS is static, the TLAS refresh is rtggx_update_as).
+// boxes, and 64-byte leaf triangles in Morton order.  The build runs on the context's build stream with host round trips
+// (PLOC rounds) and is off the per-frame path; what IS on it, for meshes that change shape, is refitLbvh at the end of
+// this file: new leaf triangles and boxes for the existing topology, five kernels on stream B, no host involvement.
 #include "rtggx_context.h"
 
 namespace rt {
@@ -281,6 +282,78 @@ __global__ void emitTris(int n, const uint32_t* __restrict__ order, const float*
   tris[s] = t;
 }
 
+// ---- refit (rtggx_refit_as): same topology, new vertex positions ---------------------------------------------------------
+// Leaf slot s keeps its primitive (tris[s].prim): rewrite its three vertices and the primitive's box.
+__global__ void refitTris(int n, const float* __restrict__ verts, const uint32_t* __restrict__ idx, BvhTri* __restrict__ tris, float* __restrict__ triBox) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t prim = tris[s].prim;
+  float mn[3], mx[3];
+  BvhTri t = tris[s];
+  for (int k = 0; k < 3; ++k) {
+    const float a = verts[6 * (size_t)idx[3 * (size_t)prim] + k], b = verts[6 * (size_t)idx[3 * (size_t)prim + 1] + k], c = verts[6 * (size_t)idx[3 * (size_t)prim + 2] + k];
+    t.v0[k] = a; t.v1[k] = b; t.v2[k] = c;
+    mn[k] = fminf(a, fminf(b, c)); mx[k] = fmaxf(a, fmaxf(b, c));
+  }
+  tris[s] = t;
+  for (int k = 0; k < 3; ++k) { triBox[6 * (size_t)prim + k] = mn[k]; triBox[6 * (size_t)prim + 3 + k] = mx[k]; }
+}
+// Sum of the half-areas of all node boxes: the tree's SAH cost up to constants.  A refit keeps the topology the build chose for
+// the OLD shape; when this sum has grown by RT_REFIT_REBUILD_RATIO the host rebuilds (capi.hip).
+__global__ void treeCostKernel(int numNodes, const float* __restrict__ nodeBox, float* __restrict__ cost) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float a = 0.0f;
+  if (i < numNodes) {
+    const float* b = nodeBox + 6 * (size_t)i;
+    const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+    a = (ex * ey + ey * ez) + ez * ex;
+  }
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+  if ((threadIdx.x & 63) == 0 && a != 0.0f) atomicAdd(cost, a);
+}
+
+void freeBuildProducts(MeshDev& m) {
+  hipFree(m.order); hipFree(m.left); hipFree(m.right); hipFree(m.nodeParent); hipFree(m.leafParent); hipFree(m.nodeBox); hipFree(m.triBox); hipFree(m.arrive);
+  m.order = nullptr; m.left = m.right = m.nodeParent = m.leafParent = nullptr; m.nodeBox = m.triBox = nullptr; m.arrive = nullptr;
+}
+
+static int launchTreeCost(MeshDev& m, hipStream_t s) {
+  if (!m.dCost) { RT_HIP(hipMalloc(&m.dCost, 4)); RT_HIP(hipHostMalloc(&m.hCost, 4)); *m.hCost = 0.0f; RT_HIP(hipEventCreateWithFlags(&m.evCost, hipEventDisableTiming)); }
+  RT_HIP(hipMemsetAsync(m.dCost, 0, 4, s));
+  const int numNodes = (int)m.numTris - 1;
+  hipLaunchKernelGGL(treeCostKernel, dim3((numNodes + 255) / 256), dim3(256), 0, s, numNodes, m.nodeBox, m.dCost);
+  return 0;
+}
+
+// New boxes for the existing tree from the CURRENT vertex buffer (m.verts): leaf triangles, bottom-up box fit with one arrival
+// counter per node, the 64-byte binary nodes (for the oracle / tests) and their 4-wide collapse (for the trace kernel), the
+// tree's cost.  Everything on stream `s` (stream B: behind the previous frame's traversal, which still reads the old boxes).
+int refitLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
+  MeshDev& m = c->mesh[slot];
+  const uint32_t n = m.numTris;
+  if (n == 0 || !m.tris) return 0;
+  const uint32_t nb = (n + 255) / 256;
+  if (!m.triBox) { setError("rtggx_refit_as: mesh %u has no build to refit", slot); return -1; }
+  hipLaunchKernelGGL(refitTris, dim3(nb), dim3(256), 0, s, (int)n, (const float*)m.verts, (const uint32_t*)m.indices, m.tris, m.triBox);
+  if (n > 1) {
+    RT_HIP(hipMemsetAsync(m.arrive, 0, 4 * (size_t)n, s));
+    hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right,
+                       (const int32_t*)m.nodeParent, (const int32_t*)m.leafParent, m.nodeBox, m.arrive);
+    hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right, (const float*)m.nodeBox, m.nodes);
+    hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right,
+                       (const int32_t*)m.nodeParent, (const float*)m.nodeBox, m.nodes4);
+    { const int r = launchTreeCost(m, s); if (r) return r; }
+    if (!m.costInFlight) {
+      RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s));
+      RT_HIP(hipEventRecord(m.evCost, s));
+      m.costInFlight = true;
+    }
+  }
+  ++m.refits;
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   MeshDev& m = c->mesh[slot];
   const uint32_t n = m.numTris;
@@ -288,6 +361,7 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   if (m.tris) { RT_HIP(hipFree(m.tris)); m.tris = nullptr; }
   if (m.nodes4) { RT_HIP(hipFree(m.nodes4)); m.nodes4 = nullptr; }
   m.root = -1; m.depth = 0;
+  freeBuildProducts(m);
   if (n == 0) return 0;
   RT_HIP(hipMalloc(&m.tris, sizeof(BvhTri) * (size_t)n));
   RT_HIP(hipMalloc(&m.nodes, sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)));
@@ -363,9 +437,12 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   }
   RT_HIP(hipGetLastError());
   RT_HIP(hipMemcpyAsync(&m.depth, arrive + n, 4, hipMemcpyDeviceToHost, s));
+  // the topology and the per-primitive boxes stay for rtggx_refit_as (freed with the mesh or by the next build)
+  m.order = order[cur]; m.left = left; m.right = right; m.nodeParent = nodeParent; m.leafParent = leafParent; m.nodeBox = nodeBox; m.triBox = triBox; m.arrive = arrive;
+  if (n > 1) { const int r = launchTreeCost(m, s); if (r) return r; RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s)); }
   RT_HIP(hipStreamSynchronize(s));
-  hipFree(codes[0]); hipFree(codes[1]); hipFree(order[0]); hipFree(order[1]); hipFree(hist); hipFree(triBox); hipFree(nodeBox);
-  hipFree(left); hipFree(right); hipFree(nodeParent); hipFree(leafParent); hipFree(arrive);
+  if (n > 1) { m.builtCost = m.lastCost = *m.hCost; m.costInFlight = false; }
+  hipFree(codes[0]); hipFree(codes[1]); hipFree(order[cur ^ 1]); hipFree(hist);
   return 0;
 }
 

@@ -18,10 +18,34 @@
 #include <vector>
 #include "rtggx_device.h"
 
+// Input sets (G-buffer, traced images, ray bins): three, used round-robin.  Stream B fills set i while the main stream
+// still consumes the set of the frame before; before stream B is given the work that overwrites a set, the HOST waits
+// for the event of that set's last reader, three frames back -- the frames-in-flight fence of the sample
+// (RayTracedGGX.cpp: FrameCount = 3), and cheaper than a cross-queue wait on the GPU (10 us per frame on stream B's
+// chain).  The frame constants live in a ring of RT_SLOTS device slots: one more than sets, because the tone map of
+// frame f still reads its slot after the event of set f has completed.
+#define RT_SETS 3
+#define RT_SLOTS 4
 namespace rt {
 
 struct MeshDev {
-  float* verts = nullptr;        // 6 floats per vertex
+  float* verts = nullptr;        // 6 floats per vertex: the buffer of the CURRENT input set (selectSet)
+  // A mesh whose vertices change per frame (rtggx_refit_as) keeps one vertex buffer per input set: the shading of frame f on the
+  // main stream still reads the vertices of frame f while stream B already moves them for frame f + 1.  A static mesh has one
+  // allocation, and the three pointers alias it.
+  float* vertsBuf[RT_SETS] = {};
+  uint32_t vertsVersion[RT_SETS] = {}, version = 0, latestSet = 0;
+  bool deforming = false;
+  float* stage[RT_SLOTS] = {};   // pinned host staging ring for the vertices handed to rtggx_refit_as
+  uint32_t stageNext = 0; int pendingStage = -1;
+  // what the build leaves behind for the refit (lbvh.hip): the binary topology, per-primitive boxes, arrival counters
+  uint32_t* order = nullptr; int32_t *left = nullptr, *right = nullptr, *nodeParent = nullptr, *leafParent = nullptr;
+  float *nodeBox = nullptr, *triBox = nullptr; uint32_t* arrive = nullptr;
+  float* dCost = nullptr;        // device: sum of the node-box half-areas of the current tree (SAH cost up to constants)
+  float* hCost = nullptr;        // pinned: its copy, refreshed asynchronously after every refit
+  hipEvent_t evCost = nullptr; bool costInFlight = false;
+  float builtCost = 0.0f, lastCost = 0.0f;
+  uint32_t refits = 0, rebuilds = 0;
   uint32_t* indices = nullptr;
   uint32_t numVerts = 0, numIndices = 0, numTris = 0;
   BvhNode* nodes = nullptr;      // numTris - 1 (0 when numTris == 1): the binary LBVH as built
@@ -60,14 +84,6 @@ struct Scene {
 
 }  // namespace rt
 
-// Input sets (G-buffer, traced images, ray bins): three, used round-robin.  Stream B fills set i while the main stream
-// still consumes the set of the frame before; before stream B is given the work that overwrites a set, the HOST waits
-// for the event of that set's last reader, three frames back -- the frames-in-flight fence of the sample
-// (RayTracedGGX.cpp: FrameCount = 3), and cheaper than a cross-queue wait on the GPU (10 us per frame on stream B's
-// chain).  The frame constants live in a ring of RT_SLOTS device slots: one more than sets, because the tone map of
-// frame f still reads its slot after the event of set f has completed.
-#define RT_SETS 3
-#define RT_SLOTS 4
 struct rtggx_context {
   int device = 0;
   uint32_t W = 0, H = 0;
@@ -86,6 +102,7 @@ struct rtggx_context {
   bool lastTraceAdaptive = false;
   bool attachEvents = true;             // RTGGX_ATTACH_EVENTS=0: record the cross-stream events with hipEventRecord instead
   hipEvent_t evAS = nullptr;      // constants uploaded (stream B -> main)
+  hipEvent_t evRefit = nullptr;   // vertices of the current set uploaded and the tree refitted (stream B -> stream C)
   hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
   bool setReadRecorded[RT_SETS] = {};
   bool externalStream = false;
@@ -112,6 +129,7 @@ struct rtggx_context {
     setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
     splitList = splitListBuf[i]; splitCount = largeCount ? largeCount + 1 + i : nullptr;
+    for (auto& m : mesh) m.verts = m.vertsBuf[i];
   }
   uint2 *tss[2] = {nullptr, nullptr}, *fltRfl = nullptr, *fltDff = nullptr;
   uint32_t frameParity = 0;
@@ -188,6 +206,8 @@ int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s);
 int uploadScene(rtggx_context* c, hipStream_t s);
 int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
+int refitLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);      // boxes of the existing tree from mesh.verts (current set): no host round trip
+void freeBuildProducts(MeshDev& m);
 int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);   // ray generation + traversal
 // `done` (may be null) on the launch functions below: an event that completes with the pass's last kernel.  It rides on that
 // kernel's own completion signal (hipExtLaunchKernelGGL) instead of a marker packet behind it: a marker costs its queue

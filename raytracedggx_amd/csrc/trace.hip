@@ -30,6 +30,7 @@
 
 namespace rt {
 
+#define RT_PRIME_LAUNCHES 4u  // launches of a context whose ray / split counters are read back synchronously (launchTrace)
 #define RT_STACK 24          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: see tools/probes/trace_stats_probe.py)
 
 struct TraceArgs {
@@ -393,6 +394,10 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
     RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->splitCount, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipEventRecord(c->evRayCounters, s));
     c->rayCountersInFlight = true;
+    // Priming: the first launches of a context wait for their own counters, so that the decisions they feed (waves per bin,
+    // capacity of the split list, the stream of the visibility pass) are settled after RT_PRIME_LAUNCHES frames instead of
+    // whenever the copies happen to arrive on a host that runs three frames ahead.
+    if (c->traceLaunches < RT_PRIME_LAUNCHES) RT_HIP(hipEventSynchronize(c->evRayCounters));
   }
   if (countRays) ++c->traceLaunches;
   RT_HIP(hipGetLastError());

@@ -33,6 +33,18 @@ void RayTracedGGX::OnInit() {
   if (m_hasMetallicOverride) for (uint32_t i = 0; i < RayTracer::NUM_MESH; ++i) m_rayTracer->SetMetallic(i, m_metallics[i]);
   m_rayTracer->SetAsyncCompute(m_asyncCompute != 0);   // -sync: one stream, submission order (the sample's single command list)
 
+  if (m_deformAmplitude != 0.0f) {       // key shapes of the breathing model: x and z displaced by a wave travelling up the y axis
+    const std::vector<float>& base = m_rayTracer->GetModelVertices();
+    m_deformShapes.assign(DeformPeriod, base);
+    for (uint32_t k = 0; k < DeformPeriod; ++k) {
+      const float phase = 6.283185307f * (float)k / (float)DeformPeriod;
+      for (size_t v = 0; v + 5 < base.size(); v += 6) {
+        const float y = base[v + 1];
+        m_deformShapes[k][v] = base[v] + m_deformAmplitude * std::sin(1.3f * y + phase);
+        m_deformShapes[k][v + 2] = base[v + 2] + 0.7f * m_deformAmplitude * std::cos(0.8f * y - phase);
+      }
+    }
+  }
   InitCamera();
   if (!m_trackFileName.empty() && !LoadTrack(m_trackFileName)) throw std::runtime_error("cannot read track " + m_trackFileName);
   m_initialized = true;
@@ -59,6 +71,10 @@ void RayTracedGGX::OnUpdate() {
       case 4: OnMouseWheel(e.a, 0.0f, 0.0f); break;
       default: OnMouseLeave(); break;
     }
+  }
+  if (!m_deformShapes.empty() && !m_isPaused) {
+    const std::vector<float>& shape = m_deformShapes[m_frameNumber % DeformPeriod];
+    m_rayTracer->UpdateMesh(shape.data(), (uint32_t)(shape.size() / 6));
   }
   ++m_frameNumber;
   const float timeStep = m_isPaused ? 0.0f : m_fixedTimeStep;
@@ -162,7 +178,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     return (arg[0] == '-' || arg[0] == '/') && lower(arg + 1) == lower(name);
   };
   // On POSIX an absolute path also starts with '/': such a token is a flag only when it names one.
-  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus", "track"};
+  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus", "track", "deform"};
   const auto isFlagName = [&](const char* name) { for (const char* f : kFlags) if (lower(name) == f) return true; return false; };
   const auto hasNextArgValue = [&](int i) {
     if (i + 1 >= argc) return false;
@@ -187,6 +203,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     else if (isArgMatched(i, "sync")) m_asyncCompute = 0;
     else if (isArgMatched(i, "device")) { if (hasNextArgValue(i)) m_device = std::atoi(argv[++i]); }
     else if (isArgMatched(i, "dump")) { if (hasNextArgValue(i)) m_dumpPrefix = argv[++i]; }
+    else if (isArgMatched(i, "deform")) { nextFloat(i, m_deformAmplitude); }
     else if (isArgMatched(i, "track")) { if (hasNextArgValue(i)) m_trackFileName = argv[++i]; }
     else if (isArgMatched(i, "gpus")) {
       // One process drives one GPU.  Several GPUs = one process per GPU, each rendering a strip of rows and exchanging the

@@ -2,7 +2,7 @@
 // DXFramework virtuals RayTracedGGX/Common/DXFramework.h:23-26): OnInit / OnUpdate / OnRender /
 // OnDestroy, the same command line (RayTracedGGX.cpp:462-511) and the same defaults
 // (RayTracedGGX.cpp:37-39, camera :19-23, 267-277).  What the window supplied interactively is
-// supplied by extra flags: -width -height -frames -dt -metallic -sharedmem -sync -device -dump.
+// supplied by extra flags: -width -height -frames -dt -metallic -sharedmem -sync -device -dump -track -deform.
 #pragma once
 #include <vector>
 #include <cstdint>
@@ -86,4 +86,9 @@ class RayTracedGGX {
   int m_device = 0;
   std::string m_dumpPrefix;
   bool m_hasMetallicOverride = false;
+  // -deform <amplitude>: the model breathes -- a travelling sine wave through its vertices, DeformPeriod key shapes computed once
+  // at start-up and handed to RayTracer::UpdateMesh one per frame (per-frame host cost: one copy of the vertex array)
+  float m_deformAmplitude = 0.0f;
+  static const uint32_t DeformPeriod = 32;
+  std::vector<std::vector<float>> m_deformShapes;
 };

@@ -46,6 +46,7 @@ bool RayTracer::Init(uint32_t width, uint32_t height, const char* fileName, cons
   ObjLoader objLoader;
   if (!objLoader.Import(fileName, true, true)) { m_error = std::string("cannot import ") + fileName; std::fprintf(stderr, "RayTracer: %s\n", m_error.c_str()); return false; }
   m_numVerts = objLoader.GetNumVertices(); m_numIndices = objLoader.GetNumIndices();
+  m_modelVerts.assign(reinterpret_cast<const float*>(objLoader.GetVertices()), reinterpret_cast<const float*>(objLoader.GetVertices()) + 6 * (size_t)m_numVerts);
   if (!check(rtggx_set_mesh(m_ctx, MODEL_OBJ, reinterpret_cast<const float*>(objLoader.GetVertices()), m_numVerts,
                             objLoader.GetIndices(), m_numIndices), "rtggx_set_mesh")) return false;
 
@@ -115,6 +116,8 @@ void RayTracer::Render(uint8_t frameIndex) {
   RenderVisibility(frameIndex);
   check(rtggx_ray_trace(m_ctx), "rtggx_ray_trace");
 }
+
+bool RayTracer::UpdateMesh(const float* vertices, uint32_t numVertices) { return check(rtggx_refit_as(m_ctx, MODEL_OBJ, vertices, numVertices), "rtggx_refit_as"); }
 
 void RayTracer::UpdateAccelerationStructure(uint8_t) { check(rtggx_update_as(m_ctx), "rtggx_update_as"); }
 

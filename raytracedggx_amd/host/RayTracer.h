@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
 #include "../../include/rtggx.h"
 #include "XMath.h"
 
@@ -42,6 +43,10 @@ class RayTracer {
   void TransformSH();
   void Render(uint8_t frameIndex);
   void UpdateAccelerationStructure(uint8_t frameIndex);
+  // Deforming model: new vertices {Pos, Nrm} for the unchanged topology of the loaded mesh.  The acceleration
+  // structure is refitted on the device at the start of the next frame, asynchronously (rtggx_refit_as).
+  bool UpdateMesh(const float* vertices, uint32_t numVertices);
+  const std::vector<float>& GetModelVertices() const { return m_modelVerts; }       // as imported: 6 floats per vertex
   void RenderVisibility(uint8_t frameIndex, bool asyncCompute = false);
   void RayTrace(uint8_t frameIndex);
 
@@ -58,6 +63,7 @@ class RayTracer {
   uint32_t m_width = 0, m_height = 0;
   float m_posScale[4] = {0.0f, 0.0f, 0.0f, 1.0f};
   uint32_t m_numVerts = 0, m_numIndices = 0;
+  std::vector<float> m_modelVerts;
 
   // state UpdateFrame keeps between frames (statics / members in the reference)
   HaltonSequence m_halton;

@@ -926,3 +926,80 @@ def test_history_apron_guard_reports_fast_motion(built, tmp_path):
     assert over > 0, "the drag is faster than the default apron covers, and the guard says by how much"
     over2, equal2 = run(HISTORY_APRON + over + 1)
     assert over2 == 0 and equal2, "with the apron widened by the reported amount the strips are exact again (%d rows over, equal: %s)" % (over2, equal2)
+
+
+def _wave(v0, f, amp=0.35):
+    v = v0.copy()
+    v[:, 0] += amp * np.sin(1.3 * v0[:, 1] + 0.9 * f)
+    v[:, 2] += 0.7 * amp * np.cos(0.8 * v0[:, 1] - 0.7 * f)
+    return v
+
+
+def test_deforming_mesh_async_refit_against_the_oracle(built):
+    """SURVEY 8f rank 4 / BASELINE config 5's "async BVH refit": rtggx_refit_as stages new vertices; the upload, the new leaf
+    triangles and the bottom-up box refit of the EXISTING tree run on stream B at the start of the next frame.  Every frame
+    against the oracle given the same vertices and the refitted tree (structure-checked: boxes tight around the moved
+    triangles), including frames WITHOUT a new shape in between (the other input sets' vertex buffers must follow) and a
+    change violent enough to trigger the rebuild."""
+    p = Pair(320, 180, metallic=(1.0, 0.5), shared_mem=True)
+    try:
+        v0, idx, _ = O.obj_import(assets.path("bunny.obj"))
+        shapes = {1: _wave(v0, 1), 2: _wave(v0, 2), 3: _wave(v0, 3), 6: _wave(v0, 6), 7: _wave(v0, 7)}      # frames 4, 5: no new shape
+        big = v0.copy(); big[:, 0] *= 3.0; big[:, 1] = v0[:, 1] * (1.0 + 0.6 * np.sin(3.0 * v0[:, 0]))     # frame 8: a very different shape
+        shapes[8] = big; shapes[9] = _wave(big, 9); shapes[10] = _wave(big, 10)
+        for f in range(11):
+            if f in shapes:
+                p.ctx.refit_as(1, shapes[f])
+                p.o.set_mesh(1, shapes[f], idx)
+            p.app.OnUpdate(); p.app.OnRender(); p.ctx.sync()
+            if f in shapes:
+                p.give_oracle_the_device_trees()                     # the refitted (or rebuilt) tree, structure-checked
+            p.o.set_frame_constants(p.app.frame_constants().tobytes()[:704] + p.o.get_frame_constants().tobytes()[704:])
+            p.o.update_as(); p.o.render_visibility(); p.rays = p.o.ray_trace(); p.o.denoise(); p.o.tone_map()
+            p.check_frame("refit frame %d" % f)
+            st = p.ctx.refit_stats(1)
+            if f == 7:
+                assert st["refits"] == 5 and st["rebuilds"] == 0 and 0.8 < st["cost_ratio"] < 1.6, st
+        st = p.ctx.refit_stats(1)
+        assert st["rebuilds"] >= 1, "the violent change made the refitted tree's cost drift past the threshold: %s" % st
+        with pytest.raises(p.capi.RtggxError, match="vertices given"):
+            p.ctx.refit_as(1, v0[:-1])
+    finally:
+        p.close()
+
+
+def test_deforming_mesh_free_running_equals_synchronised(built):
+    """The refit needs no synchronisation: 30 frames of a breathing bunny issued back to back (three frames in flight, per-set
+    vertex buffers, staging ring) against the same frames synchronised one by one -- every target bit-identical; and the
+    `-deform` flag of the host (RayTracedGGX::OnUpdate -> RayTracer::UpdateMesh) against explicit rtggx_refit_as calls."""
+    from raytracedggx_amd import app, capi
+    args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 1280, "-height", 720, "-sharedmem", "-metallic", 1.0, 0.5]
+    a, b, c = app.RayTracedGGX(args), app.RayTracedGGX(args), app.RayTracedGGX(args + ["-deform", 0.3])
+    try:
+        v0, idx, _ = app.obj_import(assets.path("bunny.obj"))
+        period = 32
+        shapes = []
+        for k in range(period):           # what host/RayTracedGGX.cpp computes for -deform 0.3 (fp32, same formula)
+            phase = np.float32(6.283185307) * np.float32(k) / np.float32(period)
+            v = v0.copy()
+            v[:, 0] = v0[:, 0] + np.float32(0.3) * np.sin(np.float32(1.3) * v0[:, 1] + phase, dtype=np.float32)
+            v[:, 2] = v0[:, 2] + np.float32(0.7) * np.float32(0.3) * np.cos(np.float32(0.8) * v0[:, 1] - phase, dtype=np.float32)
+            shapes.append(v)
+        for f in range(30):
+            a.context.refit_as(1, shapes[f % period]); a.OnUpdate(); a.OnRender(); a.context.sync()
+            b.context.refit_as(1, shapes[f % period]); b.OnUpdate(); b.OnRender()
+            c.OnUpdate(); c.OnRender()
+        b.context.sync(); c.context.sync()
+        for bid in (capi.BUF_VISIBILITY, capi.BUF_DEPTH, capi.BUF_NORMAL, capi.BUF_ROUGH_METAL, capi.BUF_VELOCITY, capi.BUF_RT_REFL, capi.BUF_RT_DIFF,
+                    capi.BUF_FLT_RFL, capi.BUF_FLT_DFF, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_BACKBUFFER, capi.BUF_BVH4_NODES1, capi.BUF_BVH_TRIS1):
+            np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="free-running, buffer %d" % bid)
+        assert a.context.ray_count() == b.context.ray_count()
+        st = b.context.refit_stats(1)
+        assert st["refits"] == 30 and st["rebuilds"] == 0, st
+        # the host's own animation: sin/cos of libm in fp32 may differ from numpy's in the last bit, so compare the geometry-independent
+        # counters and the image loosely, and the integer visibility coverage closely
+        assert c.context.refit_stats(1)["refits"] == 30
+        va, vc = a.context.readback(capi.BUF_VISIBILITY), c.context.readback(capi.BUF_VISIBILITY)
+        assert (va != vc).mean() < 2e-3, "-deform renders the same animation (%.4f%% of the visibility words differ)" % (100 * (va != vc).mean())
+    finally:
+        a.OnDestroy(); b.OnDestroy(); c.OnDestroy()

@@ -13,9 +13,12 @@
 
 template <int NLOADS, int WIDTH>
 __global__ void __launch_bounds__(256) chase(const uint32_t* __restrict__ table, const uint32_t* __restrict__ start, uint32_t* __restrict__ out, int steps,
-                                             unsigned long long laneMask) {
+                                             unsigned long long laneMask, int share = 1) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t cur = start[blockIdx.x * 256 + threadIdx.x];
+  // share = G: groups of G consecutive lanes follow the SAME chain (same record every step), as neighbouring rays walking the
+  // same nodes do.  Does the vector L1 serve such a load as one request per distinct line, or one per lane?
+  if (share > 1) cur = (uint32_t)__shfl((int)cur, (int)(lane & ~(uint32_t)(share - 1)));
   uint32_t acc = 0;
   if ((laneMask >> lane) & 1ull) {
     for (int s = 0; s < steps; ++s) {
@@ -34,12 +37,12 @@ __global__ void __launch_bounds__(256) chase(const uint32_t* __restrict__ table,
 }
 
 template <int NLOADS, int WIDTH>
-static float run(const uint32_t* dT, const uint32_t* dS, uint32_t* dO, int grid, int steps, unsigned long long mask) {
+static float run(const uint32_t* dT, const uint32_t* dS, uint32_t* dO, int grid, int steps, unsigned long long mask, int share = 1) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
   float ms = 0;
   for (int rep = 0; rep < 3; ++rep) {
     CHECK(hipEventRecord(a));
-    hipLaunchKernelGGL((chase<NLOADS, WIDTH>), dim3(grid), dim3(256), 0, 0, dT, dS, dO, steps, mask);
+    hipLaunchKernelGGL((chase<NLOADS, WIDTH>), dim3(grid), dim3(256), 0, 0, dT, dS, dO, steps, mask, share);
     CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
     CHECK(hipEventElapsedTime(&ms, a, b));
   }
@@ -69,6 +72,11 @@ int main() {
     const float d = run<1, 1>(dT, dS, dO, grid, steps, m.mask), e = run<4, 1>(dT, dS, dO, grid, steps, m.mask), f = run<8, 2>(dT, dS, dO, grid, steps, m.mask);
     printf("%s  ns per wave-step:  1 x16B %6.0f   4 x16B %6.0f   7 x16B %6.0f   1 x4B %6.0f   4 x4B %6.0f   8 x8B %6.0f\n", m.name,
            a * 1e6 / steps, b * 1e6 / steps, c * 1e6 / steps, d * 1e6 / steps, e * 1e6 / steps, f * 1e6 / steps);
+  }
+  printf("\nlanes sharing a record (all 64 lanes active; groups of G consecutive lanes read the same 128-byte record):\n");
+  for (int g : {1, 2, 4, 8, 16, 64}) {
+    const float a = run<1, 4>(dT, dS, dO, grid, steps, ~0ull, g), b = run<4, 4>(dT, dS, dO, grid, steps, ~0ull, g), c = run<7, 4>(dT, dS, dO, grid, steps, ~0ull, g);
+    printf("G = %2d (%2d distinct records per load)  ns per wave-step:  1 x16B %6.0f   4 x16B %6.0f   7 x16B %6.0f\n", g, 64 / g, a * 1e6 / steps, b * 1e6 / steps, c * 1e6 / steps);
   }
   return 0;
 }
