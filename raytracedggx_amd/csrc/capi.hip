@@ -70,6 +70,7 @@ static void invert4x4(const float* a /*row-major*/, float* out) {
 static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
 static hipError_t syncStreams(rtggx_context* c) {
   hipError_t e = c->ownVis ? hipStreamSynchronize(c->ownVis) : hipSuccess;
+  if (e == hipSuccess && c->streamRefit) e = hipStreamSynchronize(c->streamRefit);
   if (e == hipSuccess) e = hipStreamSynchronize(c->ownAS);
   if (e == hipSuccess) e = hipStreamSynchronize(c->streamMain);
   return e;
@@ -100,9 +101,6 @@ static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint
   freeMeshVerts(m);
   freeBuildProducts(m);
   if (m.indices) { hipFree(m.indices); m.indices = nullptr; }
-  if (m.nodes) { hipFree(m.nodes); m.nodes = nullptr; }
-  if (m.nodes4) { hipFree(m.nodes4); m.nodes4 = nullptr; }
-  if (m.tris) { hipFree(m.tris); m.tris = nullptr; }
   m.root = -1; m.numVerts = nv; m.numIndices = ni; m.numTris = ni / 3;
   for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) { setError("rtggx_set_mesh: index %u out of range (%u vertices)", idx[i], nv); m.numVerts = m.numIndices = m.numTris = 0; return -1; }
   if (nv && ni) {
@@ -153,7 +151,9 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   // 0.233 -> 0.229 ms, dragon 0.259 -> 0.258; RTGGX_PRIORITY_MODE=0 restores B high / main low, 2 is the reverse).
   int prioLeast = 0, prioGreatest = 0;
   RT_HIP(hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
-  const int prioMode = getenv("RTGGX_PRIORITY_MODE") ? atoi(getenv("RTGGX_PRIORITY_MODE")) : 1;      // 0: B high, main low; 1: equal; 2: main high, B low
+  // Round 2, three-stage pipeline: the main stream's chain of five kernels is the longest of the three and the one the others slow
+  // down most; with the main stream high and stream B low the frame gains 4.5 % over equal priorities (profiles/r02_c_ab_pipeline.txt).
+  const int prioMode = getenv("RTGGX_PRIORITY_MODE") ? atoi(getenv("RTGGX_PRIORITY_MODE")) : 2;      // 0: B high, main low; 1: equal; 2: main high, B low
   const int prioMid = (prioLeast + prioGreatest) / 2;
   RT_HIP(hipStreamCreateWithPriority(&c->ownMain, hipStreamNonBlocking, prioMode == 0 ? prioLeast : prioMode == 2 ? prioGreatest : prioMid));
   RT_HIP(hipStreamCreateWithPriority(&c->ownAS, hipStreamNonBlocking, prioMode == 0 ? prioGreatest : prioMode == 2 ? prioLeast : prioMid));
@@ -163,6 +163,10 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     { RT_HIP(hipStreamCreateWithPriority(&c->ownVis, hipStreamNonBlocking, prioMid)); c->streamVis = c->ownVis; }
   RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRefit, hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&c->evGen, hipEventDisableTiming));
+  for (auto& e : c->evTraceRing) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, prioMid));
+  c->pipeline = getenv("RTGGX_PIPELINE") ? atoi(getenv("RTGGX_PIPELINE")) : 1;
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -183,7 +187,8 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   c->largeCapacity = 1u << 16;
   RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 4 * (1 + RT_SETS))); RT_HIP(hipMemset(c->largeCount, 0, 4 * (1 + RT_SETS)));
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
-  RT_HIP(hipMalloc(&c->rayCounter32, 1024 * 4)); RT_HIP(hipMemset(c->rayCounter32, 0, 1024 * 4));
+  RT_HIP(hipMalloc(&c->rayCounterBuf, 1792 * 4)); RT_HIP(hipMemset(c->rayCounterBuf, 0, 1792 * 4));      // [4][256] per-frame counters + 768 statistics words
+  c->rayCounter32 = c->lastRayCounter32 = c->rayCounterBuf;
   RT_HIP(hipHostMalloc(&c->hostRayCounters, 257 * 4)); c->hostRayCounters[256] = 0; RT_HIP(hipEventCreateWithFlags(&c->evRayCounters, hipEventDisableTiming));   // [0..255] rays; [256..] RT_TRACE_STATS
   {
     hipDeviceProp_t prop;
@@ -199,7 +204,8 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
       RT_HIP(hipMalloc(&c->binCountBuf[i], (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCountBuf[i], 0, (size_t)c->numBinsMax * 4));
     }
     c->selectSet(0);
-    RT_HIP(hipMalloc(&c->binWork, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binWork, 0, (size_t)c->numBinsMax * 4));
+    for (auto& b : c->binWorkBuf) { RT_HIP(hipMalloc(&b, (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(b, 0, (size_t)c->numBinsMax * 4)); }
+    c->binWork = c->binWorkBuf[0];
     for (int i = 0; i < RT_SETS; ++i) RT_HIP(hipMalloc(&c->splitListBuf[i], (size_t)RT_SPLIT_CAP * 4));
     c->selectSet(0);
     c->splitWork = getenv("RTGGX_SPLIT_WORK") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_WORK")) : RT_SPLIT_WORK;
@@ -238,22 +244,23 @@ void rtggx_destroy(rtggx_context* c) {
   hipDeviceSynchronize();
   for (auto& m : c->mesh) {
     freeMeshVerts(m); freeBuildProducts(m);
-    hipFree(m.indices); hipFree(m.nodes); hipFree(m.nodes4); hipFree(m.tris); hipFree(m.dCost); if (m.hCost) hipHostFree(m.hCost); if (m.evCost) hipEventDestroy(m.evCost);
+    hipFree(m.indices); hipFree(m.dCost); if (m.hCost) hipHostFree(m.hCost); if (m.evCost) hipEventDestroy(m.evCost);
   }
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->backbuffer);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
-  hipFree(c->binWork); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
+  hipFree(c->binWorkBuf[0]); hipFree(c->binWorkBuf[1]); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
   hipFree(c->stackOverflow); hipFree(c->dummyRecord); hipFree(c->histReach);
-  hipFree(c->dEnvMipOffset); hipFree(c->rayCounter32); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
+  hipFree(c->dEnvMipOffset); hipFree(c->rayCounterBuf); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
   hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->ownAS); if (c->ownVis) hipStreamDestroy(c->ownVis);
-  hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit);
+  hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit); hipEventDestroy(c->evGen); for (auto e : c->evTraceRing) hipEventDestroy(e);
+  if (c->streamRefit) hipStreamDestroy(c->streamRefit);
   delete c;
 }
 
@@ -300,7 +307,7 @@ int rtggx_set_async_compute(rtggx_context* c, int enable) {
   c->asyncCompute = enable != 0;
   c->streamAS = c->asyncCompute ? c->ownAS : c->streamMain;
   c->streamVis = c->asyncCompute ? c->ownVis : nullptr;
-  c->evVisStream = nullptr;
+  c->evVisStream = nullptr; c->genStream = nullptr;
   return 0;
 }
 
@@ -344,6 +351,7 @@ int rtggx_build_as(rtggx_context* c) {
 // structure are issued by the next rtggx_render_visibility on stream B -- behind the previous frame's traversal, beside that
 // frame's shading and denoising on the main stream -- without a synchronisation.  The topology stays the one the last build
 // chose; when the tree's cost has grown by RT_REFIT_REBUILD_RATIO since that build, this call rebuilds instead (synchronous).
+static int splitBvhPerSet(MeshDev& m);
 #ifndef RT_REFIT_REBUILD_RATIO
 #define RT_REFIT_REBUILD_RATIO 1.6f
 #endif
@@ -358,7 +366,9 @@ int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
     RT_HIP(syncStreams(c));
     for (int i = 1; i < RT_SETS; ++i) { RT_HIP(hipMalloc(&m.vertsBuf[i], bytes)); RT_HIP(hipMemcpy(m.vertsBuf[i], m.vertsBuf[0], bytes, hipMemcpyDeviceToDevice)); }
     for (auto& st : m.stage) RT_HIP(hipHostMalloc(&st, bytes));
-    m.deforming = true; m.verts = m.vertsBuf[c->setIndex]; m.latestSet = c->setIndex;
+    { const int r = splitBvhPerSet(m); if (r) return r; }
+    m.deforming = true; m.latestSet = c->setIndex;
+    c->selectSet(c->setIndex);
   }
   // the cost of the tree after an earlier refit has arrived: has the shape drifted too far from the one the topology was built for?
   if (m.costInFlight && hipEventQuery(m.evCost) == hipSuccess) { m.lastCost = *m.hCost; m.costInFlight = false; }
@@ -369,7 +379,9 @@ int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
     for (int k = 0; k < 3; ++k) { m.bmin[k] = 3.4e38f; m.bmax[k] = -3.4e38f; }
     for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; if (x < m.bmin[k]) m.bmin[k] = x; if (x > m.bmax[k]) m.bmax[k] = x; }
     const uint32_t refits = m.refits, rebuilds = m.rebuilds;
-    const int r = buildLbvh(c, slot, c->streamAS);
+    int r = buildLbvh(c, slot, c->streamAS);        // one tree again, aliased by all sets ...
+    if (!r) r = splitBvhPerSet(m);                   // ... and a copy per set for the refits to come
+    c->selectSet(c->setIndex);
     m.refits = refits; m.rebuilds = rebuilds + 1;
     return r;
   }
@@ -391,27 +403,38 @@ int rtggx_refit_stats(rtggx_context* c, uint32_t slot, float* costRatio, uint32_
   return 0;
 }
 
+// The boxes and leaf triangles of a deforming mesh once per input set (rtggx_context.h): copies of the tree just built.
+static int splitBvhPerSet(MeshDev& m) {
+  const size_t n = m.numTris, nn = n > 1 ? n - 1 : 1;
+  for (int i = 1; i < RT_SETS; ++i) {
+    if (m.trisBuf[i] != m.trisBuf[0]) continue;
+    RT_HIP(hipMalloc(&m.trisBuf[i], sizeof(BvhTri) * n)); RT_HIP(hipMemcpy(m.trisBuf[i], m.trisBuf[0], sizeof(BvhTri) * n, hipMemcpyDeviceToDevice));
+    RT_HIP(hipMalloc(&m.nodesBuf[i], sizeof(BvhNode) * nn)); RT_HIP(hipMemcpy(m.nodesBuf[i], m.nodesBuf[0], sizeof(BvhNode) * nn, hipMemcpyDeviceToDevice));
+    RT_HIP(hipMalloc(&m.nodes4Buf[i], sizeof(Bvh4Node) * nn)); RT_HIP(hipMemcpy(m.nodes4Buf[i], m.nodes4Buf[0], sizeof(Bvh4Node) * nn, hipMemcpyDeviceToDevice));
+  }
+  return 0;
+}
+
 // Issued by rtggx_render_visibility once the new input set is selected and fenced: bring the set's vertex buffer up to date and
 // refit.  Everything on stream B; returns true in *touched when stream B was given work the visibility pass must follow.
 static int issuePendingRefits(rtggx_context* c, bool* touched) {
   *touched = false;
+  const hipStream_t s = c->asyncCompute ? c->streamRefit : c->streamMain;
   for (uint32_t slot = 0; slot < RTGGX_NUM_MESH; ++slot) {
     MeshDev& m = c->mesh[slot];
     if (!m.deforming) continue;
     const size_t bytes = sizeof(float) * 6 * (size_t)m.numVerts;
     const uint32_t set = c->setIndex;
     if (m.pendingStage >= 0) {
-      RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.stage[m.pendingStage], bytes, hipMemcpyHostToDevice, c->streamAS));
-      m.pendingStage = -1; ++m.version; m.vertsVersion[set] = m.version; m.latestSet = set;
-      m.verts = m.vertsBuf[set];
-      const int r = refitLbvh(c, slot, c->streamAS);
-      if (r) return r;
-      *touched = true;
+      RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.stage[m.pendingStage], bytes, hipMemcpyHostToDevice, s));
+      m.pendingStage = -1; ++m.version;
     } else if (m.vertsVersion[set] != m.version) {      // no new shape this frame: this set still holds an older one
-      RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.vertsBuf[m.latestSet], bytes, hipMemcpyDeviceToDevice, c->streamAS));
-      m.vertsVersion[set] = m.version;
-      *touched = true;
-    }
+      RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.vertsBuf[m.latestSet], bytes, hipMemcpyDeviceToDevice, s));
+    } else continue;
+    m.vertsVersion[set] = m.version; m.latestSet = set;
+    const int r = refitLbvh(c, slot, set, s);           // this set's leaf triangles and nodes from this set's vertices
+    if (r) return r;
+    *touched = true;
   }
   return 0;
 }
@@ -462,12 +485,28 @@ int rtggx_transform_sh(rtggx_context* c) {
   return projectSH(c, c->streamAS);      // consumed by the shading kernel, which runs on stream B
 }
 
+// The frame on the device (RayTracedGGX::OnRender, RayTracedGGX.cpp:302-353, re-cut for this machine).  Three stages on three
+// streams, each stage one frame behind the one before it:
+//     stream C   visibility pass (its first kernel carries the frame constants) -> ray generation        of frame f + 1
+//     stream B   traversal                                                                                of frame f
+//     main       hit / miss shading -> spatial filters -> temporal pass -> tone map                       of frame f - 1
+// plus stream R for the vertex upload and tree refit of a deforming mesh.  No stage fills the machine by itself (the traversal
+// is a latency-bound chain of dependent gathers with 2.5 waves per SIMD resident on average: profiles/r02_*_limiter.txt), so
+// the three overlap almost freely; what each stage hands to the next exists three times (the input sets), and the events are
+//     evVis / stream order   visibility -> ray generation (same stream)
+//     evGen                  ray generation f    -> traversal f                (C -> B)
+//     evTraceRing[f & 3]     traversal f         -> shading f                  (B -> main)
+//                            traversal f - 2     -> ray generation f           (B -> C: the bins' cost record and the ray counters
+//                                                                               exist twice, by frame parity)
+//     evRefit                refit f             -> visibility f, traversal f  (R -> C, B)
+//     evSetRead[set]         last reader of a set -> the HOST, three frames later (the sample's frames-in-flight fence)
+// RTGGX_PIPELINE=0 restores the round-1 arrangement: ray generation and traversal both on stream B, the visibility pass on stream C
+// only where launches are small.  rtggx_set_async_compute(0) puts everything on the main stream.
 int rtggx_render_visibility(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
   if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamAS); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
-  // Stream B renders into the other input set, so the pass overlaps whatever the main stream still has queued from
-  // the previous frame (the sample overlaps its two queues in the same spirit, RayTracedGGX.cpp:302-353).
+  ++c->frameCounter;
   c->selectSet((c->setIndex + 1u) % RT_SETS);
   // the set was last read three frames ago: normally long done; a host that has run further ahead than that waits here
   static const bool gpuSideWait = getenv("RTGGX_SET_WAIT_ON_GPU") != nullptr;      // the cross-queue wait instead (measurement)
@@ -475,29 +514,34 @@ int rtggx_render_visibility(rtggx_context* c) {
     if (gpuSideWait) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
     else if (hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
   }
-  bool refitIssued = false;
-  { const int r = issuePendingRefits(c, &refitIssued); if (r) return r; }
-  if (refitIssued) RT_HIP(hipEventRecord(c->evRefit, c->streamAS));
-  // Where the pass runs: on stream C when the launches are small (rtggx_context.h: few enough rays that the machine is not
-  // saturated), on stream B otherwise.  Either way the pass follows the previous one (shared large-triangle list) and ray
-  // generation follows it: both through evVis.  (The split list the pass's first kernel empties is this set's own.)
-  static const uint32_t visRays = getenv("RTGGX_VIS_STREAM_RAYS") ? (uint32_t)atoi(getenv("RTGGX_VIS_STREAM_RAYS")) : RT_VIS_STREAM_RAYS;
-  // (with diffuse rays the main stream also runs the two diffuse filter passes and is the longer chain: there the extra
-  //  stream costs 1-2 % at 0.6-0.9 M rays, so beyond small launches it is used for all-metal frames only)
-  const FrameParams& cur = c->slots[c->slot];
-  const bool allMetal = !(cur.mat.RoughMetals[0][1] < 1.0f || cur.mat.RoughMetals[1][1] < 1.0f);
-  const bool small = c->streamVis && (chooseSliceShift(c, true, c->numBinsMax) != 0u || (allMetal && c->lastFrameRays < visRays));
-  const hipStream_t s = small ? c->streamVis : c->streamAS;
+  c->refitIssued = false;
+  { const int r = issuePendingRefits(c, &c->refitIssued); if (r) return r; }
+  if (c->refitIssued && c->asyncCompute) RT_HIP(hipEventRecord(c->evRefit, c->streamRefit));
+  const bool pipelined = c->pipeline != 0 && c->streamVis != nullptr;
+  hipStream_t s;
+  bool small = false;
+  if (pipelined) s = c->streamVis;
+  else {
+    // Round-1 arrangement: on stream C when the launches are small (few enough rays that the machine is not saturated), on
+    // stream B otherwise; with diffuse rays the main stream is the longer chain and the extra stream costs 1-2 %, so beyond small
+    // launches it is used for all-metal frames only.
+    static const uint32_t visRays = getenv("RTGGX_VIS_STREAM_RAYS") ? (uint32_t)atoi(getenv("RTGGX_VIS_STREAM_RAYS")) : RT_VIS_STREAM_RAYS;
+    const FrameParams& cur = c->slots[c->slot];
+    const bool allMetal = !(cur.mat.RoughMetals[0][1] < 1.0f || cur.mat.RoughMetals[1][1] < 1.0f);
+    small = c->streamVis && (chooseSliceShift(c, true, c->numBinsMax) != 0u || (allMetal && c->lastFrameRays < visRays));
+    s = small ? c->streamVis : c->streamAS;
+  }
   if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on the other stream
   // constants already on their way on stream B (timing mode uploads them in rtggx_update_as): a pass on stream C reads
   // dParams[slot] and has to be ordered behind that upload (evAS); on stream B it follows it anyway
   if (c->slotUploaded && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evAS, 0));
-  if (refitIssued && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evRefit, 0));       // the rasteriser reads this set's vertices
+  if (c->refitIssued && c->asyncCompute) RT_HIP(hipStreamWaitEvent(s, c->evRefit, 0));       // the rasteriser reads this set's vertices
   if (c->timing) hipEventRecord(c->tev[2], s);
   const int r = launchVisibility(c, c->slots[c->slot], s, c->streamVis ? c->evVis : nullptr);
   if (c->streamVis) c->evVisStream = s;
   if (c->timing) hipEventRecord(c->tev[13], s);
   if (small) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evVis, 0));
+  c->genStream = pipelined ? c->streamVis : c->streamAS;
   return r;
 }
 
@@ -507,13 +551,25 @@ int rtggx_ray_trace(rtggx_context* c) {
   if (!c->env.texels) { setError("rtggx_ray_trace: no environment map"); return -1; }
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
-  if (c->timing) hipEventRecord(c->tev[3], c->streamAS);
-  int r = launchRayTrace(c, c->slots[c->slot], c->streamAS, c->evRT);
-  // stream B runs ahead with ray generation and traversal; shading and the denoiser consume the bins, the G-buffer
-  // and the traced images on the main stream (evRT completes with the trace kernel)
-  RT_HIP(hipStreamWaitEvent(c->streamMain, c->evRT, 0));
-  // the main stream has now been given work that reads the current input set: stream B may not overwrite that set (two
-  // frames from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
+  const hipStream_t sGen = c->genStream ? c->genStream : c->streamAS, sTrace = c->streamAS;
+  const uint32_t f = c->frameCounter;
+  if (sGen != sTrace) {
+    // ray generation reads the cost record of the traversal two frames back and resets that frame's ray counters (frame parity)
+    if (c->traceRecorded[(f + 2u) & 3u]) RT_HIP(hipStreamWaitEvent(sGen, c->evTraceRing[(f + 2u) & 3u], 0));
+    // a caller that skipped the visibility pass (or uploaded constants on stream B): order ray generation behind the upload
+    if (c->slotUploaded) RT_HIP(hipStreamWaitEvent(sGen, c->evAS, 0));
+  }
+  if (c->refitIssued && c->asyncCompute) RT_HIP(hipStreamWaitEvent(sTrace, c->evRefit, 0));      // this set's tree
+  if (c->timing) hipEventRecord(c->tev[3], sGen);
+  hipEvent_t evDone = c->evTraceRing[f & 3u];
+  int r = launchRayTrace(c, c->slots[c->slot], sGen, sTrace, evDone);
+  c->traceRecorded[f & 3u] = true;
+  c->lastRayCounter32 = c->rayCounter32;
+  // stream B runs ahead with the traversal; shading and the denoiser consume the bins, the G-buffer and the traced images on
+  // the main stream (the event completes with the trace kernel)
+  RT_HIP(hipStreamWaitEvent(c->streamMain, evDone, 0));
+  // the main stream has now been given work that reads the current input set: that set may not be overwritten (three frames
+  // from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
   if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain, c->evSetRead[c->setIndex]);
   c->setReadRecorded[c->setIndex] = true;
   if (c->timing) hipEventRecord(c->tev[14], c->streamMain);
@@ -547,7 +603,7 @@ int rtggx_ray_count(rtggx_context* c, uint64_t* rays) {
   RT_CHECK_CTX(c);
   uint32_t h[256];
   RT_HIP(syncStreams(c));
-  RT_HIP(hipMemcpy(h, c->rayCounter32, sizeof h, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(h, c->lastRayCounter32, sizeof h, hipMemcpyDeviceToHost));
   uint64_t s = 0; for (auto v : h) s += v;
   *rays = s;
   return 0;
@@ -559,8 +615,8 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
   RT_CHECK_CTX(c);
   if (n > 768) { setError("rtggx_debug_counters: at most 768 words"); return -1; }
   RT_HIP(syncStreams(c));
-  RT_HIP(hipMemcpy(out, c->rayCounter32 + 256, (size_t)n * 4, hipMemcpyDeviceToHost));
-  if (reset) RT_HIP(hipMemset(c->rayCounter32 + 256, 0, 768 * 4));
+  RT_HIP(hipMemcpy(out, c->rayCounterBuf + 1024, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (reset) RT_HIP(hipMemset(c->rayCounterBuf + 1024, 0, 768 * 4));
   return 0;
 }
 

@@ -9,6 +9,8 @@
 // boxes, and 64-byte leaf triangles in Morton order.  The build runs on the context's build stream with host round trips
 // (PLOC rounds) and is off the per-frame path; what IS on it, for meshes that change shape, is refitLbvh at the end of
 // this file: new leaf triangles and boxes for the existing topology, five kernels on stream B, no host involvement.
+#include <algorithm>
+#include <utility>
 #include "rtggx_context.h"
 
 namespace rt {
@@ -312,9 +314,53 @@ __global__ void treeCostKernel(int numNodes, const float* __restrict__ nodeBox, 
   if ((threadIdx.x & 63) == 0 && a != 0.0f) atomicAdd(cost, a);
 }
 
+// Bottom-up box refit without global synchronisation: TREELETS.  At build time the host cuts the tree into subtrees of at most
+// RT_TREELET_NODES internal nodes (planRefit below); one workgroup refits one treelet, round by round of the PLOC build (a node's
+// children belong to earlier rounds), with the treelet's boxes in LDS and a workgroup barrier between rounds.  What is left above
+// the treelet roots is cut the same way again, until one treelet holds the root: two launches for the bunny and the dragon.
+// A child reference of an item is: >= 0 the position of another item of the same treelet (its box is in LDS);
+// 0xC0000000 | s leaf slot s (the primitive's box); 0x80000000 | n node n of an earlier level (its box is final in nodeBox).
+#define RT_TREELET_NODES 1024
+struct RefitTreelet { uint32_t itemBegin, roundBegin, numRounds, pad; };
+__global__ void __launch_bounds__(256) refitTreelets(const RefitTreelet* __restrict__ treelets, const int4* __restrict__ items, const uint32_t* __restrict__ roundOfs,
+                                                     const uint32_t* __restrict__ order, const float* __restrict__ triBox, float* __restrict__ nodeBox) {
+  __shared__ float box[RT_TREELET_NODES][6];
+  const RefitTreelet tl = treelets[blockIdx.x];
+  for (uint32_t r = 0; r < tl.numRounds; ++r) {
+    const uint32_t b = roundOfs[tl.roundBegin + r], e = roundOfs[tl.roundBegin + r + 1u];
+    for (uint32_t k = b + threadIdx.x; k < e; k += 256u) {
+      const int4 it = items[tl.itemBegin + k];
+      float c[2][6];
+      const int32_t ref[2] = {it.y, it.z};
+      for (int s = 0; s < 2; ++s) {
+        if (ref[s] >= 0) { for (int q = 0; q < 6; ++q) c[s][q] = box[ref[s]][q]; }
+        else {
+          const uint32_t x = (uint32_t)ref[s] & 0x3FFFFFFFu;
+          const float* p = ((uint32_t)ref[s] & 0x40000000u) ? &triBox[6 * (size_t)order[x]] : &nodeBox[6 * (size_t)x];
+          for (int q = 0; q < 6; ++q) c[s][q] = p[q];
+        }
+      }
+      for (int q = 0; q < 3; ++q) {
+        const float mn = fminf(c[0][q], c[1][q]), mx = fmaxf(c[0][3 + q], c[1][3 + q]);
+        box[k][q] = mn; box[k][3 + q] = mx;
+        nodeBox[6 * (size_t)it.x + q] = mn; nodeBox[6 * (size_t)it.x + 3 + q] = mx;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Buffers that exist once per input set when the mesh deforms and alias one allocation while it is static.
+template <typename T> static void freeAliased(T* (&buf)[RT_SETS]) {
+  for (int i = 0; i < RT_SETS; ++i) { bool dup = false; for (int j = 0; j < i; ++j) dup = dup || buf[j] == buf[i]; if (!dup && buf[i]) hipFree(buf[i]); }
+  for (auto& b : buf) b = nullptr;
+}
 void freeBuildProducts(MeshDev& m) {
-  hipFree(m.order); hipFree(m.left); hipFree(m.right); hipFree(m.nodeParent); hipFree(m.leafParent); hipFree(m.nodeBox); hipFree(m.triBox); hipFree(m.arrive);
-  m.order = nullptr; m.left = m.right = m.nodeParent = m.leafParent = nullptr; m.nodeBox = m.triBox = nullptr; m.arrive = nullptr;
+  hipFree(m.order); hipFree(m.left); hipFree(m.right); hipFree(m.nodeParent); hipFree(m.leafParent); hipFree(m.nodeBox); hipFree(m.triBox); hipFree(m.dTreelets); hipFree(m.dRefitItems); hipFree(m.dRefitRounds);
+  m.order = nullptr; m.left = m.right = m.nodeParent = m.leafParent = nullptr; m.nodeBox = m.triBox = nullptr; m.dTreelets = nullptr; m.dRefitItems = nullptr; m.dRefitRounds = nullptr;
+  m.roundBase.clear(); m.refitLevels.clear();
+  freeAliased(m.nodesBuf); freeAliased(m.nodes4Buf); freeAliased(m.trisBuf);
+  m.nodes = nullptr; m.nodes4 = nullptr; m.tris = nullptr;
 }
 
 static int launchTreeCost(MeshDev& m, hipStream_t s) {
@@ -325,25 +371,26 @@ static int launchTreeCost(MeshDev& m, hipStream_t s) {
   return 0;
 }
 
-// New boxes for the existing tree from the CURRENT vertex buffer (m.verts): leaf triangles, bottom-up box fit with one arrival
-// counter per node, the 64-byte binary nodes (for the oracle / tests) and their 4-wide collapse (for the trace kernel), the
-// tree's cost.  Everything on stream `s` (stream B: behind the previous frame's traversal, which still reads the old boxes).
-int refitLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
+// New boxes for the existing tree from the vertex buffer of input set `set`, into that set's leaf triangles and nodes: the leaf
+// triangles, the node boxes treelet level by treelet level (refitTreelets), the
+// 64-byte binary nodes (for the oracle / tests) and their 4-wide collapse (for the trace kernel), every 8th time the tree's cost.
+// No host round trip; everything on stream `s` (stream R, beside whatever the other streams are doing).
+int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
   MeshDev& m = c->mesh[slot];
   const uint32_t n = m.numTris;
-  if (n == 0 || !m.tris) return 0;
+  if (n == 0 || !m.trisBuf[set]) return 0;
   const uint32_t nb = (n + 255) / 256;
-  if (!m.triBox) { setError("rtggx_refit_as: mesh %u has no build to refit", slot); return -1; }
-  hipLaunchKernelGGL(refitTris, dim3(nb), dim3(256), 0, s, (int)n, (const float*)m.verts, (const uint32_t*)m.indices, m.tris, m.triBox);
+  if (!m.triBox || (n > 1 && m.refitLevels.empty())) { setError("rtggx_refit_as: mesh %u has no PLOC build to refit (RTGGX_BVH_RADIX_TREE builds cannot be refitted)", slot); return -1; }
+  hipLaunchKernelGGL(refitTris, dim3(nb), dim3(256), 0, s, (int)n, (const float*)m.vertsBuf[set], (const uint32_t*)m.indices, m.trisBuf[set], m.triBox);
   if (n > 1) {
-    RT_HIP(hipMemsetAsync(m.arrive, 0, 4 * (size_t)n, s));
-    hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right,
-                       (const int32_t*)m.nodeParent, (const int32_t*)m.leafParent, m.nodeBox, m.arrive);
-    hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right, (const float*)m.nodeBox, m.nodes);
+    for (const auto& lv : m.refitLevels)      // (first treelet, count): level after level
+      hipLaunchKernelGGL(refitTreelets, dim3(lv.second), dim3(256), 0, s, (const RefitTreelet*)m.dTreelets + lv.first, (const int4*)m.dRefitItems, (const uint32_t*)m.dRefitRounds,
+                         (const uint32_t*)m.order, (const float*)m.triBox, m.nodeBox);
+    hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right, (const float*)m.nodeBox, m.nodesBuf[set]);
     hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right,
-                       (const int32_t*)m.nodeParent, (const float*)m.nodeBox, m.nodes4);
-    { const int r = launchTreeCost(m, s); if (r) return r; }
-    if (!m.costInFlight) {
+                       (const int32_t*)m.nodeParent, (const float*)m.nodeBox, m.nodes4Buf[set]);
+    if (!m.costInFlight && (m.refits & 7u) == 0u) {
+      { const int r = launchTreeCost(m, s); if (r) return r; }
       RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s));
       RT_HIP(hipEventRecord(m.evCost, s));
       m.costInFlight = true;
@@ -354,19 +401,81 @@ int refitLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   return 0;
 }
 
+// The refit schedule of a freshly built PLOC tree (host side; the build is synchronous anyway).  left / right: the children of the
+// numNodes internal nodes as the build left them (>= 0 node, < 0 ~leaf slot); PLOC hands out node indices round by round, so a
+// child's index is smaller than its parent's and roundBase tells a node's round.
+static int planRefit(MeshDev& m, const std::vector<int32_t>& left, const std::vector<int32_t>& right, hipStream_t s) {
+  const int numNodes = (int)m.numTris - 1;
+  std::vector<int32_t> parent(numNodes, -1), roundOf(numNodes, 0);
+  for (int i = 0; i < numNodes; ++i) { if (left[i] >= 0) parent[left[i]] = i; if (right[i] >= 0) parent[right[i]] = i; }
+  for (size_t k = 0; k + 1 < m.roundBase.size(); ++k) for (uint32_t i = m.roundBase[k]; i < m.roundBase[k + 1]; ++i) roundOf[i] = (int32_t)k;
+  std::vector<uint8_t> pending(numNodes, 1);      // nodes no level has taken yet
+  std::vector<uint32_t> cnt(numNodes);
+  std::vector<int32_t> local(numNodes, -1);
+  std::vector<RefitTreelet> treelets; std::vector<int4> items; std::vector<uint32_t> rounds;
+  m.refitLevels.clear();
+  int remaining = numNodes;
+  while (remaining > 0) {
+    // pending nodes in each subtree (children come first in index order)
+    for (int i = 0; i < numNodes; ++i) {
+      cnt[i] = pending[i] ? 1u : 0u;
+      if (pending[i]) { if (left[i] >= 0) cnt[i] += cnt[left[i]]; if (right[i] >= 0) cnt[i] += cnt[right[i]]; }
+    }
+    const uint32_t firstTreelet = (uint32_t)treelets.size();
+    for (int root = 0; root < numNodes; ++root) {
+      if (!pending[root] || cnt[root] > RT_TREELET_NODES) continue;
+      if (parent[root] >= 0 && cnt[parent[root]] <= RT_TREELET_NODES) continue;      // an inner node of somebody else's treelet
+      // the pending nodes below `root`, by PLOC round (then by index: deterministic)
+      std::vector<int32_t> nodes, stack{root};
+      while (!stack.empty()) {
+        const int32_t v = stack.back(); stack.pop_back();
+        nodes.push_back(v);
+        if (left[v] >= 0 && pending[left[v]]) stack.push_back(left[v]);
+        if (right[v] >= 0 && pending[right[v]]) stack.push_back(right[v]);
+      }
+      std::sort(nodes.begin(), nodes.end(), [&](int32_t a, int32_t b) { return roundOf[a] != roundOf[b] ? roundOf[a] < roundOf[b] : a < b; });
+      RefitTreelet tl{(uint32_t)items.size(), (uint32_t)rounds.size(), 0u, 0u};
+      for (size_t k = 0; k < nodes.size(); ++k) local[nodes[k]] = (int32_t)k;
+      for (size_t k = 0; k < nodes.size(); ++k) {
+        if (k == 0 || roundOf[nodes[k]] != roundOf[nodes[k - 1]]) { rounds.push_back((uint32_t)k); ++tl.numRounds; }
+        const int32_t v = nodes[k];
+        const auto ref = [&](int32_t ch) -> int32_t {
+          if (ch < 0) return (int32_t)(0xC0000000u | (uint32_t)~ch);                        // leaf slot
+          if (pending[ch]) return local[ch];                                                // same treelet (its subtree is closed)
+          return (int32_t)(0x80000000u | (uint32_t)ch);                                     // finished by an earlier level
+        };
+        items.push_back(make_int4(v, ref(left[v]), ref(right[v]), 0));
+      }
+      rounds.push_back((uint32_t)nodes.size());
+      treelets.push_back(tl);
+      for (int32_t v : nodes) { pending[v] = 2; }      // taken by this level (still "pending" for the scan of this level's other roots)
+      remaining -= (int)nodes.size();
+    }
+    for (int i = 0; i < numNodes; ++i) if (pending[i] == 2) pending[i] = 0;
+    if (treelets.size() == firstTreelet) { setError("planRefit: no progress with %d nodes left", remaining); return -3; }
+    m.refitLevels.push_back({firstTreelet, (uint32_t)treelets.size() - firstTreelet});
+  }
+  RT_HIP(hipMalloc(&m.dTreelets, sizeof(RefitTreelet) * treelets.size()));
+  RT_HIP(hipMalloc(&m.dRefitItems, sizeof(int4) * items.size()));
+  RT_HIP(hipMalloc(&m.dRefitRounds, 4 * rounds.size()));
+  RT_HIP(hipMemcpyAsync(m.dTreelets, treelets.data(), sizeof(RefitTreelet) * treelets.size(), hipMemcpyHostToDevice, s));
+  RT_HIP(hipMemcpyAsync(m.dRefitItems, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice, s));
+  RT_HIP(hipMemcpyAsync(m.dRefitRounds, rounds.data(), 4 * rounds.size(), hipMemcpyHostToDevice, s));
+  RT_HIP(hipStreamSynchronize(s));      // the host vectors go out of scope
+  return 0;
+}
+
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   MeshDev& m = c->mesh[slot];
   const uint32_t n = m.numTris;
-  if (m.nodes) { RT_HIP(hipFree(m.nodes)); m.nodes = nullptr; }
-  if (m.tris) { RT_HIP(hipFree(m.tris)); m.tris = nullptr; }
-  if (m.nodes4) { RT_HIP(hipFree(m.nodes4)); m.nodes4 = nullptr; }
   m.root = -1; m.depth = 0;
-  freeBuildProducts(m);
+  freeBuildProducts(m);       // also the nodes / leaf triangles of every input set
   if (n == 0) return 0;
   RT_HIP(hipMalloc(&m.tris, sizeof(BvhTri) * (size_t)n));
   RT_HIP(hipMalloc(&m.nodes, sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)));
   RT_HIP(hipMalloc(&m.nodes4, sizeof(Bvh4Node) * (size_t)(n > 1 ? n - 1 : 1)));
   RT_HIP(hipMemsetAsync(m.nodes4, 0, sizeof(Bvh4Node) * (size_t)(n > 1 ? n - 1 : 1), s));
+  for (int i = 0; i < RT_SETS; ++i) { m.nodesBuf[i] = m.nodes; m.nodes4Buf[i] = m.nodes4; m.trisBuf[i] = m.tris; }     // one allocation for all input sets until the mesh deforms
 
   const float* mn = m.bmin; const float* mx = m.bmax;   // vertex bounds recorded by rtggx_set_mesh
   float3 bmin = make_float3(mn[0], mn[1], mn[2]);
@@ -407,6 +516,7 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
       RT_HIP(hipMalloc(&keepPos, 4 * (size_t)n)); RT_HIP(hipMalloc(&mergePos, 4 * (size_t)n));
       hipLaunchKernelGGL(plocInit, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, clRef[0], clBox[0]);
       int m = (int)n, nodeBase = 0, a = 0;
+      std::vector<uint32_t> roundBase;
       const int radius = getenv("RTGGX_PLOC_RADIUS") ? atoi(getenv("RTGGX_PLOC_RADIUS")) : RT_PLOC_RADIUS;
       while (m > 1) {
         const dim3 g((m + 255) / 256);
@@ -422,8 +532,11 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
         RT_HIP(hipStreamSynchronize(s));
         const int kept = (int)(lastPos[0] + lastFlags[0]), merged = (int)(lastPos[1] + lastFlags[1]);
         if (merged <= 0 || kept != m - merged) { setError("buildBvh: clustering made no progress (%d clusters, %d merges, %d kept)", m, merged, kept); return -3; }
+        roundBase.push_back((uint32_t)nodeBase);
         nodeBase += merged; m = kept; a ^= 1;
       }
+      roundBase.push_back((uint32_t)nodeBase);
+      c->mesh[slot].roundBase = roundBase;
       root = (int32_t)n - 2;                      // the last node created
       const int32_t none = -1;
       RT_HIP(hipMemcpyAsync(nodeParent + root, &none, 4, hipMemcpyHostToDevice, s));
@@ -438,11 +551,18 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   RT_HIP(hipGetLastError());
   RT_HIP(hipMemcpyAsync(&m.depth, arrive + n, 4, hipMemcpyDeviceToHost, s));
   // the topology and the per-primitive boxes stay for rtggx_refit_as (freed with the mesh or by the next build)
-  m.order = order[cur]; m.left = left; m.right = right; m.nodeParent = nodeParent; m.leafParent = leafParent; m.nodeBox = nodeBox; m.triBox = triBox; m.arrive = arrive;
+  m.order = order[cur]; m.left = left; m.right = right; m.nodeParent = nodeParent; m.leafParent = leafParent; m.nodeBox = nodeBox; m.triBox = triBox;
+  if (m.roundBase.size() >= 2) {      // PLOC build: plan the refit (rtggx_refit_as) while the topology is at hand
+    std::vector<int32_t> hl(n - 1), hr(n - 1);
+    RT_HIP(hipMemcpyAsync(hl.data(), left, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, s)); RT_HIP(hipMemcpyAsync(hr.data(), right, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, s));
+    RT_HIP(hipStreamSynchronize(s));
+    const int r = planRefit(m, hl, hr, s);
+    if (r) return r;
+  }
   if (n > 1) { const int r = launchTreeCost(m, s); if (r) return r; RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s)); }
   RT_HIP(hipStreamSynchronize(s));
   if (n > 1) { m.builtCost = m.lastCost = *m.hCost; m.costInFlight = false; }
-  hipFree(codes[0]); hipFree(codes[1]); hipFree(order[cur ^ 1]); hipFree(hist);
+  hipFree(codes[0]); hipFree(codes[1]); hipFree(order[cur ^ 1]); hipFree(hist); hipFree(arrive);
   return 0;
 }
 

@@ -199,7 +199,7 @@ RT_DEV f2 calcBarycentrics(const f4 p[3], f2 ndc) {   // :204-225
 struct GenArgs {
   const unsigned long long* visDepth;
   uint32_t* normalOut; uint16_t* roughMetalOut; uint32_t* velocityOut; uint32_t* reflOut; uint32_t* diffOut;
-  const uint16_t* roughMetalPrev; const uint32_t* diffPrev;   // the other input set = what these targets held before this frame
+  const uint16_t* roughMetalPrev;   // the previous frame's input set = what this target held before this frame
   const float* verts0; const uint32_t* idx0; const float* verts1; const uint32_t* idx1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* cosSin;
@@ -264,7 +264,8 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
     // G-buffer stores :552-554
     A.normalOut[pix] = packR10G10B10A2(N.x * 0.5f + 0.5f, N.y * 0.5f + 0.5f, N.z * 0.5f + 0.5f, hit ? 1.0f : 0.0f);
     // the reference leaves RoughMetal untouched where nothing is hit, and RayTracingOut1 where no diffuse ray is traced:
-    // with several input sets "untouched" means carrying the word of the previous frame.s set over
+    // with several input sets "untouched" means carrying the word of the previous frame's set over.  RoughMetal is carried here
+    // (the previous set's was written by the previous ray generation, earlier on this stream); RayTracingOut1 by shadeKernel
     A.roughMetalOut[pix] = hit ? (uint16_t)packR8G8(rghMtl.x, rghMtl.y) : A.roughMetalPrev[pix];
     A.velocityOut[pix] = packR16G16F(velocity.x, velocity.y);
 
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
         rd.dx = dir.x; rd.dy = dir.y; rd.dz = dir.z; rd.tmax = 10000.0f;
         rd.pixel = (uint32_t)pix; rd.skip = skip; rd.flags = 1u;
         rd.wx = color.x * (1.0f - 0.04f); rd.wy = color.y * (1.0f - 0.04f); rd.wz = color.z * (1.0f - 0.04f);   // :532
-      } else A.diffOut[pix] = A.diffPrev[pix];
+      }      // else: RayTracingOut1 keeps what it held -- carried over from the previous frame's set by shadeKernel (see there)
     }
   }
   // wave-level compaction into this wave's own bin (rt_queue.h): reflection rays first, then diffuse rays
@@ -365,6 +366,8 @@ struct ShadeArgs {
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* sh;
   uint32_t* reflOut; uint32_t* diffOut;
+  // carry-over of RayTracingOut1 (see the kernel)
+  const uint32_t* diffPrev; const unsigned long long* visDepth; uint32_t tilesX, rowBegin, rowEnd, carryMask;
 };
 
 // computeReflection at recursion depth 1 (:424-484)
@@ -386,6 +389,21 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict
   const EnvRef env{A.env, A.envSize, A.envMips, A.envMipOffset};
   // workgroup b shades the four bins its rayGen namesake filled: wave w <-> bin 4b + w
   const uint32_t bin = blockIdx.x * 4u + (threadIdx.x >> 6);
+  // Carry-over of RayTracingOut1.  The reference has ONE such texture and leaves it untouched where no diffuse ray is traced
+  // (covered pixels of a fully metallic instance, RayTracing.hlsl:559): it keeps the last value ever written there.  With three
+  // input sets that is the word of the previous frame's set -- final only once that frame's shading has run, which is earlier
+  // on THIS stream; ray generation (stream C, a frame ahead of this stream) must not read it.  The wave's bin is its 8x8 pixel
+  // sub-tile, so it walks those pixels: covered by an instance with metallic >= 1 (carryMask bit per instance) -> copy.
+  if (A.carryMask != 0u) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t px = (blockIdx.x % A.tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = A.rowBegin + (blockIdx.x / A.tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
+    if (px < fp.W && py < A.rowEnd) {
+      const size_t pix = (size_t)py * fp.W + px;
+      const uint32_t vis = (uint32_t)A.visDepth[pix];
+      if (vis != 0u && ((A.carryMask >> ((vis - 1u) >> 24)) & 1u)) A.diffOut[pix] = A.diffPrev[pix];
+    }
+  }
   const uint32_t count = min(A.binCount[bin] & 0xFFu, RT_BIN);
   for (uint32_t i = threadIdx.x & 63u; i < count; i += 64u) {
     const size_t slot = (size_t)bin * RT_BIN + i;
@@ -434,14 +452,14 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict
 // =========================================================================================================
 // host side
 // =========================================================================================================
-int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done) {
+int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hipStream_t s, hipEvent_t done) {
   uint32_t rb, re;
   passRows(fp, ROWS_GBUFFER, rb, re);
   if (re <= rb) return 0;
   const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
   GenArgs G;
   G.visDepth = c->visDepth; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
-  G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS]; G.diffPrev = c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
+  G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
   G.verts0 = c->mesh[0].verts; G.idx0 = c->mesh[0].indices; G.verts1 = c->mesh[1].verts; G.idx1 = c->mesh[1].indices;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
   G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;
@@ -457,7 +475,12 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEv
   static const uint32_t frontWork = getenv("RTGGX_SPLIT_FRONT") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_FRONT")) : RT_SPLIT_FRONT;
   G.frontWork = frontWork < splitWork ? frontWork : splitWork;
   G.splitWork = splitWork; G.splitMaxShift = splitMaxShift < 3u ? splitMaxShift : 3u; G.splitCap = splitCap < RT_SPLIT_CAP ? splitCap : RT_SPLIT_CAP;
-  hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, s, c->dParams + c->slot, G);
+  if (sGen != s && c->attachEvents) hipExtLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, sGen, nullptr, c->evGen, 0, (const FrameParams*)(c->dParams + c->slot), G);
+  else hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, sGen, c->dParams + c->slot, G);
+  if (sGen != s) {      // ray generation on the visibility pass's stream, the traversal on stream B behind it
+    if (!c->attachEvents) RT_HIP(hipEventRecord(c->evGen, sGen));
+    RT_HIP(hipStreamWaitEvent(s, c->evGen, 0));
+  }
   if (c->timing) hipEventRecord(c->tev[11], s);
   const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size() && (c->ringTick++ % c->ringStride) == 0u;
   // a sampled frame: the event pair of the kernel ring rides on the dispatch (and `done` is recorded behind it)
@@ -477,8 +500,10 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
   uint32_t rb, re;
   passRows(fp, ROWS_GBUFFER, rb, re);
   if (re <= rb) return 0;
-  const uint32_t numTiles = ((fp.W + 15) / 16) * ((re - rb + 15) / 16);
+  const uint32_t tilesX = (fp.W + 15) / 16, numTiles = tilesX * ((re - rb + 15) / 16);
   ShadeArgs S;
+  S.diffPrev = c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS]; S.visDepth = c->visDepth; S.tilesX = tilesX; S.rowBegin = rb; S.rowEnd = re;
+  S.carryMask = (fp.mat.RoughMetals[0][1] >= 1.0f ? 1u : 0u) | (fp.mat.RoughMetals[1][1] >= 1.0f ? 2u : 0u);      // rghMtl.y < 1 is the test of :559; it is the instance's constant
   S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitKey*)c->hitQueue; S.binCount = c->binCount;
   S.verts0 = c->mesh[0].verts; S.idx0 = c->mesh[0].indices; S.verts1 = c->mesh[1].verts; S.idx1 = c->mesh[1].indices;
   S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 #include "rtggx_device.h"
 
@@ -40,7 +41,7 @@ struct MeshDev {
   uint32_t stageNext = 0; int pendingStage = -1;
   // what the build leaves behind for the refit (lbvh.hip): the binary topology, per-primitive boxes, arrival counters
   uint32_t* order = nullptr; int32_t *left = nullptr, *right = nullptr, *nodeParent = nullptr, *leafParent = nullptr;
-  float *nodeBox = nullptr, *triBox = nullptr; uint32_t* arrive = nullptr;
+  float *nodeBox = nullptr, *triBox = nullptr;
   float* dCost = nullptr;        // device: sum of the node-box half-areas of the current tree (SAH cost up to constants)
   float* hCost = nullptr;        // pinned: its copy, refreshed asynchronously after every refit
   hipEvent_t evCost = nullptr; bool costInFlight = false;
@@ -51,6 +52,15 @@ struct MeshDev {
   BvhNode* nodes = nullptr;      // numTris - 1 (0 when numTris == 1): the binary LBVH as built
   Bvh4Node* nodes4 = nullptr;    // same count, sparse: the 4-wide collapse the trace kernel walks
   BvhTri* tris = nullptr;        // numTris, leaf (Morton) order
+  // the three above are those of the CURRENT input set: like the vertices, the boxes and leaf triangles of a deforming mesh exist
+  // once per input set (frame f + 1's refit on stream R writes its set while frame f's traversal still walks the other)
+  BvhNode* nodesBuf[RT_SETS] = {}; Bvh4Node* nodes4Buf[RT_SETS] = {}; BvhTri* trisBuf[RT_SETS] = {};
+  // PLOC creates nodes in rounds; a node's children are leaves or nodes of EARLIER rounds, and node indices are handed out round
+  // by round: refitting round after round needs no synchronisation inside a round (lbvh.hip: refitLbvh)
+  std::vector<uint32_t> roundBase;      // roundBase[k] = first node of round k; roundBase.back() = numTris - 1
+  // the refit schedule planned from it at build time (lbvh.hip planRefit): treelets of <= 1024 nodes, one workgroup each, level by level
+  void *dTreelets = nullptr, *dRefitItems = nullptr; uint32_t* dRefitRounds = nullptr;
+  std::vector<std::pair<uint32_t, uint32_t>> refitLevels;      // (first treelet, number of treelets) per launch
   int32_t root = -1;             // 0, or ~0 for a single-triangle mesh
   uint32_t depth = 0;            // deepest leaf (number of ancestors): bounds the traversal stack
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // vertex bounds (Morton normalisation box)
@@ -91,6 +101,15 @@ struct rtggx_context {
   uint32_t historyApron = 18;           // rows of TemporalSSOut beyond the strip the caller delivers between frames (rtggx_set_history_apron)
   uint32_t* histReach = nullptr;        // device word: the furthest a history tap reached beyond them, in rows (temporalKernel)
   hipStream_t streamMain = nullptr, streamAS = nullptr, ownMain = nullptr;
+  hipStream_t streamRefit = nullptr;               // stream R: vertex uploads and tree refits of deforming meshes (rtggx_refit_as)
+  // Frame pipeline (capi.hip): 1 = three stages on three streams -- C: visibility + ray generation, B: traversal, main: shading +
+  // denoiser + tone map -- so that ray generation of frame f + 1 runs beside the traversal of frame f; 0 = the round-1 arrangement
+  // (ray generation and traversal on B; the visibility pass on C only where launches are small).  RTGGX_PIPELINE overrides.
+  int pipeline = 1;
+  bool refitIssued = false; bool traceRecorded[4] = {}; hipStream_t genStream = nullptr;   // per-frame issue state (capi.hip)
+  uint32_t frameCounter = 0;                       // frames started (rtggx_render_visibility); parity selects binWork / ray counters
+  hipEvent_t evGen = nullptr;                      // ray generation of the current frame done (C -> B)
+  hipEvent_t evTraceRing[4] = {};                  // traversal of frame f done: [f & 3] (B -> main; B -> C two frames later: binWork)
   hipStream_t ownAS = nullptr, ownVis = nullptr;   // the context's own stream B / stream C; streamAS / streamVis alias streamMain / null while
   bool asyncCompute = true;                        // rtggx_set_async_compute(0) is in force (the sample's [A] toggle: one queue, submission order)
   // Launches with few rays (thin strips, small frames) leave most of the machine idle and last as long as stream B's chain
@@ -129,7 +148,9 @@ struct rtggx_context {
     setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
     splitList = splitListBuf[i]; splitCount = largeCount ? largeCount + 1 + i : nullptr;
-    for (auto& m : mesh) m.verts = m.vertsBuf[i];
+    for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.tris = m.trisBuf[i]; }
+    const uint32_t par = pipeline != 0 ? (frameCounter & 1u) : 0u;
+    binWork = binWorkBuf[par]; rayCounter32 = rayCounterBuf + (pipeline != 0 ? (frameCounter & 3u) : 0u) * 256u;
   }
   uint2 *tss[2] = {nullptr, nullptr}, *fltRfl = nullptr, *fltDff = nullptr;
   uint32_t frameParity = 0;
@@ -139,6 +160,8 @@ struct rtggx_context {
   uint32_t* largeCount = nullptr;       // [0] entries of largeTris, [1 + set] entries of splitList[set] (zeroed by that set's clearVisDepth)
   // Bins whose traversal was expensive in the previous frame are traced by 2, 4 or 8 waves (trace.hip "adaptive split"):
   uint32_t* binWork = nullptr;          // [numBinsMax] lane-steps the trace kernel spent on the bin (read and zeroed by rayGenKernel)
+  uint32_t* binWorkBuf[2] = {};         // by frame parity: ray generation of frame f reads what the traversal of frame f - 2 recorded
+                                        // (frame f - 1's may still be running beside it) and the traversal of frame f records anew
   // per input set (the visibility pass of the next frame, which empties its set's list, may run beside this frame's traversal):
   uint32_t* splitListBuf[RT_SETS] = {}; // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a listed bin
   uint32_t* splitList = nullptr; uint32_t* splitCount = nullptr;     // the current set's (selectSet)
@@ -162,7 +185,11 @@ struct rtggx_context {
   uint32_t* hostRayCounters = nullptr;  // pinned copy of rayCounter32[0..255], refreshed asynchronously after every trace launch
   hipEvent_t evRayCounters = nullptr; bool rayCountersInFlight = false; uint32_t traceLaunches = 0;
   uint32_t lastFrameRays = 0xFFFFFFFFu; // rays of the most recent frame whose counters have arrived (unknown: assume a full machine)
-  uint32_t* rayCounter32 = nullptr;     // 256 per-frame partial counts written by the trace kernel
+  uint32_t* rayCounter32 = nullptr;     // 256 per-frame partial counts written by the trace kernel (the current frame's half of ...)
+  uint32_t* rayCounterBuf = nullptr;    // ... [4][256] by frame number & 3, then 768 words of RT_TRACE_STATS counters.  (Four, not two like binWork:
+                                        // ray generation of frame f zeroes its quarter, and the asynchronous copy of frame f - 2's counters to the
+                                        // host, queued behind that frame's traversal, may not have run yet; frame f - 4's has.)
+  uint32_t* lastRayCounter32 = nullptr; // the half of the most recent rtggx_ray_trace (rtggx_ray_count)
   unsigned long long* rayCounter = nullptr;   // [0..255] last frame, [256..511] running total
 
   // per-frame constants: ring of RayTracer::FrameCount slots (host side; kernels take them by value)
@@ -206,9 +233,9 @@ int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s);
 int uploadScene(rtggx_context* c, hipStream_t s);
 int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
-int refitLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);      // boxes of the existing tree from mesh.verts (current set): no host round trip
+int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s);      // boxes of the existing tree from the vertices of input set `set`, into that set's BVH arrays: no host round trip
 void freeBuildProducts(MeshDev& m);
-int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);   // ray generation + traversal
+int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hipStream_t sTrace, hipEvent_t done = nullptr);   // ray generation on sGen, traversal on sTrace (joined by evGen when they differ)
 // `done` (may be null) on the launch functions below: an event that completes with the pass's last kernel.  It rides on that
 // kernel's own completion signal (hipExtLaunchKernelGGL) instead of a marker packet behind it: a marker costs its queue
 // 5-7 us, and the frame's two chains had four of them (rocprofv3 kernel trace, profiles/).

@@ -31,7 +31,9 @@
 namespace rt {
 
 #define RT_PRIME_LAUNCHES 4u  // launches of a context whose ray / split counters are read back synchronously (launchTrace)
+#ifndef RT_STACK
 #define RT_STACK 24          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: see tools/probes/trace_stats_probe.py)
+#endif
 
 struct TraceArgs {
   const float4* nodes0; const float4* tris0;   // 128-byte 4-wide nodes (8 x float4), 64-byte leaf triangles (4 x float4)
@@ -41,7 +43,8 @@ struct TraceArgs {
   const RayRec* rays; HitKey* hits;
   const uint32_t* binCount; uint32_t numBins;
   int32_t* overflow;        // [entry][numBinsMax * RT_BIN] spill area for stacks deeper than RT_STACK
-  uint32_t* rayTotals;       // 256 per-frame partial counters (+ RT_TRACE_STATS words from 256)
+  uint32_t* rayTotals;       // 256 per-frame partial counters (the current frame parity's half)
+  uint32_t* stats;           // 768 RT_TRACE_STATS words
   unsigned long long* runTotals;   // 256 running totals (rtggx_ray_total)
   uint32_t countRowBegin, countRowEnd, width;
   size_t spillStride;
@@ -318,16 +321,16 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
 #ifdef RT_TRACE_STATS
   for (int o = 32; o > 0; o >>= 1) { stNode += __shfl_down(stNode, o); stLeaf += __shfl_down(stLeaf, o); stSteal += __shfl_down(stSteal, o); stDeep = max(stDeep, (uint32_t)__shfl_down((int)stDeep, o)); }
   if (lane == 0) {   // lane node steps, lane leaf steps, wave iterations, waves, deepest stack, wave lifetime (sum, max), most iterations, steals
-    uint32_t* st = A.rayTotals + 256 + (bin & 15u) * 16u;      // 16 copies to keep the atomics off one word
+    uint32_t* st = A.stats + (bin & 15u) * 16u;      // 16 copies to keep the atomics off one word
     atomicAdd(&st[0], stNode); atomicAdd(&st[1], stLeaf); atomicAdd(&st[2], stIter);
     atomicAdd(&st[3], 1u); atomicMax(&st[4], stDeep);
     const uint32_t life = (uint32_t)((clock64() - stT0) >> 4);
     {   // histograms of wave start / end times, 8 us buckets from the stamp of stampKernel (wall clock: 100 MHz)
-      const unsigned long long t0 = *reinterpret_cast<const unsigned long long*>(A.rayTotals + 1020);
+      const unsigned long long t0 = *reinterpret_cast<const unsigned long long*>(A.stats + 764);
       const unsigned long long now = wall_clock64();
       const uint32_t be = min((uint32_t)((now - t0) / 800ull), 31u);
       const uint32_t bs = min((uint32_t)((stW0 - t0) / 800ull), 31u);
-      atomicAdd(&A.rayTotals[512 + be], 1u); atomicAdd(&A.rayTotals[544 + bs], 1u);
+      atomicAdd(&A.stats[256 + be], 1u); atomicAdd(&A.stats[288 + bs], 1u);
     }
     atomicAdd(&st[5], life >> 6); atomicMax(&st[6], life); atomicMax(&st[7], stIter); atomicAdd(&st[8], stSteal); atomicAdd(&st[9], stLeafPhase);
   }
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
 }
 
 #ifdef RT_TRACE_STATS
-__global__ void stampKernel(uint32_t* totals) { *reinterpret_cast<unsigned long long*>(totals + 1020) = wall_clock64(); }
+__global__ void stampKernel(uint32_t* stats) { *reinterpret_cast<unsigned long long*>(stats + 764) = wall_clock64(); }
 #endif
 
 // How many waves per bin for the whole launch: one when the rays fill the chip (~5000 wave slots x 64 lanes); 2, 4 or
@@ -374,11 +377,11 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
     c->spillEntries = deepest - RT_STACK;
     RT_HIP(hipMalloc(&c->stackOverflow, (size_t)c->spillEntries * c->numBinsMax * 512 * 4));
   }
-  T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32; T.runTotals = c->rayCounter + 256;
+  T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32; T.stats = c->rayCounterBuf + 1024; T.runTotals = c->rayCounter + 256;
   T.spillStride = (size_t)c->numBinsMax * 512;
   T.countRowBegin = countRays ? fp.rowBegin : 0u; T.countRowEnd = countRays ? fp.rowEnd : 0u; T.width = fp.W;
 #ifdef RT_TRACE_STATS
-  hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounter32);
+  hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounterBuf + 1024);
 #endif
   T.tilesX = tilesX; T.tilesY = tilesY;
   T.sliceShift = sliceShift;

@@ -455,7 +455,9 @@ def test_adaptive_split_of_expensive_bins_changes_nothing(built):
             assert a.context.debug_trace_split(0, 0) == 0
             for bid in (capi.BUF_VISIBILITY, capi.BUF_DEPTH, capi.BUF_NORMAL, capi.BUF_RT_REFL, capi.BUF_RT_DIFF, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_BACKBUFFER):
                 np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="frame %d buffer %d" % (f, bid))
-        assert demands[0] == 0 and min(demands[1:]) > 1000, demands       # the first frame knows no costs yet
+        # the first frame knows no costs yet -- nor the second: ray generation of frame f reads what the traversal of frame f - 2
+        # recorded (frame f - 1's may still be running beside it: the cost record exists twice, by frame parity)
+        assert demands[0] == 0 and min(demands[2:]) > 1000, demands
     finally:
         a.OnDestroy(); b.OnDestroy()
 
@@ -958,8 +960,8 @@ def test_deforming_mesh_async_refit_against_the_oracle(built):
             p.o.update_as(); p.o.render_visibility(); p.rays = p.o.ray_trace(); p.o.denoise(); p.o.tone_map()
             p.check_frame("refit frame %d" % f)
             st = p.ctx.refit_stats(1)
-            if f == 7:
-                assert st["refits"] == 5 and st["rebuilds"] == 0 and 0.8 < st["cost_ratio"] < 1.6, st
+            if f == 7:       # 5 new shapes + frames 4 and 5, whose input sets still held an older shape: vertices copied over and refitted as well
+                assert st["refits"] == 7 and st["rebuilds"] == 0 and 0.8 < st["cost_ratio"] < 1.6, st
         st = p.ctx.refit_stats(1)
         assert st["rebuilds"] >= 1, "the violent change made the refitted tree's cost drift past the threshold: %s" % st
         with pytest.raises(p.capi.RtggxError, match="vertices given"):
