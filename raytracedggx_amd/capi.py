@@ -29,7 +29,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -58,6 +58,7 @@ def load():
     L.rtggx_set_stream.argtypes = [vp, vp]
     L.rtggx_set_async_compute.argtypes = [vp, C.c_int]
     L.rtggx_set_history_apron.argtypes = [vp, C.c_uint32]
+    L.rtggx_debug_shader_clock.argtypes = [vp, C.POINTER(C.c_double)]
     L.rtggx_refit_as.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
     L.rtggx_refit_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rtggx_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
@@ -125,6 +126,11 @@ class Context:
 
     def set_stream(self, stream_handle):
         self._check(self.L.rtggx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def shader_clock_mhz(self):
+        m = C.c_double()
+        self._check(self.L.rtggx_debug_shader_clock(self.h, C.byref(m)))
+        return m.value
 
     def copy_bandwidth(self, nbytes=1 << 30, iterations=8):
         """GB/s (read + written) of a float4 copy kernel over two buffers of nbytes each: the attainable HBM peak on this box."""

@@ -91,6 +91,9 @@ static int ensureParams(rtggx_context* c) { return c->slotUploaded ? 0 : uploadP
 static void freeMeshVerts(MeshDev& m) {
   for (int i = 0; i < RT_SETS; ++i) { bool dup = false; for (int j = 0; j < i; ++j) dup = dup || m.vertsBuf[j] == m.vertsBuf[i]; if (!dup && m.vertsBuf[i]) hipFree(m.vertsBuf[i]); }
   for (auto& b : m.vertsBuf) b = nullptr;
+  for (int i = 0; i < RT_SETS; ++i) { bool dup = false; for (int j = 0; j < i; ++j) dup = dup || m.fatBuf[j] == m.fatBuf[i]; if (!dup && m.fatBuf[i]) hipFree(m.fatBuf[i]); }
+  for (auto& b : m.fatBuf) b = nullptr;
+  m.fat = nullptr;
   for (auto& st : m.stage) { if (st) hipHostFree(st); st = nullptr; }
   m.verts = nullptr; m.deforming = false; m.pendingStage = -1; m.version = 0; m.latestSet = 0;
   for (auto& v : m.vertsVersion) v = 0;
@@ -111,6 +114,10 @@ static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint
     RT_HIP(hipMemcpy(m.indices, idx, sizeof(uint32_t) * (size_t)ni, hipMemcpyHostToDevice));
     for (int k = 0; k < 3; ++k) { m.bmin[k] = 3.4e38f; m.bmax[k] = -3.4e38f; }
     for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; if (x < m.bmin[k]) m.bmin[k] = x; if (x > m.bmax[k]) m.bmax[k] = x; }
+    RT_HIP(hipMalloc(&m.fat, sizeof(float4) * 5 * (size_t)m.numTris));
+    for (auto& b : m.fatBuf) b = m.fat;
+    { const int r = buildFatTris(c, slot, 0, c->streamMain); if (r) return r; }
+    RT_HIP(hipStreamSynchronize(c->streamMain));
   }
   c->asBuilt = false; c->sceneDirty = true;
   return 0;
@@ -365,6 +372,7 @@ int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
   if (!m.deforming) {        // first time: one vertex buffer per input set (rtggx_context.h), a staging ring
     RT_HIP(syncStreams(c));
     for (int i = 1; i < RT_SETS; ++i) { RT_HIP(hipMalloc(&m.vertsBuf[i], bytes)); RT_HIP(hipMemcpy(m.vertsBuf[i], m.vertsBuf[0], bytes, hipMemcpyDeviceToDevice)); }
+    { const size_t fb = sizeof(float4) * 5 * (size_t)m.numTris; for (int i = 1; i < RT_SETS; ++i) { RT_HIP(hipMalloc(&m.fatBuf[i], fb)); RT_HIP(hipMemcpy(m.fatBuf[i], m.fatBuf[0], fb, hipMemcpyDeviceToDevice)); } }
     for (auto& st : m.stage) RT_HIP(hipHostMalloc(&st, bytes));
     { const int r = splitBvhPerSet(m); if (r) return r; }
     m.deforming = true; m.latestSet = c->setIndex;
@@ -379,6 +387,7 @@ int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
     for (int k = 0; k < 3; ++k) { m.bmin[k] = 3.4e38f; m.bmax[k] = -3.4e38f; }
     for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; if (x < m.bmin[k]) m.bmin[k] = x; if (x > m.bmax[k]) m.bmax[k] = x; }
     const uint32_t refits = m.refits, rebuilds = m.rebuilds;
+    for (uint32_t i = 0; i < RT_SETS; ++i) { const int rf = buildFatTris(c, slot, i, c->streamAS); if (rf) return rf; }
     int r = buildLbvh(c, slot, c->streamAS);        // one tree again, aliased by all sets ...
     if (!r) r = splitBvhPerSet(m);                   // ... and a copy per set for the refits to come
     c->selectSet(c->setIndex);
@@ -694,7 +703,7 @@ static int bufferInfo(rtggx_context* c, int id, void** ptr, size_t* bytes) {
     case RTGGX_BUF_BVH_NODES0: case RTGGX_BUF_BVH_NODES1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_NODES1]; *ptr = m.nodes; *bytes = m.numTris > 1 && m.nodes ? (size_t)(m.numTris - 1) * 64 : 0; return 0; }
     case RTGGX_BUF_BVH_TRIS0: case RTGGX_BUF_BVH_TRIS1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_TRIS1]; *ptr = m.tris; *bytes = m.tris ? (size_t)m.numTris * 64 : 0; return 0; }
     case RTGGX_BUF_TLAS: *ptr = nullptr; *bytes = 128; return 0;
-    case RTGGX_BUF_BVH4_NODES0: case RTGGX_BUF_BVH4_NODES1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH4_NODES1]; *ptr = m.nodes4; *bytes = m.numTris > 1 && m.nodes4 ? (size_t)(m.numTris - 1) * 128 : 0; return 0; }
+    case RTGGX_BUF_BVH4_NODES0: case RTGGX_BUF_BVH4_NODES1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH4_NODES1]; *ptr = m.nodes4; *bytes = m.numTris > 1 && m.nodes4 ? (size_t)(m.numTris - 1) * sizeof(Bvh4Node) : 0; return 0; }
     case RTGGX_BUF_BIN_WORK: *ptr = c->binWork; *bytes = (size_t)(((c->W + 15) / 16) * ((c->H + 15) / 16)) * 4u * 4u; return 0;
     case RTGGX_BUF_ENV: *ptr = c->env.texels; *bytes = (size_t)c->env.totalTexels * 8; return 0;
     default: setError("unknown buffer id %d", id); return -1;
@@ -784,6 +793,28 @@ int rtggx_copy_bandwidth(rtggx_context* c, size_t bytes, int iterations, double*
   hipEventDestroy(e0); hipEventDestroy(e1); hipFree(src); hipFree(dst);
   if (e != hipSuccess || !(ms > 0.0f)) { setError("rtggx_copy_bandwidth: %s", hipGetErrorString(e)); return -2; }
   *gbytesPerS = 2.0 * (double)(n * 16) * iterations / ((double)ms * 1e-3) / 1e9;
+  return 0;
+}
+
+// Diagnostic: the shader clock the chip is running at right now -- one wave on stream R idles for ~20 us between two readings of
+// s_memtime (shader cycles) and s_memrealtime (100 MHz), while whatever the other streams hold keeps running (profiles/r02_*).
+__global__ void clockProbeKernel(unsigned long long* out) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < 2000ull) { __builtin_amdgcn_s_sleep(32); r1 = __builtin_amdgcn_s_memrealtime(); }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+int rtggx_debug_shader_clock(rtggx_context* c, double* mhz) {
+  RT_CHECK_CTX(c);
+  if (!mhz) { setError("rtggx_debug_shader_clock: null result"); return -1; }
+  unsigned long long* d = nullptr; unsigned long long h[2] = {0, 1};
+  RT_HIP(hipMalloc(&d, 16));
+  hipLaunchKernelGGL(clockProbeKernel, dim3(1), dim3(64), 0, c->streamRefit, d);
+  RT_HIP(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->streamRefit));
+  RT_HIP(hipStreamSynchronize(c->streamRefit));
+  hipFree(d);
+  *mhz = (double)h[0] / (double)h[1] * 100.0;
   return 0;
 }
 

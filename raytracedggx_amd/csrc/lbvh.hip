@@ -350,6 +350,23 @@ __global__ void __launch_bounds__(256) refitTreelets(const RefitTreelet* __restr
   }
 }
 
+// Fat triangles (rtggx_context.h): primitive p's three vertices, 6 floats each, at fat[5 p .. 5 p + 4].
+__global__ void emitFatTris(uint32_t n, const float* __restrict__ verts, const uint32_t* __restrict__ idx, float4* __restrict__ fat) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float v[20];
+  for (int k = 0; k < 3; ++k) { const float* src = verts + 6 * (size_t)idx[3 * (size_t)p + k]; for (int q = 0; q < 6; ++q) v[6 * k + q] = src[q]; }
+  v[18] = 0.0f; v[19] = 0.0f;
+  for (int q = 0; q < 5; ++q) fat[5 * (size_t)p + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+int buildFatTris(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
+  MeshDev& m = c->mesh[slot];
+  if (m.numTris == 0 || !m.fatBuf[set]) return 0;
+  hipLaunchKernelGGL(emitFatTris, dim3((m.numTris + 255) / 256), dim3(256), 0, s, m.numTris, (const float*)m.vertsBuf[set], (const uint32_t*)m.indices, m.fatBuf[set]);
+  RT_HIP(hipGetLastError());
+  return 0;
+}
+
 // Buffers that exist once per input set when the mesh deforms and alias one allocation while it is static.
 template <typename T> static void freeAliased(T* (&buf)[RT_SETS]) {
   for (int i = 0; i < RT_SETS; ++i) { bool dup = false; for (int j = 0; j < i; ++j) dup = dup || buf[j] == buf[i]; if (!dup && buf[i]) hipFree(buf[i]); }
@@ -381,6 +398,7 @@ int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
   if (n == 0 || !m.trisBuf[set]) return 0;
   const uint32_t nb = (n + 255) / 256;
   if (!m.triBox || (n > 1 && m.refitLevels.empty())) { setError("rtggx_refit_as: mesh %u has no PLOC build to refit (RTGGX_BVH_RADIX_TREE builds cannot be refitted)", slot); return -1; }
+  { const int r = buildFatTris(c, slot, set, s); if (r) return r; }
   hipLaunchKernelGGL(refitTris, dim3(nb), dim3(256), 0, s, (int)n, (const float*)m.vertsBuf[set], (const uint32_t*)m.indices, m.trisBuf[set], m.triBox);
   if (n > 1) {
     for (const auto& lv : m.refitLevels)      // (first treelet, count): level after level

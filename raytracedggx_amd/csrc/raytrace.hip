@@ -158,13 +158,13 @@ RT_DEV f3 localToWorld(f3 n, f3 l) {   // :129-147
   return (xAxis * l.x + yAxis * l.y) + n * l.z;
 }
 struct Tri3 { f3 pos[3], nrm[3]; };
-RT_DEV Tri3 getVertices(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t prim) {   // :230-244
+RT_DEV Tri3 getVertices(const float4* __restrict__ fat, uint32_t prim) {   // :230-244, from the primitive's fat triangle (rtggx_context.h): five 16-byte loads, one dependent step
+  const float4* p = fat + 5 * (size_t)prim;
+  const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
   Tri3 v;
-  const uint32_t* ip = idx + 3 * (size_t)prim;
-  for (int k = 0; k < 3; ++k) {
-    const float* p = verts + 6 * (size_t)ip[k];
-    v.pos[k] = mk3(p[0], p[1], p[2]); v.nrm[k] = mk3(p[3], p[4], p[5]);
-  }
+  v.pos[0] = mk3(a.x, a.y, a.z); v.nrm[0] = mk3(a.w, b.x, b.y);
+  v.pos[1] = mk3(b.z, b.w, c.x); v.nrm[1] = mk3(c.y, c.z, c.w);
+  v.pos[2] = mk3(d.x, d.y, d.z); v.nrm[2] = mk3(d.w, e.x, e.y);
   return v;
 }
 struct Attrib { f3 Pos, Nrm; f2 UV; };
@@ -200,7 +200,7 @@ struct GenArgs {
   const unsigned long long* visDepth;
   uint32_t* normalOut; uint16_t* roughMetalOut; uint32_t* velocityOut; uint32_t* reflOut; uint32_t* diffOut;
   const uint16_t* roughMetalPrev;   // the previous frame's input set = what this target held before this frame
-  const float* verts0; const uint32_t* idx0; const float* verts1; const uint32_t* idx1;
+  const float4* fat0; const float4* fat1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* cosSin;
   RayRec* rays; HitKey* hits; uint32_t* binCount;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
       --visibility;
       hit = true; inst = visibility >> 24; prim = visibility & 0xFFFFFFu;
       asm volatile("" : "+v"(prim));      // see shadeKernel: the mask must survive the array indexing by inst below
-      const Tri3 v = getVertices(inst ? A.verts1 : A.verts0, inst ? A.idx1 : A.idx0, prim);
+      const Tri3 v = getVertices(inst ? A.fat1 : A.fat0, prim);
       const M4 wvp = cbLoad4x4(fp.g.WorldViewProjs[inst]);
       f4 p[3];
       for (int k = 0; k < 3; ++k) p[k] = mulPoint(v.pos[k], wvp);
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restric
 // =========================================================================================================
 struct ShadeArgs {
   const RayRec* rays; const HitKey* hits; const uint32_t* binCount;
-  const float* verts0; const uint32_t* idx0; const float* verts1; const uint32_t* idx1;
+  const float4* fat0; const float4* fat1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* sh;
   uint32_t* reflOut; uint32_t* diffOut;
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict
         // hipcc 7.2 drops this mask when the same id also indexes a two-element array (it then addresses the triangle
         // with the whole id: a fault for every hit on instance 1): keep it behind a barrier, and select instead of index
         asm volatile("" : "+v"(hPrim));
-        const Tri3 v = getVertices(hInst ? A.verts1 : A.verts0, hInst ? A.idx1 : A.idx0, hPrim);
+        const Tri3 v = getVertices(hInst ? A.fat1 : A.fat0, hPrim);
         // the hit attributes (barycentrics) of the recorded triangle: the traversal's own test, repeated
         float ht, hb1 = 0.0f, hb2 = 0.0f;
         woopTestVerts(toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, hInst ? fp.invWorld[1] : fp.invWorld[0]), v.pos[0], v.pos[1], v.pos[2], ht, hb1, hb2);
@@ -460,7 +460,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   GenArgs G;
   G.visDepth = c->visDepth; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
-  G.verts0 = c->mesh[0].verts; G.idx0 = c->mesh[0].indices; G.verts1 = c->mesh[1].verts; G.idx1 = c->mesh[1].indices;
+  G.fat0 = c->mesh[0].fat; G.fat1 = c->mesh[1].fat;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
   G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;
   G.tilesX = tilesX; G.numTiles = tilesX * tilesY; G.rowBegin = rb; G.rowEnd = re;
@@ -505,7 +505,7 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
   S.diffPrev = c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS]; S.visDepth = c->visDepth; S.tilesX = tilesX; S.rowBegin = rb; S.rowEnd = re;
   S.carryMask = (fp.mat.RoughMetals[0][1] >= 1.0f ? 1u : 0u) | (fp.mat.RoughMetals[1][1] >= 1.0f ? 2u : 0u);      // rghMtl.y < 1 is the test of :559; it is the instance's constant
   S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitKey*)c->hitQueue; S.binCount = c->binCount;
-  S.verts0 = c->mesh[0].verts; S.idx0 = c->mesh[0].indices; S.verts1 = c->mesh[1].verts; S.idx1 = c->mesh[1].indices;
+  S.fat0 = c->mesh[0].fat; S.fat1 = c->mesh[1].fat;
   S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;
   S.reflOut = c->rtRefl; S.diffOut = c->rtDiff;
   if (done && c->attachEvents) hipExtLaunchKernelGGL(shadeKernel, dim3(numTiles), dim3(256), 0, s, nullptr, done, 0, (const FrameParams*)(c->dParams + c->slot), S);
@@ -530,8 +530,7 @@ __global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec
   keys[i] = hitKey(rr.tmax, 0xFFFFFFFFu);
 }
 __global__ void exportTestHits(const FrameParams* __restrict__ fpp, const RayRec* __restrict__ rays, const HitKey* __restrict__ hits, uint32_t n,
-                               const float* __restrict__ verts0, const uint32_t* __restrict__ idx0, const float* __restrict__ verts1, const uint32_t* __restrict__ idx1,
-                               float* __restrict__ out) {
+                               const float4* __restrict__ fat0, const float4* __restrict__ fat1, float* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const HitKey k = hits[i];
@@ -545,7 +544,7 @@ __global__ void exportTestHits(const FrameParams* __restrict__ fpp, const RayRec
     uint32_t prim = id & 0xFFFFFFu;
     // (same compiler hazard as in shadeKernel: keep the mask behind a barrier)
     asm volatile("" : "+v"(prim));
-    const Tri3 v = getVertices(inst ? verts1 : verts0, inst ? idx1 : idx0, prim);
+    const Tri3 v = getVertices(inst ? fat1 : fat0, prim);
     woopTestVerts(toObject(rr.ox, rr.oy, rr.oz, rr.dx, rr.dy, rr.dz, inst ? fpp->invWorld[1] : fpp->invWorld[0]), v.pos[0], v.pos[1], v.pos[2], t, b1, b2);
   }
   o[0] = t; o[1] = u2f(valid ? id >> 24 : 0u); o[2] = u2f(valid ? id & 0xFFFFFFu : 0u); o[3] = b1; o[4] = b2; o[5] = valid ? 1.0f : 0.0f;
@@ -558,7 +557,7 @@ int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays,
   hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, (HitKey*)c->hitQueue, c->binCount);
   { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u, chooseSliceShift(c, false, numBins), -1); if (r) return r; }
   hipLaunchKernelGGL(exportTestHits, dim3((n + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, (const RayRec*)c->rayQueue, (const HitKey*)c->hitQueue, n,
-                     c->mesh[0].verts, c->mesh[0].indices, c->mesh[1].verts, c->mesh[1].indices, dOut);
+                     (const float4*)c->mesh[0].fat, (const float4*)c->mesh[1].fat, dOut);
   RT_HIP(hipGetLastError());
   return 0;
 }

@@ -19,11 +19,15 @@ namespace rt {
 #ifndef RT_VIS_STREAM_RAYS
 #define RT_VIS_STREAM_RAYS 800000u   // below this many rays per frame the visibility pass runs on its own stream (capi.hip: all-metal frames; measured: -4.6 % at 0.52 M rays, +0.8 % at 2 M)
 #endif
+// Round 2 (three-stage pipeline, profiles/r02_c_ab_pipeline.txt block 5): with the traversal no longer the frame's longest chain,
+// what pays is STARTING the dearer bins first (a lower threshold: 1000 -> 300, the mean bin costs ~700) and splitting fewer of them
+// (2400 -> 3200): every extra wave of a split bin is wave-slot time the other two stages want.  The trace kernel alone gets slower
+// (0.120 -> 0.134 ms), the frame faster (0.2207 -> 0.2119 ms; dragon -5 %, 4K -3 %).
 #ifndef RT_SPLIT_FRONT
-#define RT_SPLIT_FRONT 1000u // above this a bin goes on the list: the launch starts with the listed bins
+#define RT_SPLIT_FRONT 300u  // above this a bin goes on the list: the launch starts with the listed bins
 #endif
 #ifndef RT_SPLIT_WORK
-#define RT_SPLIT_WORK 2400u  // above this (per wave) a listed bin gets twice the waves ...
+#define RT_SPLIT_WORK 3200u  // above this (per wave) a listed bin gets twice the waves ...
 #endif
 #ifndef RT_SPLIT_MAX_SHIFT
 #define RT_SPLIT_MAX_SHIFT 1u   // ... up to 2^this

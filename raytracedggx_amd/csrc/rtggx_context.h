@@ -35,6 +35,11 @@ struct MeshDev {
   // main stream still reads the vertices of frame f while stream B already moves them for frame f + 1.  A static mesh has one
   // allocation, and the three pointers alias it.
   float* vertsBuf[RT_SETS] = {};
+  // "Fat triangles": per primitive its three 24-byte vertices side by side (80 bytes = 5 x 16: p0 n0 p1 n1 p2 n2 + 8 pad), indexed by
+  // primitive id.  Ray generation and hit shading fetch a triangle's vertices with five 16-byte loads in ONE dependent step instead of
+  // three index loads followed by eighteen 4-byte loads (two steps): these kernels are latency-bound (profiles/r02_d_limiter.txt).
+  // Per input set like the vertices; rebuilt from them by a refit.
+  float4* fat = nullptr; float4* fatBuf[RT_SETS] = {};
   uint32_t vertsVersion[RT_SETS] = {}, version = 0, latestSet = 0;
   bool deforming = false;
   float* stage[RT_SLOTS] = {};   // pinned host staging ring for the vertices handed to rtggx_refit_as
@@ -148,7 +153,7 @@ struct rtggx_context {
     setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
     splitList = splitListBuf[i]; splitCount = largeCount ? largeCount + 1 + i : nullptr;
-    for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.tris = m.trisBuf[i]; }
+    for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.fat = m.fatBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.tris = m.trisBuf[i]; }
     const uint32_t par = pipeline != 0 ? (frameCounter & 1u) : 0u;
     binWork = binWorkBuf[par]; rayCounter32 = rayCounterBuf + (pipeline != 0 ? (frameCounter & 3u) : 0u) * 256u;
   }
@@ -235,6 +240,7 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
 int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s);      // boxes of the existing tree from the vertices of input set `set`, into that set's BVH arrays: no host round trip
 void freeBuildProducts(MeshDev& m);
+int buildFatTris(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s);      // mesh.fatBuf[set] from mesh.vertsBuf[set] and the indices
 int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hipStream_t sTrace, hipEvent_t done = nullptr);   // ray generation on sGen, traversal on sTrace (joined by evGen when they differ)
 // `done` (may be null) on the launch functions below: an event that completes with the pass's last kernel.  It rides on that
 // kernel's own completion signal (hipExtLaunchKernelGGL) instead of a marker packet behind it: a marker costs its queue

@@ -84,6 +84,9 @@ struct TraceArgs {
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 1
 #endif
+#ifndef RT_PREFETCH
+#define RT_PREFETCH 0     // touch-prefetch of the next record: measured +20 % kernel time (one more divergent load per step; profiles/r02_d_limiter.txt)
+#endif
 #ifndef RT_TRACE_MIN_WAVES
 #define RT_TRACE_MIN_WAVES 6     // waves per SIMD the register allocation aims for (80 VGPRs; 85 without the hint = 5 waves)
 #endif
@@ -183,6 +186,9 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
   uint32_t owner = slot;                             // the ray slot whose key this job's hits go to
   float myT = bestT; uint32_t myId = bestId;         // the best hit of the job in hand (a helper's: its victim's, then its own)
 
+#if RT_PREFETCH
+  float pf = 0.0f;      // destination of the touch load that warms the L1 line of the record this lane visits next (see the loop's end)
+#endif
   for (;;) {
     const unsigned long long jobMask = __ballot(job);
     if (jobMask == 0ull) break;
@@ -301,6 +307,15 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
         }
       }
     }
+#if RT_PREFETCH
+    // -- touch the record this lane stands on now: its node (one 128-byte line) or leaf triangle is fetched by the NEXT iteration,
+    //    behind that iteration's ballots, work sharing and LDS traffic; asking for the line now turns that fetch's L2 round trip
+    //    (500-900 cycles under load) into an L1 hit.  One 4-byte load per lane, its value unused.
+    if (job) {
+      const float* line = cur >= 0 ? reinterpret_cast<const float*>(nodes + (size_t)cur * 8) : reinterpret_cast<const float*>(tris + (size_t)(~cur) * 4);
+      pf = __builtin_nontemporal_load(line);
+    }
+#endif
     // -- a finished helper merges its best hit into the ray's key (one that found nothing closer than what it started
     //    with repeats its victim's candidate: harmless); a finished primary job keeps its own in bestT / bestId
     if (finished) {
