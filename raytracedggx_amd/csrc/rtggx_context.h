@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <utility>
 #include <vector>
@@ -225,7 +226,11 @@ namespace rt {
 // instead of exchanging it.
 enum RowPass { ROWS_GBUFFER /* visibility, ray trace, H filters: +-18 */, ROWS_VFILTER /* +-2 */, ROWS_TEMPORAL /* +-1 */, ROWS_FINAL };
 inline void passRows(const FrameParams& fp, RowPass pass, uint32_t& b, uint32_t& e) {
-  const uint32_t apron = pass == ROWS_GBUFFER ? 18u : pass == ROWS_VFILTER ? 2u : pass == ROWS_TEMPORAL ? 1u : 0u;
+  // MEASUREMENT switch (tools/probes/strip_halo_projection.py): RTGGX_GBUFFER_APRON=0 makes the G-buffer passes and H filters cover
+  // the strip's own rows only, as they would if the +-18 halo rows were RECEIVED from the neighbours (the north-star design) instead
+  // of recomputed.  Rows near the strip edges are then wrong: for timing a strip's compute, never for rendering.
+  static const uint32_t gApron = getenv("RTGGX_GBUFFER_APRON") ? (uint32_t)atoi(getenv("RTGGX_GBUFFER_APRON")) : 18u;
+  const uint32_t apron = pass == ROWS_GBUFFER ? gApron : pass == ROWS_VFILTER ? 2u : pass == ROWS_TEMPORAL ? 1u : 0u;
   b = fp.rowBegin > apron ? fp.rowBegin - apron : 0u;
   e = fp.rowEnd + apron < fp.H ? fp.rowEnd + apron : fp.H;
   if (fp.rowEnd <= fp.rowBegin) { b = e = 0; }

@@ -32,8 +32,8 @@ for block in re.split(r"\n(?=\S)", txt):
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and name.startswith(("rt::", "void rt::")):
         out["kernels"][name] = {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                                 "traffic_bytes": int(1024 * (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]))}
-# wave-level VALU instructions of the frame's kernels (SQ_INSTS_VALU per dispatch, one dispatch of each per frame): the frame is
-# bound by VALU issue, and bench.py reports the fraction of the issue slots (4 cycles per instruction, 1024 SIMDs, 2.4 GHz)
+# wave-level VALU instructions of the frame's kernels (SQ_INSTS_VALU per dispatch, one dispatch of each per frame): bench.py reports
+# the share of the VALU issue slots they take (2 cycles per wave64 instruction on a SIMD-32, 1024 SIMDs, 2.4 GHz; profiles/r02_a_valu_issue.txt)
 frame_kernels = ("rt::clearVisDepth", "rt::rasterSmall", "rt::rasterLarge", "rt::rayGenKernel", "rt::traceKernel", "rt::shadeKernel",
                  "void rt::spatialTiledKernel<0>", "void rt::spatialTiledKernel<1>", "void rt::spatialTiledKernel<2>", "void rt::spatialTiledKernel<3>",
                  "rt::temporalKernel", "rt::toneMapKernel")
