@@ -424,29 +424,44 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
 }
 
 // PSToneMap.hlsl:13-41; source = TSS[parity] (passed as T.scratch)
+// One workgroup = 64 x RT_TM_ROWS pixels, RT_TM_ROWS / 4 per thread: the pass is one memory round trip and a handful of instructions per
+// pixel, so a wave's life is its launch plus that round trip -- four pixels per thread put four times the bytes in flight per wave
+// and take a quarter of the waves (64 x 4 blocks: 32 400 waves, 37 M wave quad-cycles per frame; profiles/r02_d_limiter.txt), and
+// the one-texel apron costs 1.16 x instead of 1.55 x.
+#define RT_TM_ROWS 16
 __global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
 #pragma clang fp contract(fast)
-  __shared__ float4 tile[6][66];          // c / (c + 0.5) of the block's pixels and a one-texel apron, computed once per texel
+  __shared__ float4 tile[RT_TM_ROWS + 2][66];          // c / (c + 0.5) of the block's pixels and a one-texel apron, computed once per texel
   const int W = T.W, H = T.H;
   {
-    const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * 4 - 1;
-    for (int t = threadIdx.x; t < 6 * 66; t += 256) {
-      const f4 c = loadRGBA16(T.scratch, ox + t % 66, oy + t / 66, W, H);
-      tile[t / 66][t % 66] = make_float4(c.x * rcpFast(c.x + 0.5f), c.y * rcpFast(c.y + 0.5f), c.z * rcpFast(c.z + 0.5f), c.w);
+    const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * RT_TM_ROWS - 1;
+    constexpr int N = (RT_TM_ROWS + 2) * 66, PER = (N + 255) / 256;
+    f4 c[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int t = threadIdx.x + 256 * k; c[k] = t < N ? loadRGBA16(T.scratch, ox + t % 66, oy + t / 66, W, H) : f4{0.0f, 0.0f, 0.0f, 0.0f}; }      // all loads first
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int t = threadIdx.x + 256 * k;
+      if (t < N) tile[t / 66][t % 66] = make_float4(c[k].x * rcpFast(c[k].x + 0.5f), c[k].y * rcpFast(c[k].y + 0.5f), c[k].z * rcpFast(c[k].z + 0.5f), c[k].w);
     }
   }
   __syncthreads();
-  const int lx = (threadIdx.x & 63) + 1, ly = (threadIdx.x >> 6) + 1;
+  const int lx = (threadIdx.x & 63) + 1;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= T.W || y >= T.rowEnd) return;
-  const float4 c0 = tile[ly][lx], c1 = tile[ly][lx - 1], c2 = tile[ly][lx + 1], c3 = tile[ly - 1][lx], c4 = tile[ly + 1][lx];
-  float lx_ = -4.0f * c0.x, ly_ = -4.0f * c0.y, lz_ = -4.0f * c0.z;
-  lx_ += c1.x; ly_ += c1.y; lz_ += c1.z;
-  lx_ += c2.x; ly_ += c2.y; lz_ += c2.z;
-  lx_ += c3.x; ly_ += c3.y; lz_ += c3.z;
-  lx_ += c4.x; ly_ += c4.y; lz_ += c4.z;
-  T.backbuffer[(size_t)y * W + x] = packRGBA8(c0.x - 0.2f * lx_, c0.y - 0.2f * ly_, c0.z - 0.2f * lz_, c0.w);
+  if (x >= T.W) return;
+#pragma unroll
+  for (int k = 0; k < RT_TM_ROWS / 4; ++k) {
+    const int ly = (threadIdx.x >> 6) + 4 * k + 1;
+    const int y = T.rowBegin + blockIdx.y * RT_TM_ROWS + (threadIdx.x >> 6) + 4 * k;
+    if (y >= T.rowEnd) continue;
+    const float4 c0 = tile[ly][lx], c1 = tile[ly][lx - 1], c2 = tile[ly][lx + 1], c3 = tile[ly - 1][lx], c4 = tile[ly + 1][lx];
+    float lx_ = -4.0f * c0.x, ly_ = -4.0f * c0.y, lz_ = -4.0f * c0.z;
+    lx_ += c1.x; ly_ += c1.y; lz_ += c1.z;
+    lx_ += c2.x; ly_ += c2.y; lz_ += c2.z;
+    lx_ += c3.x; ly_ += c3.y; lz_ += c3.z;
+    lx_ += c4.x; ly_ += c4.y; lz_ += c4.z;
+    T.backbuffer[(size_t)y * W + x] = packRGBA8(c0.x - 0.2f * lx_, c0.y - 0.2f * ly_, c0.z - 0.2f * lz_, c0.w);
+  }
 }
 
 static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass) {
@@ -502,7 +517,7 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
 int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
   if (fp.rowEnd <= fp.rowBegin) return 0;
   const Targets T = makeTargets(c, fp, ROWS_FINAL);
-  const dim3 grid((fp.W + 63) / 64, (T.rowEnd - T.rowBegin + 3) / 4), block(256);
+  const dim3 grid((fp.W + 63) / 64, (T.rowEnd - T.rowBegin + RT_TM_ROWS - 1) / RT_TM_ROWS), block(256);
   hipLaunchKernelGGL(toneMapKernel, grid, block, 0, s, T);
   RT_HIP(hipGetLastError());
   return 0;

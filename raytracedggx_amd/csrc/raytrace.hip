@@ -210,7 +210,10 @@ struct GenArgs {
   uint32_t* binWork; uint32_t* splitList; uint32_t* splitCount; uint32_t splitWork, frontWork, splitMaxShift, splitCap;
 };
 
-__global__ void __launch_bounds__(256) rayGenKernel(const FrameParams* __restrict__ fpp, GenArgs A) {
+#ifndef RT_GEN_MIN_BLOCKS
+#define RT_GEN_MIN_BLOCKS 1
+#endif
+__global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const FrameParams* __restrict__ fpp, GenArgs A) {
   const FrameParams& fp = *fpp;
   if (blockIdx.x == 0) A.frameRays[threadIdx.x] = 0u;
   // 16x16 pixel tile per workgroup, 8x8 per wave: the 64 rays a wave appends are neighbours on screen
@@ -384,7 +387,7 @@ RT_DEV f3 reflectionDepth1(const EnvRef& env, f2 rghMtl, f3 N, f3 V, f3 color) {
   return e * envBRDFApprox(f0, rghMtl.x, NoV);
 }
 
-__global__ void __launch_bounds__(256) shadeKernel(const FrameParams* __restrict__ fpp, ShadeArgs A) {
+__global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) shadeKernel(const FrameParams* __restrict__ fpp, ShadeArgs A) {
   const FrameParams& fp = *fpp;
   const EnvRef env{A.env, A.envSize, A.envMips, A.envMipOffset};
   // workgroup b shades the four bins its rayGen namesake filled: wave w <-> bin 4b + w

@@ -77,8 +77,14 @@ __global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begi
     uint32_t* d = reinterpret_cast<uint32_t*>(dst);
     for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4; i += blockDim.x) d[i] = s[i];
   }
-  const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < end) vd[i] = 0x00FFFFFF00000000ull;
+  // four words (32 bytes) per thread: a quarter of the waves, each with 2 KB of stores in flight (one word per thread made this a kernel
+  // of 32 400 waves that each lived for one store)
+  const uint32_t i = begin + (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+  const unsigned long long clear = 0x00FFFFFF00000000ull;
+  if (i + 3u < end && (i & 1u) == 0u) {
+    ulonglong2* p = reinterpret_cast<ulonglong2*>(vd + i);
+    p[0] = make_ulonglong2(clear, clear); p[1] = make_ulonglong2(clear, clear);
+  } else for (uint32_t k = 0; k < 4u; ++k) if (i + k < end) vd[i + k] = clear;
 }
 
 // Fragment test + depth for one pixel; returns the key or ~0 when not covered.
@@ -250,7 +256,7 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   passRows(fp, ROWS_GBUFFER, rb, re);
   const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
-  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 255) / 256), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount, c->splitCount,
+  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 1023) / 1024), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount, c->splitCount,
                      fp, c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot);
   c->slotUploaded = true;
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
