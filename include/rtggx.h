@@ -167,16 +167,17 @@ int  rtggx_build_as(rtggx_context* ctx);
 int  rtggx_refit_as(rtggx_context* ctx, uint32_t slot, const float* verts, uint32_t num_verts);
 int  rtggx_refit_stats(rtggx_context* ctx, uint32_t slot, float* cost_ratio, uint32_t* refits, uint32_t* rebuilds);
 
-/* Per-frame constants; copied into the next slot of a ring of RayTracer::FrameCount + 1 (= 4). */
+/* Per-frame constants; copied into the next slot of a ring of (input sets + 1) = 5. */
 int  rtggx_update_frame(rtggx_context* ctx, const RtggxFrameConstants* constants);
 /* Refreshes the TLAS (the two world->object matrices) from the constants of the current slot.  May be called before or
  * after rtggx_render_visibility of the same frame (the sample overlaps the two on different queues); rtggx_ray_trace sends
  * the refreshed constants to the device again when the visibility pass had already carried the slot there. */
 int  rtggx_update_as(rtggx_context* ctx);
 int  rtggx_transform_sh(rtggx_context* ctx);
-/* Starts a frame: advances to the next of RayTracer::FrameCount (= 3) input sets (G-buffer, traced images, ray bins).  All
- * pass functions only enqueue work; this one is the frames-in-flight fence of the sample (RayTracedGGX.cpp:672-701): it
- * blocks the calling thread while the frame that last used that set, three frames back, is still being read on the GPU. */
+/* Starts a frame: advances to the next of 4 input sets (G-buffer, traced images, ray bins, and -- for a deforming mesh -- vertices and
+ * tree; the sample's RayTracer::FrameCount is 3).  All pass functions only enqueue work; this one is the frames-in-flight fence of the
+ * sample (RayTracedGGX.cpp:672-701): it blocks the calling thread while the frame that last used that set, four frames back, is still
+ * being read on the GPU.  A pending rtggx_refit_as is issued here. */
 int  rtggx_render_visibility(rtggx_context* ctx);
 int  rtggx_ray_trace(rtggx_context* ctx);
 int  rtggx_denoise(rtggx_context* ctx, int use_shared_mem);

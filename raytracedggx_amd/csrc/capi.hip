@@ -173,7 +173,8 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipEventCreateWithFlags(&c->evRefit, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evGen, hipEventDisableTiming));
   for (auto& e : c->evTraceRing) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, prioMid));
+  { const int pr = getenv("RTGGX_PRIORITY_R") ? atoi(getenv("RTGGX_PRIORITY_R")) : 1;      // stream R: 0 low, 1 mid, 2 high
+    RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, pr == 0 ? prioLeast : pr == 2 ? prioGreatest : prioMid)); }
   c->pipeline = getenv("RTGGX_PIPELINE") ? atoi(getenv("RTGGX_PIPELINE")) : 1;
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));

@@ -5,7 +5,7 @@
 // with __ballot/popcount and records how many there are.  Each wave of the trace kernel owns one bin, so no
 // queue head is ever contended (device-scope atomics on a shared head word cost ~11 ns each at the memory side
 // and serialised the first, work-queue versions of this pass).  The bins exist twice (rtggx_context.h): stream B
-// fills and traces one set while the main stream still shades the set of the frame before (three sets, rtggx_context.h).
+// fills and traces one set while the main stream still shades the set of the frame before (RT_SETS sets, rtggx_context.h).
 #pragma once
 #include "rtggx_context.h"
 

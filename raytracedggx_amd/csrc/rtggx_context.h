@@ -20,14 +20,19 @@
 #include <vector>
 #include "rtggx_device.h"
 
-// Input sets (G-buffer, traced images, ray bins): three, used round-robin.  Stream B fills set i while the main stream
+// Input sets (G-buffer, traced images, ray bins): RT_SETS of them, used round-robin.  Stream B fills set i while the main stream
 // still consumes the set of the frame before; before stream B is given the work that overwrites a set, the HOST waits
 // for the event of that set's last reader, three frames back -- the frames-in-flight fence of the sample
 // (RayTracedGGX.cpp: FrameCount = 3), and cheaper than a cross-queue wait on the GPU (10 us per frame on stream B's
 // chain).  The frame constants live in a ring of RT_SLOTS device slots: one more than sets, because the tone map of
 // frame f still reads its slot after the event of set f has completed.
-#define RT_SETS 3
-#define RT_SLOTS 4
+// Round 2: FOUR sets (the sample's FrameCount is 3).  A frame's latency through the three stages (+ the refit of a deforming mesh) is
+// 0.45-0.6 ms; with three sets in flight a thin strip or a deforming mesh ran out of frames to overlap: 1920x171 strip 0.0726 -> 0.0579 ms,
+// deforming bunny 0.2432 -> 0.2347, 4K 0.758 -> 0.743, the 1080p frame unchanged; five and six give nothing more (profiles/r02_c_ab_pipeline.txt).
+#ifndef RT_SETS
+#define RT_SETS 4
+#endif
+#define RT_SLOTS (RT_SETS + 1)
 namespace rt {
 
 struct MeshDev {
