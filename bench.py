@@ -45,6 +45,7 @@ def parse_args(argv=None):
     ap.add_argument("--mesh", default="bunny.obj")
     ap.add_argument("--metallic", type=float, nargs=2, default=None, help="metallic of ground and model (default: the sample's 1 1 = no diffuse rays)")
     ap.add_argument("--deform", type=float, default=0.0, help="amplitude of the breathing-model animation (-deform): new vertices and an asynchronous BVH refit every frame")
+    ap.add_argument("--trace-waves", type=int, default=0, help="pin the size of the traversal's resident workgroup (10, 12, 14, 16) instead of letting the library steer it (measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
     ap.add_argument("--prime-frames", type=int, default=256, help="frames rendered during SET-UP, before the warm-up steps: the GPU's compute clock ramps for "
@@ -190,6 +191,8 @@ def main():
     # clock governor has settled (it ramps the compute clock over 30-50 ms of sustained load after ANY idle period -- set-up leaves the
     # GPU idle for about a second -- which costs the first ~150 frames 5-13 %; measured in profiles/r02_b_clock_ramp.txt).  Reported
     # in the result line as config.setup_priming_frames.
+    if not args.stub and args.trace_waves:
+        ctx.trace_residency(args.trace_waves)
     for _ in range(0 if args.stub else args.prime_frames):
         r.frame()
     for _ in range(args.warmup):
@@ -257,6 +260,7 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     # The same kernel with nothing beside it (after the timed region: 32 frames issued to ONE stream, rtggx_set_async_compute(0)): in the
     # timed region it shares the chip with two other stages at low stream priority, and its duration there is not its speed.
+    residency = None if args.stub else r.context.trace_residency(args.trace_waves)
     k_alone = float("nan")
     if world == 1:
         r.context.set_async_compute(False)
@@ -276,7 +280,8 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
                                                   ", model deforming every frame (amplitude %g, asynchronous BVH refit)" % args.deform if args.deform else ""),
                    "rays_per_frame": round(rays_total / args.steps, 1), "parallelism": "row strips x%d" % world, "strip_bounds": r.bounds,
                    "history_apron_rows": r.apron, "history_overreach_rows": overreach,
-                   "setup_priming_frames": args.prime_frames},
+                   "setup_priming_frames": args.prime_frames,
+                   "trace_workgroup_waves": None if residency is None else residency[0], "trace_share_of_period": None if residency is None else round(residency[1], 3)},
         "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),

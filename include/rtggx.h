@@ -103,7 +103,9 @@ enum {
   RTGGX_BUF_BVH4_NODES1 = 20, /*   minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4]; ref: >=0 node, <0 ~leaf slot, 0x7FFFFFFF none */
   RTGGX_BUF_BIN_WORK = 21,    /* uint32 per ray bin (8x8-pixel sub-tile; bin = 4 * (tileY * tilesX + tileX) + 2 * subY + subX over 16x16 tiles):
                                  lane-steps the last traversal spent on the bin's rays; zero unless that launch recorded them (full-size frames) */
-  RTGGX_BUF_COUNT = 22
+  RTGGX_BUF_BVH4_TOP0 = 22,   /* the first (up to 16 / 96) 4-wide nodes of mesh 0 / 1 in breadth-first order, same 128-byte records; a reference to */
+  RTGGX_BUF_BVH4_TOP1 = 23,   /*   a node that is in the table itself reads 0x40000000 | position (the copy the trace kernel keeps in LDS) */
+  RTGGX_BUF_COUNT = 24
 };
 
 /* Per-pass GPU timings of the last completed frame, in milliseconds (hipEvent based). */
@@ -197,6 +199,10 @@ int  rtggx_debug_counters(rtggx_context* ctx, uint32_t* out, uint32_t n, int res
  * demand of earlier frames, the default).  *last_demand (may be NULL) receives the number of list entries the most recent
  * frame asked for; synchronises.  Results do not depend on any of this: hits merge with a 64-bit atomic min. */
 int  rtggx_debug_trace_split(rtggx_context* ctx, uint32_t work_per_wave, uint32_t max_shift, int capacity, uint32_t* last_demand);
+/* The traversal kernel keeps one workgroup of 12 to 16 waves per CU resident on full-size frames; the size follows the share of
+   the frame period the traversal takes (DESIGN.md "The trace kernel").  Reports the size and the share last sampled (0 before the
+   first sample).  force_waves: 0 leaves the choice to the library, 10/12/14/16 pins it (measurement). */
+int  rtggx_debug_trace_residency(rtggx_context* ctx, uint32_t force_waves, uint32_t* waves, float* share);
 int  rtggx_get_timings(rtggx_context* ctx, RtggxTimings* out);
 /* mode 0 off, 1 every pass (rtggx_get_timings), 2 only the ray-trace kernel: one HIP event pair per frame,
  * recorded on the launching stream right around the kernel, kept for up to RTGGX_KERNEL_RING frames; 3 like 2 for

@@ -15,20 +15,21 @@ LIB_PATH = os.path.join(_HERE, "librtggx.so")
 # buffer ids (rtggx.h)
 BUF_VISIBILITY, BUF_DEPTH, BUF_NORMAL, BUF_ROUGH_METAL, BUF_VELOCITY, BUF_RT_REFL, BUF_RT_DIFF, BUF_TSS0, BUF_TSS1, \
     BUF_FLT_RFL, BUF_FLT_DFF, BUF_BACKBUFFER, BUF_SH_COEFFS, BUF_BVH_NODES0, BUF_BVH_TRIS0, BUF_BVH_NODES1, BUF_BVH_TRIS1, \
-    BUF_TLAS, BUF_ENV, BUF_BVH4_NODES0, BUF_BVH4_NODES1, BUF_BIN_WORK = range(22)
+    BUF_TLAS, BUF_ENV, BUF_BVH4_NODES0, BUF_BVH4_NODES1, BUF_BIN_WORK, BUF_BVH4_TOP0, BUF_BVH4_TOP1 = range(24)
 FORMAT_RGBA32F, FORMAT_RGBA16F, FORMAT_BC6H_UF16, FORMAT_BC6H_SF16 = 2, 10, 95, 96
 
 _BUF_DTYPE = {BUF_VISIBILITY: np.uint32, BUF_DEPTH: np.uint32, BUF_NORMAL: np.uint32, BUF_ROUGH_METAL: np.uint16,
               BUF_VELOCITY: np.uint32, BUF_RT_REFL: np.uint32, BUF_RT_DIFF: np.uint32, BUF_TSS0: np.uint64, BUF_TSS1: np.uint64,
               BUF_FLT_RFL: np.uint64, BUF_FLT_DFF: np.uint64, BUF_BACKBUFFER: np.uint32, BUF_SH_COEFFS: np.float32,
               BUF_BVH_NODES0: np.uint32, BUF_BVH_TRIS0: np.uint32, BUF_BVH_NODES1: np.uint32, BUF_BVH_TRIS1: np.uint32,
-              BUF_TLAS: np.float32, BUF_ENV: np.uint16, BUF_BVH4_NODES0: np.uint32, BUF_BVH4_NODES1: np.uint32, BUF_BIN_WORK: np.uint32}
+              BUF_TLAS: np.float32, BUF_ENV: np.uint16, BUF_BVH4_NODES0: np.uint32, BUF_BVH4_NODES1: np.uint32, BUF_BIN_WORK: np.uint32,
+              BUF_BVH4_TOP0: np.uint32, BUF_BVH4_TOP1: np.uint32}
 
 EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip", "rtggx_set_stream", "rtggx_set_mesh",
            "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
-           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split",
+           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency",
            "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_debug_shader_clock"]
 
 
@@ -223,6 +224,13 @@ class Context:
         self._check(self.L.rtggx_debug_trace_split(self.h, work_per_wave, max_shift, capacity, C.byref(d)))
         return int(d.value)
 
+    def trace_residency(self, force_waves=0):
+        """(waves of the traversal's resident workgroup, share of the frame period the traversal took when last sampled)."""
+        w, sh = C.c_uint32(), C.c_float()
+        self.L.rtggx_debug_trace_residency.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        self._check(self.L.rtggx_debug_trace_residency(self.h, force_waves, C.byref(w), C.byref(sh)))
+        return int(w.value), float(sh.value)
+
     def debug_counters(self, n=8, reset=True):
         out = np.zeros(n, np.uint32)
         self.L.rtggx_debug_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
@@ -272,7 +280,7 @@ class Context:
             return out.reshape(2, 4, 4)
         if bid == BUF_ENV:
             return out.reshape(-1, 4)
-        if bid in (BUF_BVH4_NODES0, BUF_BVH4_NODES1):
+        if bid in (BUF_BVH4_NODES0, BUF_BVH4_NODES1, BUF_BVH4_TOP0, BUF_BVH4_TOP1):
             return out.reshape(-1, 32)
         return out
 

@@ -198,7 +198,8 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
   RT_HIP(hipMalloc(&c->rayCounterBuf, 1792 * 4)); RT_HIP(hipMemset(c->rayCounterBuf, 0, 1792 * 4));      // [4][256] per-frame counters + 768 statistics words
   c->rayCounter32 = c->lastRayCounter32 = c->rayCounterBuf;
-  RT_HIP(hipHostMalloc(&c->hostRayCounters, 257 * 4)); c->hostRayCounters[256] = 0; RT_HIP(hipEventCreateWithFlags(&c->evRayCounters, hipEventDisableTiming));   // [0..255] rays; [256..] RT_TRACE_STATS
+  RT_HIP(hipMalloc(&c->traceStamps, 8 * 8)); RT_HIP(hipMemset(c->traceStamps, 0, 8 * 8));
+  RT_HIP(hipHostMalloc(&c->hostRayCounters, 264 * 4)); memset(c->hostRayCounters, 0, 264 * 4); RT_HIP(hipEventCreateWithFlags(&c->evRayCounters, hipEventDisableTiming));   // [0..255] rays; [256] split demand; [258..261] duration and period of a trace launch (two 64-bit words)
   {
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, device));
@@ -262,7 +263,7 @@ void rtggx_destroy(rtggx_context* c) {
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
   hipFree(c->binWorkBuf[0]); hipFree(c->binWorkBuf[1]); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
   hipFree(c->stackOverflow); hipFree(c->dummyRecord); hipFree(c->histReach);
-  hipFree(c->dEnvMipOffset); hipFree(c->rayCounterBuf); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
+  hipFree(c->dEnvMipOffset); hipFree(c->rayCounterBuf); hipFree(c->traceStamps); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
@@ -422,6 +423,7 @@ static int splitBvhPerSet(MeshDev& m) {
     RT_HIP(hipMalloc(&m.trisBuf[i], sizeof(BvhTri) * n)); RT_HIP(hipMemcpy(m.trisBuf[i], m.trisBuf[0], sizeof(BvhTri) * n, hipMemcpyDeviceToDevice));
     RT_HIP(hipMalloc(&m.nodesBuf[i], sizeof(BvhNode) * nn)); RT_HIP(hipMemcpy(m.nodesBuf[i], m.nodesBuf[0], sizeof(BvhNode) * nn, hipMemcpyDeviceToDevice));
     RT_HIP(hipMalloc(&m.nodes4Buf[i], sizeof(Bvh4Node) * nn)); RT_HIP(hipMemcpy(m.nodes4Buf[i], m.nodes4Buf[0], sizeof(Bvh4Node) * nn, hipMemcpyDeviceToDevice));
+    if (m.topCount) { RT_HIP(hipMalloc(&m.topBuf[i], sizeof(Bvh4Node) * m.topCount)); RT_HIP(hipMemcpy(m.topBuf[i], m.topBuf[0], sizeof(Bvh4Node) * m.topCount, hipMemcpyDeviceToDevice)); }
   }
   return 0;
 }
@@ -631,6 +633,16 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
   return 0;
 }
 
+int rtggx_debug_trace_residency(rtggx_context* c, uint32_t forceWaves, uint32_t* waves, float* share) {
+  RT_CHECK_CTX(c);
+  if (forceWaves != 0u && forceWaves != 10u && forceWaves != 12u && forceWaves != 14u && forceWaves != 16u) { setError("rtggx_debug_trace_residency: %u waves: 0, 10, 12, 14 or 16", forceWaves); return -1; }
+  c->traceWavesForced = forceWaves;
+  if (forceWaves) c->traceWaves = forceWaves;
+  if (waves) *waves = c->traceWaves;
+  if (share) *share = c->traceShare;
+  return 0;
+}
+
 int rtggx_debug_trace_split(rtggx_context* c, uint32_t workPerWave, uint32_t maxShift, int capacity, uint32_t* lastDemand) {
   RT_CHECK_CTX(c);
   if (maxShift > 3u) { setError("rtggx_debug_trace_split: max_shift %u > 3", maxShift); return -1; }
@@ -706,6 +718,7 @@ static int bufferInfo(rtggx_context* c, int id, void** ptr, size_t* bytes) {
     case RTGGX_BUF_BVH_TRIS0: case RTGGX_BUF_BVH_TRIS1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH_TRIS1]; *ptr = m.tris; *bytes = m.tris ? (size_t)m.numTris * 64 : 0; return 0; }
     case RTGGX_BUF_TLAS: *ptr = nullptr; *bytes = 128; return 0;
     case RTGGX_BUF_BVH4_NODES0: case RTGGX_BUF_BVH4_NODES1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH4_NODES1]; *ptr = m.nodes4; *bytes = m.numTris > 1 && m.nodes4 ? (size_t)(m.numTris - 1) * sizeof(Bvh4Node) : 0; return 0; }
+    case RTGGX_BUF_BVH4_TOP0: case RTGGX_BUF_BVH4_TOP1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH4_TOP1]; *ptr = m.top; *bytes = m.top ? (size_t)m.topCount * sizeof(Bvh4Node) : 0; return 0; }
     case RTGGX_BUF_BIN_WORK: *ptr = c->binWork; *bytes = (size_t)(((c->W + 15) / 16) * ((c->H + 15) / 16)) * 4u * 4u; return 0;
     case RTGGX_BUF_ENV: *ptr = c->env.texels; *bytes = (size_t)c->env.totalTexels * 8; return 0;
     default: setError("unknown buffer id %d", id); return -1;

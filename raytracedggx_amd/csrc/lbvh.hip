@@ -267,6 +267,7 @@ __global__ void emitNodes4(int n, const uint32_t* __restrict__ order, const floa
     }
     nd.pad[k] = 0;
   }
+  nd.pad[0] = depth >> 1;      // level in the 4-wide tree (read by -DRT_TRACE_STATS builds only)
   nodes4[i] = nd;
 }
 __global__ void emitTris(int n, const uint32_t* __restrict__ order, const float* __restrict__ verts, const uint32_t* __restrict__ idx, BvhTri* __restrict__ tris) {
@@ -282,6 +283,18 @@ __global__ void emitTris(int n, const uint32_t* __restrict__ order, const float*
   t.prim = prim;
   for (int k = 0; k < 3; ++k) { t.pad0[k] = 0; t.pad1[k] = 0; }
   tris[s] = t;
+}
+// The table of the tree's top for the trace kernel's LDS (rtggx_device.h RT_TOP_*): entry k = the 4-wide node topList[k], its
+// references to nodes that are in the table themselves replaced by RT_TOP_FLAG | rank.
+__global__ void emitTop(int count, const int32_t* __restrict__ topList, const int32_t* __restrict__ topRank, const Bvh4Node* __restrict__ nodes4, Bvh4Node* __restrict__ top) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  Bvh4Node nd = nodes4[topList[k]];
+  for (int e = 0; e < 4; ++e) {
+    const int32_t r = nd.ref[e];
+    if (r >= 0 && r != RT_BVH4_EMPTY && topRank[r] >= 0) nd.ref[e] = RT_TOP_FLAG | topRank[r];
+  }
+  top[k] = nd;
 }
 
 // ---- refit (rtggx_refit_as): same topology, new vertex positions ---------------------------------------------------------
@@ -376,8 +389,9 @@ void freeBuildProducts(MeshDev& m) {
   hipFree(m.order); hipFree(m.left); hipFree(m.right); hipFree(m.nodeParent); hipFree(m.leafParent); hipFree(m.nodeBox); hipFree(m.triBox); hipFree(m.dTreelets); hipFree(m.dRefitItems); hipFree(m.dRefitRounds);
   m.order = nullptr; m.left = m.right = m.nodeParent = m.leafParent = nullptr; m.nodeBox = m.triBox = nullptr; m.dTreelets = nullptr; m.dRefitItems = nullptr; m.dRefitRounds = nullptr;
   m.roundBase.clear(); m.refitLevels.clear();
-  freeAliased(m.nodesBuf); freeAliased(m.nodes4Buf); freeAliased(m.trisBuf);
-  m.nodes = nullptr; m.nodes4 = nullptr; m.tris = nullptr;
+  freeAliased(m.nodesBuf); freeAliased(m.nodes4Buf); freeAliased(m.trisBuf); freeAliased(m.topBuf);
+  hipFree(m.topList); hipFree(m.topRank); m.topList = m.topRank = nullptr; m.topCount = 0;
+  m.nodes = nullptr; m.nodes4 = nullptr; m.tris = nullptr; m.top = nullptr;
 }
 
 static int launchTreeCost(MeshDev& m, hipStream_t s) {
@@ -407,6 +421,7 @@ int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
     hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right, (const float*)m.nodeBox, m.nodesBuf[set]);
     hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right,
                        (const int32_t*)m.nodeParent, (const float*)m.nodeBox, m.nodes4Buf[set]);
+    if (m.topCount) hipLaunchKernelGGL(emitTop, dim3((m.topCount + 63) / 64), dim3(64), 0, s, (int)m.topCount, (const int32_t*)m.topList, (const int32_t*)m.topRank, (const Bvh4Node*)m.nodes4Buf[set], m.topBuf[set]);
     if (!m.costInFlight && (m.refits & 7u) == 0u) {
       { const int r = launchTreeCost(m, s); if (r) return r; }
       RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s));
@@ -416,6 +431,33 @@ int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
   }
   ++m.refits;
   RT_HIP(hipGetLastError());
+  return 0;
+}
+
+// The first `capacity` 4-wide nodes in breadth-first order (4-wide nodes = the binary nodes of even depth, rtggx_device.h): their
+// list, every node's rank in it, and the table emitTop makes of them.  Host side, at build time.
+static int planTop(MeshDev& m, uint32_t capacity, const std::vector<int32_t>& left, const std::vector<int32_t>& right, hipStream_t s) {
+  const int numNodes = (int)m.numTris - 1;
+  std::vector<int32_t> list, rank(numNodes, -1);
+  if (m.root >= 0) list.push_back(m.root);
+  for (size_t head = 0; head < list.size() && list.size() < capacity; ++head) {      // breadth first: `list` is the queue
+    const int32_t v = list[head];
+    const int32_t ch[2] = {left[v], right[v]};
+    for (int side = 0; side < 2; ++side) {
+      if (ch[side] < 0) continue;
+      const int32_t g[2] = {left[ch[side]], right[ch[side]]};
+      for (int k = 0; k < 2; ++k) if (g[k] >= 0 && list.size() < capacity) list.push_back(g[k]);
+    }
+  }
+  for (size_t k = 0; k < list.size(); ++k) rank[list[k]] = (int32_t)k;
+  m.topCount = (uint32_t)list.size();
+  if (m.topCount == 0) return 0;
+  RT_HIP(hipMalloc(&m.topList, 4 * list.size())); RT_HIP(hipMalloc(&m.topRank, 4 * (size_t)numNodes)); RT_HIP(hipMalloc(&m.topBuf[0], sizeof(Bvh4Node) * list.size()));
+  for (int i = 1; i < RT_SETS; ++i) m.topBuf[i] = m.topBuf[0];
+  m.top = m.topBuf[0];
+  RT_HIP(hipMemcpyAsync(m.topList, list.data(), 4 * list.size(), hipMemcpyHostToDevice, s)); RT_HIP(hipMemcpyAsync(m.topRank, rank.data(), 4 * (size_t)numNodes, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(emitTop, dim3((m.topCount + 63) / 64), dim3(64), 0, s, (int)m.topCount, (const int32_t*)m.topList, (const int32_t*)m.topRank, (const Bvh4Node*)m.nodes4, m.topBuf[0]);
+  RT_HIP(hipStreamSynchronize(s));      // list / rank are host vectors
   return 0;
 }
 
@@ -570,12 +612,15 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   RT_HIP(hipMemcpyAsync(&m.depth, arrive + n, 4, hipMemcpyDeviceToHost, s));
   // the topology and the per-primitive boxes stay for rtggx_refit_as (freed with the mesh or by the next build)
   m.order = order[cur]; m.left = left; m.right = right; m.nodeParent = nodeParent; m.leafParent = leafParent; m.nodeBox = nodeBox; m.triBox = triBox;
-  if (m.roundBase.size() >= 2) {      // PLOC build: plan the refit (rtggx_refit_as) while the topology is at hand
+  if (n > 1) {
     std::vector<int32_t> hl(n - 1), hr(n - 1);
     RT_HIP(hipMemcpyAsync(hl.data(), left, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, s)); RT_HIP(hipMemcpyAsync(hr.data(), right, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, s));
     RT_HIP(hipStreamSynchronize(s));
-    const int r = planRefit(m, hl, hr, s);
-    if (r) return r;
+    { const int r = planTop(m, slot == 0 ? RT_TOP_SLOT0 : RT_TOP_SLOT1, hl, hr, s); if (r) return r; }
+    if (m.roundBase.size() >= 2) {      // PLOC build: plan the refit (rtggx_refit_as) while the topology is at hand
+      const int r = planRefit(m, hl, hr, s);
+      if (r) return r;
+    }
   }
   if (n > 1) { const int r = launchTreeCost(m, s); if (r) return r; RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s)); }
   RT_HIP(hipStreamSynchronize(s));

@@ -66,6 +66,10 @@ struct MeshDev {
   // the three above are those of the CURRENT input set: like the vertices, the boxes and leaf triangles of a deforming mesh exist
   // once per input set (frame f + 1's refit on stream R writes its set while frame f's traversal still walks the other)
   BvhNode* nodesBuf[RT_SETS] = {}; Bvh4Node* nodes4Buf[RT_SETS] = {}; BvhTri* trisBuf[RT_SETS] = {};
+  // the top of the tree once more, breadth-first, for the trace kernel's LDS (rtggx_device.h RT_TOP_*; lbvh.hip planTop / emitTop):
+  // topList[k] = node of rank k, topRank[node] = its rank or -1; the table itself per input set like the nodes
+  int32_t *topList = nullptr, *topRank = nullptr; uint32_t topCount = 0;
+  Bvh4Node* top = nullptr; Bvh4Node* topBuf[RT_SETS] = {};
   // PLOC creates nodes in rounds; a node's children are leaves or nodes of EARLIER rounds, and node indices are handed out round
   // by round: refitting round after round needs no synchronisation inside a round (lbvh.hip: refitLbvh)
   std::vector<uint32_t> roundBase;      // roundBase[k] = first node of round k; roundBase.back() = numTris - 1
@@ -159,7 +163,7 @@ struct rtggx_context {
     setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
     splitList = splitListBuf[i]; splitCount = largeCount ? largeCount + 1 + i : nullptr;
-    for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.fat = m.fatBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.tris = m.trisBuf[i]; }
+    for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.fat = m.fatBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.top = m.topBuf[i]; m.tris = m.trisBuf[i]; }
     const uint32_t par = pipeline != 0 ? (frameCounter & 1u) : 0u;
     binWork = binWorkBuf[par]; rayCounter32 = rayCounterBuf + (pipeline != 0 ? (frameCounter & 3u) : 0u) * 256u;
   }
@@ -191,6 +195,10 @@ struct rtggx_context {
   void* dummyRecord = nullptr;          // 128 zero bytes: record base for meshes without nodes / absent meshes
   uint32_t* dEnvMipOffset = nullptr;    // device copy of env.mipOffset
   uint32_t numCUs = 256;
+  // the trace kernel's workgroup size (full-size launches) and the time stamps it takes of itself (trace.hip): stamps = 3 x (start, end) + (sum of durations, latest start)
+  uint32_t traceWaves = 12, traceWavesForced = 0; float traceShare = 0.0f; unsigned long long* traceStamps = nullptr; uint32_t traceStampLaunch = 0;
+  unsigned long long traceStampSum = 0, traceStampStart = 0; uint32_t traceStampAt = 0, traceSampleLaunch = 0;      // the previous sample; the launch the sample in flight was taken at
+  uint32_t traceTrial = 0, traceCooldown = 0, traceWavesSince = 0; float traceTrialBase = 0.0f;      // a trial of two more waves: samples seen, the period to beat
 
   // counters
   uint32_t* hostRayCounters = nullptr;  // pinned copy of rayCounter32[0..255], refreshed asynchronously after every trace launch

@@ -196,6 +196,17 @@ struct Bvh4Node {
   int32_t ref[4];          // >= 0: 4-wide node (= binary node index), < 0: leaf ~slot, RT_BVH4_EMPTY: unused entry
   int32_t pad[4];
 };
+// The top of each tree a second time, for the trace kernel's LDS (trace.hip): the first RT_TOP_SLOT0 / RT_TOP_SLOT1 4-wide nodes of
+// mesh 0 / mesh 1 in breadth-first order, as Bvh4Node records whose references to nodes INSIDE the table read RT_TOP_FLAG | rank
+// (rank = position in the table); references to nodes outside it, to leaves and empty entries are unchanged.
+#define RT_TOP_FLAG 0x40000000
+#ifndef RT_TOP_SLOT0
+#define RT_TOP_SLOT0 16
+#endif
+#ifndef RT_TOP_SLOT1
+#define RT_TOP_SLOT1 96
+#endif
+#define RT_TOP_NODES (RT_TOP_SLOT0 + RT_TOP_SLOT1)
 struct BvhTri {            // 64 B (same record size as a node: one cooperative 64-byte gather serves both)
   float v0[3], v1[3], v2[3];
   uint32_t pad0[3];

@@ -32,7 +32,7 @@ namespace rt {
 
 #define RT_PRIME_LAUNCHES 4u  // launches of a context whose ray / split counters are read back synchronously (launchTrace)
 #ifndef RT_STACK
-#define RT_STACK 24          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: see tools/probes/trace_stats_probe.py)
+#define RT_STACK 16          // LDS stack entries per lane (deepest stack seen on the bunny/dragon frames: 18, see tools/probes/trace_stats_probe.py; deeper entries spill)
 #endif
 
 struct TraceArgs {
@@ -53,6 +53,10 @@ struct TraceArgs {
   // adaptive split: the first splitBlocks workgroups take their (bin, slice) from the split list; a bin marked as split
   // (binCount bits 8..) is left to them.  binWork: lane-steps spent per bin, for the next frame's decision; null when off.
   const uint32_t* splitList; const uint32_t* splitCount; uint32_t* binWork; uint32_t splitBlocks;
+  // the top of both trees for the LDS (rtggx_device.h RT_TOP_*): Bvh4Node records, breadth-first
+  const float4* top0; const float4* top1; uint32_t topCount0, topCount1;
+  unsigned long long* stamps; uint32_t launch;      // see the kernel
+  uint32_t totalItems;       // work items of the launch: what used to be single-wave workgroups, one per (bin, slice); see traceKernel
 };
 
 // Wave w of the grid traces the rays of bin w, 64 at a time (a second round only where a sub-tile has more than 64
@@ -76,30 +80,38 @@ struct TraceArgs {
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 8u         // lanes standing on a leaf that make a triangle-test phase worthwhile
 #endif
-// Workgroup = ONE wave.  The LDS stack of a workgroup stays allocated until its last wave ends; with four bins per
-// workgroup, three of them empty or cheap, a CU ran out of LDS (6 workgroups) long before it ran out of wave slots, and
-// the kernel averaged 2100 live waves on 5120 slots (tools/probes/trace_stats_probe.py).  The index arithmetic below
-// still speaks of 256-thread "blocks" (four consecutive bins of a tile): hardware workgroup g is wave (g >> 3) & 3 of
-// virtual block ((g >> 5) << 3) | (g & 7) -- same XCD (g & 7) for the four waves of a block.
-#ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 1
-#endif
+// Resident workgroups that draw their bins.  Round 1 launched one single-wave workgroup per bin and let the dispatcher keep the
+// chip full of them (24 waves and 150 KB of LDS stacks per CU).  The kernel is now ONE workgroup of RT_TRACE_WAVES waves per CU
+// (launchTrace) whose waves draw work ITEMS -- what used to be a workgroup id: a (bin, slice) in dispatch order -- until none are
+// left.  Two reasons (profiles/r02_j_resident_trace.txt):
+//   * the frame is a pipeline of three streams (capi.hip), and what the trace kernel occupies is not available to the shading and
+//     denoising kernels next to it.  Ten resident waves and 55 KB of LDS per CU make the kernel itself 10 % slower than 24 waves
+//     and 150 KB did (0.117 against 0.105 ms alone) -- and the frame 7 % faster (0.198 against 0.213 ms).  Six waves are too few
+//     (the traversal becomes the longest stage), twelve and more, or more than ~80 KB of LDS, take the gain away again;
+//   * a workgroup that lives for the whole launch can afford to keep the top of both trees in LDS (RT_TOP_NODES nodes as 7 x 16
+//     bytes, field-major so that lanes on different nodes spread over the banks): 38 % of all node visits on the 1080p bunny frame
+//     go to the model's top four levels (85 nodes) and 13 % to the ground's five nodes (profiles/r02_j_levels.txt).  Those visits
+//     cost ds_read_b128s instead of requests to the vector L1, the unit the whole frame queues for: worth 2 % on the kernel alone
+//     and 5 % on the frame.  A fifth level (341 nodes, 46 KB) adds nothing.
+// Items keep their XCD (item & 7 = the XCD of the workgroup id they replace, so the tile -> L2 assignment below stands).
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0     // touch-prefetch of the next record: measured +20 % kernel time (one more divergent load per step; profiles/r02_d_limiter.txt)
 #endif
-#ifndef RT_TRACE_MIN_WAVES
-#define RT_TRACE_MIN_WAVES 6     // waves per SIMD the register allocation aims for (80 VGPRs; 85 without the hint = 5 waves)
-#endif
-__global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
-  __shared__ int32_t stackMem[RT_STACK * 64 * RT_TRACE_WAVES];
-  __shared__ uint32_t victimMem[64 * RT_TRACE_WAVES];              // scratch: the lanes offering work, compacted
-  const FrameParams& fp = *fpp;
+#define RT_TOP_FIELDS 7          // float4 fields of a Bvh4Node the traversal reads
+template <int WAVES, int TOP> struct TraceLds {
+  int32_t stack[RT_STACK * 64 * WAVES];
+  uint32_t victims[64 * WAVES];              // scratch: the lanes offering work, compacted
+  uint32_t next, done, pad[2];
+  float4 top[TOP ? RT_TOP_FIELDS * RT_TOP_NODES : 1];           // field f of table node k at [f * RT_TOP_NODES + k]; mesh 1's nodes start at k = RT_TOP_SLOT0
+};
+// LDS pointers carry their address space: a generic pointer that may be LDS or global turns every node fetch into a flat load
+typedef __attribute__((address_space(3))) int32_t LdsInt;
+typedef __attribute__((address_space(3))) uint32_t LdsUint;
+typedef float __attribute__((ext_vector_type(4))) NativeFloat4;      // float4 is a class: it has no copy from another address space
+typedef __attribute__((address_space(3))) NativeFloat4 LdsFloat4;
+template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& fp, const TraceArgs& A, LdsInt* const stackMem, LdsUint* const victimMem, const LdsFloat4* const topMem, const uint32_t item) {
   const uint32_t lane = threadIdx.x & 63u;
-#if RT_TRACE_WAVES == 1
-  const uint32_t wave = (blockIdx.x >> 3) & 3u, vblock = ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7u), ldsWave = 0u;
-#else
-  const uint32_t wave = threadIdx.x >> 6, vblock = blockIdx.x, ldsWave = wave;
-#endif
+  const uint32_t wave = (item >> 3) & 3u, vblock = ((item >> 5) << 3) | (item & 7u), ldsWave = threadIdx.x >> 6;
   // Workgroup -> tile.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2; handing every
   // XCD whole super-tiles of 8x8 tiles (128x128 pixels), dealt round-robin over the screen, keeps the part of the tree
   // an L2 needs at any one time small without tying an XCD to one (cheap or expensive) region of the screen.
@@ -139,9 +151,9 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
   if (vblock >= A.splitBlocks && A.binWork != nullptr && (countWord >> 8) != 0u) return;      // traced by the waves of the split list
   const uint32_t count = min(countWord & 0xFFu, RT_BIN);
   if (count <= slice * raysPerWave) return;
-  int32_t* const stackBase = stackMem + ldsWave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
-  int32_t* const stack = stackBase + lane;
-  uint32_t* const victims = victimMem + ldsWave * 64;
+  LdsInt* const stackBase = stackMem + ldsWave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
+  LdsInt* const stack = stackBase + lane;
+  LdsUint* const victims = victimMem + ldsWave * 64;
   const size_t spillStride = A.spillStride;
   int32_t* const spill = A.overflow + (size_t)bin * 512u + slice * 64u + lane;            // entry e at spill[e * spillStride] (512 lanes per bin: up to 8 waves)
   const unsigned long long laneLt = (1ull << lane) - 1ull;
@@ -179,7 +191,7 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
   LaneRay r = toObject(ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, fp.invWorld[INST]);
   float tmin = tmin0;
   uint32_t skip = rc.y;
-  int32_t cur = INST ? A.root1 : A.root0;
+  int32_t cur = (INST ? A.topCount1 : A.topCount0) ? RT_TOP_FLAG : (INST ? A.root1 : A.root0);      // the root is entry 0 of the table
   int sp = 0, sb = 0;                                // my stack holds entries [sb, sp)
   // job state: the primary job of my own ray (none for a degenerate interval: the key stays a miss)
   bool job = hasRay && bestT > tmin, helper = false;
@@ -227,7 +239,7 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
       }
     }
 #ifdef RT_TRACE_STATS
-    ++stIter; if (job && cur >= 0) ++stNode;
+    ++stIter; if (job && cur >= 0) { ++stNode; atomicAdd(&A.stats[512 + INST * 32 + ((cur & RT_TOP_FLAG) ? 31 : min(__float_as_int(nodes[(size_t)cur * 8 + 7].x), 30))], 1u); }
 #endif
     bool finished = false;
     // Pop the next entry of my stack; with none left the job is over.  (The LDS part of the stack is read
@@ -246,8 +258,16 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
     };
     // -- node phase: lanes standing on a 4-wide node test its boxes (one 128-byte fetch); lanes standing on a leaf wait
     if (job && cur >= 0) {
-      const float4* rec = nodes + (size_t)cur * 8;
-      float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+      float4 q0, q1, q2, q3, q4, q5, q6;
+      if (TOP && (cur & RT_TOP_FLAG)) {      // a node of the table in LDS
+        const LdsFloat4* rec = topMem + (INST ? RT_TOP_SLOT0 : 0) + (cur & 0xFFFF);
+#define RT_TOP_FIELD(q, f) { const NativeFloat4 v = rec[(f) * RT_TOP_NODES]; q = make_float4(v.x, v.y, v.z, v.w); }
+        RT_TOP_FIELD(q0, 0) RT_TOP_FIELD(q1, 1) RT_TOP_FIELD(q2, 2) RT_TOP_FIELD(q3, 3) RT_TOP_FIELD(q4, 4) RT_TOP_FIELD(q5, 5) RT_TOP_FIELD(q6, 6)
+#undef RT_TOP_FIELD
+      } else {
+        const float4* rec = nodes + (size_t)cur * 8;
+        q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3]; q4 = rec[4]; q5 = rec[5]; q6 = rec[6];
+      }
       asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
       asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
       asm volatile("" : "+v"(q4.x), "+v"(q4.y), "+v"(q4.z), "+v"(q4.w), "+v"(q5.x), "+v"(q5.y), "+v"(q5.z), "+v"(q5.w));
@@ -352,6 +372,43 @@ __global__ void __launch_bounds__(64 * RT_TRACE_WAVES, RT_TRACE_MIN_WAVES) trace
 #endif
 }
 
+// WAVES waves per workgroup; PER_SIMD: the waves per SIMD the register allocation has to leave room for (launchTrace's variants)
+// TOP = 0: no table in LDS (launchTrace passes topCount0 = topCount1 = 0 to such a variant)
+template <int WAVES, int PER_SIMD, int TOP> __global__ void __launch_bounds__(64 * WAVES, PER_SIMD) traceKernel(const FrameParams* __restrict__ fpp, TraceArgs A) {
+  __shared__ TraceLds<WAVES, TOP> lds;
+  // the tables: Bvh4Node records (8 x float4, the last one padding) -> field-major
+  if (TOP) for (uint32_t i = threadIdx.x; i < A.topCount0 * 8u; i += 64u * WAVES) { const uint32_t k = i >> 3, f = i & 7u; if (f < RT_TOP_FIELDS) lds.top[f * RT_TOP_NODES + k] = A.top0[i]; }
+  if (TOP) for (uint32_t i = threadIdx.x; i < A.topCount1 * 8u; i += 64u * WAVES) { const uint32_t k = i >> 3, f = i & 7u; if (f < RT_TOP_FIELDS) lds.top[f * RT_TOP_NODES + RT_TOP_SLOT0 + k] = A.top1[i]; }
+  if (threadIdx.x == 0) { lds.next = 0u; lds.done = 0u; }
+  // Time stamps for the choice of the workgroup size (steerTraceWaves; 100 MHz wall clock).  Three slots in turn: this launch writes slot
+  // launch % 3 (start; end = the latest workgroup end), reads the previous launch's and clears the next one's.
+  if (blockIdx.x == 0 && threadIdx.x == 0 && A.stamps != nullptr) {
+    const unsigned long long now = wall_clock64();
+    unsigned long long* const mine = A.stamps + 2u * (A.launch % 3u);
+    const unsigned long long* const prev = A.stamps + 2u * ((A.launch + 2u) % 3u);
+    unsigned long long* const next = A.stamps + 2u * ((A.launch + 1u) % 3u);
+    if (A.launch != 0u && prev[0] != 0ull && prev[1] > prev[0]) A.stamps[6] += prev[1] - prev[0];      // running sum of the durations of the launches before this one
+    A.stamps[7] = now;
+    mine[0] = now; next[0] = 0ull; next[1] = 0ull;
+  }
+  __syncthreads();
+  // Items are dealt to the workgroups of an XCD round-robin: every workgroup gets a sample of the whole list (the expensive bins
+  // of the split list first).  The waves of a workgroup draw from that share through a counter in LDS and leave when it is used up.
+  // (One counter per XCD in global memory, drawn from by every wave of the chip, cost 0.75 ms per launch: device-scope atomics on
+  // one address are served one at a time at the memory side, ~20 ns each; profiles/r02_j_resident_trace.txt.)
+  const uint32_t xcd = blockIdx.x & 7u, groupsPerXcd = gridDim.x >> 3;
+  for (;;) {
+    uint32_t j = 0;
+    if ((threadIdx.x & 63u) == 0u) j = atomicAdd(&lds.next, 1u);
+    j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+    const uint32_t item = ((blockIdx.x >> 3) + j * groupsPerXcd) * 8u + xcd;
+    if (j >= 0x1000000u || item >= A.totalItems) break;
+    traceItem<TOP>(*fpp, A, (LdsInt*)lds.stack, (LdsUint*)lds.victims, (const LdsFloat4*)lds.top, item);
+  }
+  // the last wave of the workgroup to leave stamps the end (no barrier: a wave that is done gives its slot back at once)
+  if ((threadIdx.x & 63u) == 0u && A.stamps != nullptr && atomicAdd(&lds.done, 1u) == (uint32_t)WAVES - 1u) atomicMax(A.stamps + 2u * (A.launch % 3u) + 1u, wall_clock64());
+}
+
 #ifdef RT_TRACE_STATS
 __global__ void stampKernel(uint32_t* stats) { *reinterpret_cast<unsigned long long*>(stats + 764) = wall_clock64(); }
 #endif
@@ -359,10 +416,49 @@ __global__ void stampKernel(uint32_t* stats) { *reinterpret_cast<unsigned long l
 // How many waves per bin for the whole launch: one when the rays fill the chip (~5000 wave slots x 64 lanes); 2, 4 or
 // 8 when they do not (small frames, thin strips of a multi-GPU frame).  The ray count is last frame's, copied back
 // asynchronously.
+// The size of the traversal's one workgroup per CU.  What the traversal keeps resident is not available to the kernels of the other
+// two pipeline stages (capi.hip), so it should be small -- 12 waves are best or within noise of best on seven of eight workloads --
+// unless the traversal is what the frame waits for (a large mesh with diffuse rays as well: 0.43 ms per frame with 12 waves, 0.37
+// with 14; profiles/r02_j_resident_trace.txt).  The kernel stamps its own start and end and keeps a running sum of its durations;
+// with the ray counters (every 16th frame) the host gets, for the launches since the last sample, the PERIOD between launches and
+// the SHARE of it the traversal ran.  The share alone does not tell the workloads apart that gain from more waves from those that
+// lose (0.92 against 0.88-0.91), so the size is tried: with a share above RT_WAVES_TRY two more waves for two samples; they stay if
+// the period fell by 3 %, else the old size returns and the next trial waits RT_WAVES_RETRY samples (the workload drifts: a turning
+// model changes the period by 30 % over a few hundred frames).  A share below RT_WAVES_SHRINK
+// takes two waves away again (down to 12).  Results never depend on any of this.
+#define RT_WAVES_TRY 0.88f
+#define RT_WAVES_SHRINK 0.70f
+#define RT_WAVES_RETRY 16u
+static void steerTraceWaves(rtggx_context* c, const unsigned long long* stamps, uint32_t launch) {
+  const unsigned long long sum = stamps[0], start = stamps[1];
+  const unsigned long long dSum = sum - c->traceStampSum, dStart = start - c->traceStampStart;
+  const uint32_t launches = launch - c->traceStampAt, windowBegin = c->traceStampAt;
+  const bool usable = c->traceStampStart != 0ull && start > c->traceStampStart && sum >= c->traceStampSum && dSum <= dStart && launches >= 8u && launches <= 64u;
+  c->traceStampSum = sum; c->traceStampStart = start; c->traceStampAt = launch;
+  if (!usable) { c->traceTrial = 0u; return; }
+  const float period = (float)dStart / (float)launches;
+  c->traceShare = (float)dSum / (float)dStart;
+  static const bool log = getenv("RTGGX_TRACE_LOG") != nullptr;
+  if (log) fprintf(stderr, "[rtggx] trace sample at launch %u: %u launches, period %.1f us, share %.3f, waves %u, trial %u (base %.1f us), cooldown %u\n", launch, launches, period * 0.01f, c->traceShare, c->traceWaves, c->traceTrial, c->traceTrialBase * 0.01f, c->traceCooldown);
+  if (c->traceWavesForced) return;
+  if (c->traceTrial != 0u) {
+    if (++c->traceTrial == 2u) return;                 // the first sample after the change mixes both sizes (frames in flight)
+    if (period < 0.97f * c->traceTrialBase) c->traceCooldown = 8u;                       // the new size stays
+    else { c->traceWaves -= 2u; c->traceWavesSince = launch; c->traceCooldown = RT_WAVES_RETRY; }
+    c->traceTrial = 0u;
+    return;
+  }
+  if (c->traceCooldown) --c->traceCooldown;
+  const bool clean = windowBegin >= c->traceWavesSince + 8u;      // every launch of this sample's window ran with the current size (up to 4 frames are in flight)
+  if (c->traceShare < RT_WAVES_SHRINK && c->traceWaves > 12u) { c->traceWaves -= 2u; c->traceWavesSince = launch; if (c->traceCooldown < 4u) c->traceCooldown = 4u; }
+  else if (c->traceShare > RT_WAVES_TRY && c->traceWaves < 16u && c->traceCooldown == 0u && clean) { c->traceTrialBase = period; c->traceWaves += 2u; c->traceWavesSince = launch; c->traceTrial = 1u; }
+}
+
 uint32_t chooseSliceShift(rtggx_context* c, bool countRays, uint32_t numBins) {
   if (countRays && c->rayCountersInFlight && hipEventQuery(c->evRayCounters) == hipSuccess) {
     uint32_t sum = 0; for (int i = 0; i < 256; ++i) sum += c->hostRayCounters[i];
     c->lastFrameRays = sum; c->splitDemand = c->hostRayCounters[256]; c->rayCountersInFlight = false;
+    steerTraceWaves(c, reinterpret_cast<const unsigned long long*>(c->hostRayCounters + 258), c->traceSampleLaunch);
   }
   static const int forcedShift = getenv("RTGGX_SLICE_SHIFT") ? atoi(getenv("RTGGX_SLICE_SHIFT")) : -1;
   const uint32_t raysGuess = countRays ? c->lastFrameRays : numBins * 40u;
@@ -405,11 +501,41 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.binWork = adaptive ? c->binWork : nullptr; T.splitBlocks = adaptive ? (uint32_t)splitCap / 4u : 0u;
   const uint32_t superTiles = ((tilesX + 7u) / 8u) * ((tilesY + 7u) / 8u);
   const uint32_t grid = T.splitBlocks + ((tilesX ? ((superTiles + 7u) / 8u) * 8u * 64u : (((numBins + 3u) / 4u + 7u) / 8u) * 8u) << T.sliceShift);   // virtual blocks, a multiple of 8
-  if (start || stop) hipExtLaunchKernelGGL(traceKernel, dim3(grid * (4u / RT_TRACE_WAVES)), dim3(64 * RT_TRACE_WAVES), 0, s, start, stop, 0, (const FrameParams*)(c->dParams + c->slot), T);
-  else hipLaunchKernelGGL(traceKernel, dim3(grid * (4u / RT_TRACE_WAVES)), dim3(64 * RT_TRACE_WAVES), 0, s, c->dParams + c->slot, T);
+  T.totalItems = grid * 4u;      // one item per (bin, slice), in the order single-wave workgroups would have been dispatched in
+  T.top0 = (const float4*)c->mesh[0].top; T.topCount0 = have0 && c->mesh[0].top ? c->mesh[0].topCount : 0u;
+  T.top1 = (const float4*)c->mesh[1].top; T.topCount1 = have1 && c->mesh[1].top ? c->mesh[1].topCount : 0u;
+  static const bool noTop = getenv("RTGGX_TRACE_NO_TOP") && atoi(getenv("RTGGX_TRACE_NO_TOP")) != 0;      // measurement: every node from global memory
+  if (noTop) T.topCount0 = T.topCount1 = 0u;
+  if (T.topCount0 > RT_TOP_SLOT0 || T.topCount1 > RT_TOP_SLOT1) { setError("launchTrace: tree tables of %u / %u nodes exceed the LDS slots", T.topCount0, T.topCount1); return -1; }
+  // Which variant.  A full-size launch gets ONE workgroup of traceWaves (12, see steerTraceWaves) waves per CU: see the kernel.  A launch with few rays
+  // (a small frame, a thin strip: sliceShift > 0) lasts as long as its longest chain of dependent steps; it is alone on the chip for
+  // most of that time and wants every wave slot at once: single-wave workgroups without the table, one per item, as in round 1
+  // (0.058 ms for a 1920x171 frame against 0.064 with 3 x 8 resident waves and 0.066 with 16; profiles/r02_j_resident_trace.txt).
+  static const int forced = getenv("RTGGX_TRACE_WAVES") ? atoi(getenv("RTGGX_TRACE_WAVES")) : 0;      // measurement: 1, 10, 12, 14, 16
+  const uint32_t waves = forced ? (uint32_t)forced : (sliceShift > 0u || !countRays) ? 1u : c->traceWaves;
+  const uint32_t perCu = waves == 1u ? 0x10000u : 1u;      // single-wave workgroups: one per item, the dispatcher deals them
+  if (waves == 1u) T.topCount0 = T.topCount1 = 0u;
+  T.stamps = waves == 1u ? nullptr : c->traceStamps; T.launch = c->traceStampLaunch++;      // (thousands of workgroups stamping one word would take longer than the launch)
+  // as many workgroups as stay resident, a multiple of 8 so that every XCD gets its share; fewer when there is less to do
+  const uint32_t wanted = (T.totalItems + waves - 1u) / waves;
+  uint32_t blocks = c->numCUs * perCu < wanted ? c->numCUs * perCu : wanted;
+  blocks = (blocks + 7u) & ~7u;
+  const FrameParams* const dfp = c->dParams + c->slot;
+#define RT_LAUNCH_TRACE(W, PER_SIMD, TOP) { if (start || stop) hipExtLaunchKernelGGL((traceKernel<W, PER_SIMD, TOP>), dim3(blocks), dim3(64 * W), 0, s, start, stop, 0, dfp, T); \
+                                            else hipLaunchKernelGGL((traceKernel<W, PER_SIMD, TOP>), dim3(blocks), dim3(64 * W), 0, s, dfp, T); }
+  switch (waves) {
+    case 1u: RT_LAUNCH_TRACE(1, 5, 0) break;
+    case 10u: RT_LAUNCH_TRACE(10, 4, 1) break;
+    case 12u: RT_LAUNCH_TRACE(12, 4, 1) break;
+    case 14u: RT_LAUNCH_TRACE(14, 4, 1) break;
+    case 16u: RT_LAUNCH_TRACE(16, 4, 1) break;
+    default: setError("launchTrace: no kernel variant with %u waves", waves); return -1;
+  }
+#undef RT_LAUNCH_TRACE
   if (countRays && !c->rayCountersInFlight && (c->traceLaunches < 8u || (c->traceLaunches & 15u) == 0u)) {     // the first frames, then every 16th: ray counters and split demand, for later launches
     RT_HIP(hipMemcpyAsync(c->hostRayCounters, c->rayCounter32, 256 * 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->splitCount, 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipMemcpyAsync(c->hostRayCounters + 258, c->traceStamps + 6, 16, hipMemcpyDeviceToHost, s)); c->traceSampleLaunch = c->traceLaunches;      // sum of the kernel's durations so far, start of this launch
     RT_HIP(hipEventRecord(c->evRayCounters, s));
     c->rayCountersInFlight = true;
     // Priming: the first launches of a context wait for their own counters, so that the decisions they feed (waves per bin,

@@ -95,3 +95,39 @@ def bvh4_check(nodes_u32, nodes4_u32, root):
     inner = wr[used & (wr >= 0)]
     assert (depth[inner] % 2 == 0).all()
     return len(even)
+
+
+TOP_FLAG = 0x40000000
+
+
+def bvh4_top_check(nodes4_u32, top_u32, root, capacity):
+    """The table of the tree's top the trace kernel keeps in LDS (RTGGX_BUF_BVH4_TOP*): the first min(capacity, all) 4-wide nodes
+    in breadth-first order, bit-identical to their records in the node array except that a reference to a node inside the table
+    reads TOP_FLAG | position.  Walks table and tree side by side from the root; returns the number of table entries."""
+    top = top_u32.reshape(-1, 32)
+    if root < 0:
+        assert len(top) == 0
+        return 0
+    nodes4 = nodes4_u32.reshape(-1, 32)
+    assert 1 <= len(top) <= capacity
+    pair = {0: root}                      # table position -> node
+    order = [root]                        # breadth-first order of the tree, as far as needed
+    head = 0
+    while head < len(order) and len(order) < len(top) + 4:
+        refs = nodes4[order[head], 24:28].view(np.int32)
+        order.extend(int(r) for r in refs if 0 <= r != 0x7FFFFFFF)
+        head += 1
+    assert len(order) >= len(top)
+    in_tree = int((nodes4.any(axis=1)).sum())
+    assert len(top) == min(capacity, in_tree), "the table holds %d of %d nodes (capacity %d)" % (len(top), in_tree, capacity)
+    for k in range(len(top)):
+        node = order[k]
+        assert np.array_equal(top[k, :24], nodes4[node, :24]), "boxes of table entry %d" % k
+        want = nodes4[node, 24:28].view(np.int32).astype(np.int64)
+        got = top[k, 24:28].view(np.int32).astype(np.int64)
+        for e in range(4):
+            if 0 <= want[e] != 0x7FFFFFFF and want[e] in order[:len(top)]:
+                assert got[e] == (TOP_FLAG | order.index(int(want[e]))), "entry %d reference %d" % (k, e)
+            else:
+                assert got[e] == want[e], "entry %d reference %d" % (k, e)
+    return len(top)

@@ -57,10 +57,13 @@ class Pair:
         """The CPU re-traces the same BVH arrays the HIP kernels use -- after checking them: every primitive in exactly one
         leaf, every box tight around what is below it, the 4-wide collapse equal to the binary tree (tests/bvh_checks.py)."""
         capi = self.capi
-        for slot, (bn, bt, b4) in enumerate(((capi.BUF_BVH_NODES0, capi.BUF_BVH_TRIS0, capi.BUF_BVH4_NODES0), (capi.BUF_BVH_NODES1, capi.BUF_BVH_TRIS1, capi.BUF_BVH4_NODES1))):
+        for slot, (bn, bt, b4, btop, cap) in enumerate(((capi.BUF_BVH_NODES0, capi.BUF_BVH_TRIS0, capi.BUF_BVH4_NODES0, capi.BUF_BVH4_TOP0, 16),
+                                                        (capi.BUF_BVH_NODES1, capi.BUF_BVH_TRIS1, capi.BUF_BVH4_NODES1, capi.BUF_BVH4_TOP1, 96))):
             nodes, tris, root = self.ctx.readback(bn), self.ctx.readback(bt), self.ctx.bvh_root(slot)
             bvh_checks.bvh_check(nodes, tris, root, self.num_tris[slot])
-            bvh_checks.bvh4_check(nodes, self.ctx.readback(b4), root)
+            nodes4 = self.ctx.readback(b4)
+            bvh_checks.bvh4_check(nodes, nodes4, root)
+            bvh_checks.bvh4_top_check(nodes4, self.ctx.readback(btop), root, cap)
             self.o.set_bvh(slot, nodes, tris, root)
 
     def frame(self):

@@ -22,3 +22,13 @@ for f in range(int(sys.argv[3]) if len(sys.argv) > 3 else 3):
     print("   the wave with the most iterations (%d) did %d lane steps: lane utilisation %.2f" % (longest[0], longest[1], longest[1] / max(longest[0] * 64.0, 1)))
     print("   wave starts per 8 us:", " ".join(str(int(v)) for v in allc[288:320]))
     print("   wave ends   per 8 us:", " ".join(str(int(v)) for v in allc[256:288]))
+    for inst in range(2):
+        lv = allc[512 + 32 * inst:544 + 32 * inst].astype(float)
+        if lv.sum() > 0:
+            print("   instance %d node steps by 4-wide level (share, cumulative):" % inst, " ".join("%d:%.1f%%/%.0f%%" % (k, 100 * lv[k] / c[0], 100 * lv[:k + 1].sum() / c[0]) for k in range(32) if lv[k] > 0))
+import numpy as np
+for inst, bid in ((0, app.capi.BUF_BVH4_NODES0), (1, app.capi.BUF_BVH4_NODES1)):
+    n4 = a.context.readback(bid).reshape(-1, 32)
+    used = n4.any(axis=1)
+    pop = np.bincount(n4[used, 28].astype(np.int64), minlength=1)
+    print("instance %d: %d 4-wide nodes; per level:" % (inst, used.sum()), " ".join(str(int(v)) for v in pop), "; cumulative:", " ".join(str(int(v)) for v in np.cumsum(pop)))
