@@ -26,8 +26,19 @@ txt = open("profiles/%s_pmc_report.txt" % tag).read()
 out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `python3 bench.py --steps 4 --warmup 2` (tools/pmc.sh groups 10, 11), per dispatch averages",
        "correction": "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): FETCH_SIZE is in KB and counts 128-byte requests as 64 on gfx950 (MI355X_MICROARCH.md 'HBM'); uncalibrated for narrow gathers",
        "workload": "bunny 1920x1080, all-metal, shared-memory denoiser", "kernels": {}}
-for block in re.split(r"\n(?=\S)", txt):
+# the trace kernel is a template (waves per workgroup, waves per SIMD, table in LDS): the variant with the most dispatches is "the" kernel
+def dispatches(block):
+    m = re.search(r"\((\d+) dispatches\)", block)
+    return int(m.group(1)) if m else 0
+blocks = re.split(r"\n(?=\S)", txt)
+variants = [b for b in blocks if b.split("\n")[0].strip().startswith("void rt::traceKernel<")]
+main_variant = max(variants, key=dispatches).split("\n")[0].strip() if variants else None
+def kernel_name(block):
     name = block.split("\n")[0].strip()
+    return "rt::traceKernel" if name == main_variant else name
+out["trace_kernel_variant"] = main_variant
+for block in blocks:
+    name = kernel_name(block)
     vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([0-9.]+) per dispatch", block, re.M)}
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and name.startswith(("rt::", "void rt::")):
         out["kernels"][name] = {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
@@ -38,8 +49,8 @@ frame_kernels = ("rt::clearVisDepth", "rt::rasterSmall", "rt::rasterLarge", "rt:
                  "void rt::spatialTiledKernel<0>", "void rt::spatialTiledKernel<1>", "void rt::spatialTiledKernel<2>", "void rt::spatialTiledKernel<3>",
                  "rt::temporalKernel", "rt::toneMapKernel")
 valu = 0.0
-for block in re.split(r"\n(?=\S)", txt):
-    name = block.split("\n")[0].strip()
+for block in blocks:
+    name = kernel_name(block)
     m = re.search(r"^\s+SQ_INSTS_VALU\s+([0-9.]+) per dispatch", block, re.M)
     if m and name.split("(")[0] in frame_kernels:
         valu += float(m.group(1))

@@ -7,7 +7,7 @@ count = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 def short(n):
     return n.replace("void ", "").replace("rt::", "").split("(")[0]
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), short(r["Kernel_Name"])) for r in rows)
-tr = [k for k in ks if k[3] == "traceKernel"]
+tr = [k for k in ks if k[3].startswith("traceKernel")]
 t0, t1 = tr[first][0] - 150000, tr[first + count][1]
 last_end = {}
 for s, e, q, n in ks:
