@@ -564,8 +564,20 @@ int rtggx_ray_trace(rtggx_context* c) {
   if (!c->env.texels) { setError("rtggx_ray_trace: no environment map"); return -1; }
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
-  const hipStream_t sGen = c->genStream ? c->genStream : c->streamAS, sTrace = c->streamAS;
   const uint32_t f = c->frameCounter;
+  const hipStream_t sGen = c->genStream ? c->genStream : c->streamAS;
+  // Launches with few rays (thin strips, small frames) last as long as their longest chain of dependent traversal steps and leave
+  // most of the chip idle meanwhile: the traversals of odd frames go to a second stream, so that two of them can be in flight
+  // (the slowest of the eight strips of the 1080p frame: 0.107 -> 0.081 ms; profiles/r02_l_strip_projection.txt).
+  // Everything a traversal shares with its neighbours in time is per input set, per frame parity or per frame & 3, and everybody
+  // who needs its results waits for its event, not for its stream; the stack spill area exists twice (launchTrace).
+  // The second stream is the refit stream, idle unless a mesh deforms: a FIFTH stream would share one of the four hardware queues
+  // with another one (measured: the deforming bunny went from 0.22 to 0.40 ms per frame when a fifth stream merely existed).
+  static const bool twoTraceStreams = !(getenv("RTGGX_TRACE_STREAMS") && atoi(getenv("RTGGX_TRACE_STREAMS")) == 1);
+  const bool deforming = c->mesh[0].deforming || c->mesh[1].deforming;
+  const bool alternate = twoTraceStreams && c->pipeline != 0 && c->asyncCompute && sGen != c->streamAS && c->streamRefit != nullptr && !deforming && c->lastTraceSmall && (f & 1u) != 0u;
+  const hipStream_t sTrace = alternate ? c->streamRefit : c->streamAS;
+  c->traceSpillHalf = alternate ? 1u : 0u;
   if (sGen != sTrace) {
     // ray generation reads the cost record of the traversal two frames back and resets that frame's ray counters (frame parity)
     if (c->traceRecorded[(f + 2u) & 3u]) RT_HIP(hipStreamWaitEvent(sGen, c->evTraceRing[(f + 2u) & 3u], 0));

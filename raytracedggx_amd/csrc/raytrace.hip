@@ -469,6 +469,9 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   G.tilesX = tilesX; G.numTiles = tilesX * tilesY; G.rowBegin = rb; G.rowEnd = re;
   const uint32_t splitWork = c->splitWork, splitMaxShift = c->splitMaxShift;
   const uint32_t sliceShift = chooseSliceShift(c, true, G.numTiles * 4u);
+  // "wide" launches: few enough rays that the traversal does not fill the chip for long (trace.hip launchTrace, capi.hip rtggx_ray_trace)
+  static const uint32_t wideRays = getenv("RTGGX_WIDE_RAYS") ? (uint32_t)atoi(getenv("RTGGX_WIDE_RAYS")) : RT_WIDE_RAYS;
+  c->lastTraceSmall = sliceShift > 0u || c->lastFrameRays < wideRays;
   const bool adaptive = splitWork != 0u && sliceShift == 0u;
   c->lastTraceAdaptive = adaptive;
   // the split list is sized from the demand of an earlier frame (copied back asynchronously, like the ray counters)

@@ -194,6 +194,7 @@ struct rtggx_context {
   uint32_t spillEntries = 0;            // the depth of the built trees: [spillEntries][numBinsMax * 128] words
   void* dummyRecord = nullptr;          // 128 zero bytes: record base for meshes without nodes / absent meshes
   uint32_t* dEnvMipOffset = nullptr;    // device copy of env.mipOffset
+  bool lastTraceSmall = false; uint32_t traceSpillHalf = 0;
   uint32_t numCUs = 256;
   // the trace kernel's workgroup size (full-size launches) and the time stamps it takes of itself (trace.hip): stamps = 3 x (start, end) + (sum of durations, latest start)
   uint32_t traceWaves = 12, traceWavesForced = 0; float traceShare = 0.0f; unsigned long long* traceStamps = nullptr; uint32_t traceStampLaunch = 0;

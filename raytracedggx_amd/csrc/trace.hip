@@ -483,12 +483,12 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   // (a 4-wide node leaves at most 3 entries behind, and there is one per two levels of the binary tree)
   const uint32_t deepest = 3u * ((c->mesh[0].depth > c->mesh[1].depth ? c->mesh[0].depth : c->mesh[1].depth) / 2u + 1u);
   if (deepest > RT_STACK + c->spillEntries) {
-    RT_HIP(hipStreamSynchronize(s));
+    RT_HIP(hipDeviceSynchronize());
     if (c->stackOverflow) { RT_HIP(hipFree(c->stackOverflow)); c->stackOverflow = nullptr; }
     c->spillEntries = deepest - RT_STACK;
-    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)c->spillEntries * c->numBinsMax * 512 * 4));
+    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)2 * c->spillEntries * c->numBinsMax * 512 * 4));      // twice: two traversals can be in flight (traceSpillHalf)
   }
-  T.overflow = c->stackOverflow; T.rayTotals = c->rayCounter32; T.stats = c->rayCounterBuf + 1024; T.runTotals = c->rayCounter + 256;
+  T.overflow = c->stackOverflow + (size_t)c->traceSpillHalf * c->spillEntries * c->numBinsMax * 512; T.rayTotals = c->rayCounter32; T.stats = c->rayCounterBuf + 1024; T.runTotals = c->rayCounter + 256;
   T.spillStride = (size_t)c->numBinsMax * 512;
   T.countRowBegin = countRays ? fp.rowBegin : 0u; T.countRowEnd = countRays ? fp.rowEnd : 0u; T.width = fp.W;
 #ifdef RT_TRACE_STATS
@@ -512,7 +512,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   // most of that time and wants every wave slot at once: single-wave workgroups without the table, one per item, as in round 1
   // (0.058 ms for a 1920x171 frame against 0.064 with 3 x 8 resident waves and 0.066 with 16; profiles/r02_j_resident_trace.txt).
   static const int forced = getenv("RTGGX_TRACE_WAVES") ? atoi(getenv("RTGGX_TRACE_WAVES")) : 0;      // measurement: 1, 10, 12, 14, 16
-  const uint32_t waves = forced ? (uint32_t)forced : (sliceShift > 0u || !countRays) ? 1u : c->traceWaves;
+  const uint32_t waves = forced ? (uint32_t)forced : (sliceShift > 0u || !countRays || c->lastTraceSmall) ? 1u : c->traceWaves;
   const uint32_t perCu = waves == 1u ? 0x10000u : 1u;      // single-wave workgroups: one per item, the dispatcher deals them
   if (waves == 1u) T.topCount0 = T.topCount1 = 0u;
   T.stamps = waves == 1u ? nullptr : c->traceStamps; T.launch = c->traceStampLaunch++;      // (thousands of workgroups stamping one word would take longer than the launch)
