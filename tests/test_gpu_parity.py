@@ -811,6 +811,28 @@ def test_timing_mode_free_running_equals_synchronised(built):
         a.OnDestroy(); b.OnDestroy()
 
 
+def test_small_frames_two_traversals_in_flight_equal_synchronised(built):
+    """Launches below 200 000 rays send the traversals of odd frames to a second stream, so that two are in flight (capi.hip
+    rtggx_ray_trace): 48 free-running frames of a turning 640x360 bunny (with diffuse rays: two rays per pixel, both image targets)
+    and of a 1920x171 frame against the same frames synchronised one by one -- every target bit-identical, and the free-running
+    ray total equal to the synchronised one."""
+    from raytracedggx_amd import app, capi
+    for size, extra in (((640, 360), ["-metallic", 0.25, 0.5]), ((1920, 171), [])):
+        args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", size[0], "-height", size[1], "-sharedmem", "-dt", 0.05] + extra
+        a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+        try:
+            for f in range(48):
+                a.OnUpdate(); a.OnRender(); a.context.sync()
+                b.OnUpdate(); b.OnRender()
+            b.context.sync()
+            assert a.context.ray_total() == b.context.ray_total() > 0
+            for bid in (capi.BUF_VISIBILITY, capi.BUF_DEPTH, capi.BUF_NORMAL, capi.BUF_VELOCITY, capi.BUF_RT_REFL, capi.BUF_RT_DIFF, capi.BUF_FLT_RFL, capi.BUF_TSS0, capi.BUF_TSS1,
+                        capi.BUF_BACKBUFFER):
+                np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="%dx%d buffer %d" % (size + (bid,)))
+        finally:
+            a.OnDestroy(); b.OnDestroy()
+
+
 def test_update_as_after_render_visibility(built):
     """The C ABI allows rtggx_update_as after rtggx_render_visibility of the same frame (the sample overlaps the two on its two
     queues, RayTracedGGX.cpp:304-339): the visibility pass has then carried the slot to the device with the previous frame's TLAS,
