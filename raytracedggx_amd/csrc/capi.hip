@@ -209,7 +209,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     c->numBinsMax = tiles * 4u;
     if (c->numBinsMax < 64u) c->numBinsMax = 64u;            // room for rtggx_trace_rays batches on tiny frames
     for (int i = 0; i < RT_SETS; ++i) {
-      RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * 128 * 64));
+      RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * RT_BIN * sizeof(rt::RayRec)));
       RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * 128 * 8));
       RT_HIP(hipMalloc(&c->binCountBuf[i], (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCountBuf[i], 0, (size_t)c->numBinsMax * 4));
     }
@@ -262,7 +262,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
   hipFree(c->binWorkBuf[0]); hipFree(c->binWorkBuf[1]); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
-  hipFree(c->stackOverflow); hipFree(c->dummyRecord); hipFree(c->histReach);
+  hipFree(c->stackOverflow); hipFree(c->testRayRange); hipFree(c->dummyRecord); hipFree(c->histReach);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounterBuf); hipFree(c->traceStamps); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);

@@ -225,7 +225,6 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
   const EnvRef env{A.env, A.envSize, A.envMips, A.envMipOffset};
   bool wantRefl = false, wantDiff = false;
   RayRec rr, rd;
-  rr.pad = 0; rr.wpad = 0.0f; rd.pad = 0; rd.wpad = 0.0f;
   if (inside) {
     const uint32_t W = fp.W, H = fp.H;
     const size_t pix = (size_t)py * W + px;
@@ -301,8 +300,8 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
           const float NoH = saturatef(dot3(N, Hh));
           const float k = 4.0f * VoH / NoH;
           wantRefl = true;
-          rr.ox = P.x; rr.oy = P.y; rr.oz = P.z; rr.tmin = 1e-5f;
-          rr.dx = R.x; rr.dy = R.y; rr.dz = R.z; rr.tmax = 10000.0f;
+          rr.ox = P.x; rr.oy = P.y; rr.oz = P.z;
+          rr.dx = R.x; rr.dy = R.y; rr.dz = R.z;
           rr.pixel = (uint32_t)pix; rr.skip = skip; rr.flags = 0u;
           rr.wx = ((NoL * F.x) * vis) * k; rr.wy = ((NoL * F.y) * vis) * k; rr.wz = ((NoL * F.z) * vis) * k;   // :477
         }
@@ -312,8 +311,8 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
         const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
         const f3 dir = normalize3(N + mk3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta));
         wantDiff = true;
-        rd.ox = P.x; rd.oy = P.y; rd.oz = P.z; rd.tmin = 1e-5f;
-        rd.dx = dir.x; rd.dy = dir.y; rd.dz = dir.z; rd.tmax = 10000.0f;
+        rd.ox = P.x; rd.oy = P.y; rd.oz = P.z;
+        rd.dx = dir.x; rd.dy = dir.y; rd.dz = dir.z;
         rd.pixel = (uint32_t)pix; rd.skip = skip; rd.flags = 1u;
         rd.wx = color.x * (1.0f - 0.04f); rd.wy = color.y * (1.0f - 0.04f); rd.wz = color.z * (1.0f - 0.04f);   // :532
       }      // else: RayTracingOut1 keeps what it held -- carried over from the previous frame's set by shadeKernel (see there)
@@ -325,8 +324,8 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
   const uint32_t nR = (uint32_t)__popcll(maskR);
   RayRec* dst = A.rays + (size_t)bin * RT_BIN;
   HitKey* keys = A.hits + (size_t)bin * RT_BIN;      // every ray starts as a miss at TMax
-  if (wantRefl) { const uint32_t k = (uint32_t)__popcll(maskR & below); dst[k] = rr; keys[k] = hitKey(rr.tmax, 0xFFFFFFFFu); }
-  if (wantDiff) { const uint32_t k = nR + (uint32_t)__popcll(maskD & below); dst[k] = rd; keys[k] = hitKey(rd.tmax, 0xFFFFFFFFu); }
+  if (wantRefl) { const uint32_t k = (uint32_t)__popcll(maskR & below); dst[k] = rr; keys[k] = hitKey(RT_RAY_TMAX, 0xFFFFFFFFu); }
+  if (wantDiff) { const uint32_t k = nR + (uint32_t)__popcll(maskD & below); dst[k] = rd; keys[k] = hitKey(RT_RAY_TMAX, 0xFFFFFFFFu); }
   const uint32_t nRaysInBin = nR + (uint32_t)__popcll(maskD);
   if (A.binWork == nullptr) {
     if (lane == 0) A.binCount[bin] = nRaysInBin;
@@ -411,8 +410,10 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) shadeKernel(const Fram
   for (uint32_t i = threadIdx.x & 63u; i < count; i += 64u) {
     const size_t slot = (size_t)bin * RT_BIN + i;
     const float4* rp = reinterpret_cast<const float4*>(A.rays + slot);
-    const float4 ra = rp[0], rb = rp[1], rw = rp[3];
-    const uint4 rc = reinterpret_cast<const uint4*>(A.rays + slot)[2];
+    const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    // the round-1 names: ra = origin, rb = direction, rc = (pixel, skip, flags), rw = weight
+    const float4 ra = make_float4(q0.x, q0.y, q0.z, RT_RAY_TMIN), rb = make_float4(q0.w, q1.x, q1.y, RT_RAY_TMAX), rw = make_float4(q2.x, q2.y, q2.z, 0.0f);
+    const uint4 rc = make_uint4(__float_as_uint(q1.z), __float_as_uint(q1.w), __float_as_uint(q2.w), 0u);
     const uint32_t hitId = hitKeyId(A.hits[slot]);
     const f3 dir = mk3(rb.x, rb.y, rb.z);
     const bool diffuseGroup = (rc.z & 1u) != 0u;
@@ -524,16 +525,17 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
 }
 
 // ---- test entry: closest-hit queries for an explicit ray list (through the same trace kernel) ---------------
-__global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec* q0, HitKey* keys, uint32_t* binCount) {
+__global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec* q0, HitKey* keys, uint32_t* binCount, float2* tRange) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i % RT_BIN == 0 && i < n) binCount[i / RT_BIN] = n - i < RT_BIN ? n - i : RT_BIN;   // bins are filled densely, in order
   if (i >= n) return;
   const float* r = rays + 8 * (size_t)i;
   RayRec rr;
-  rr.ox = r[0]; rr.oy = r[1]; rr.oz = r[2]; rr.tmin = r[6]; rr.dx = r[3]; rr.dy = r[4]; rr.dz = r[5]; rr.tmax = r[7];
-  rr.pixel = 0u; rr.skip = 0xFFFFFFFFu; rr.flags = 0u; rr.pad = 0u; rr.wx = rr.wy = rr.wz = rr.wpad = 0.0f;
+  rr.ox = r[0]; rr.oy = r[1]; rr.oz = r[2]; rr.dx = r[3]; rr.dy = r[4]; rr.dz = r[5];
+  rr.pixel = 0u; rr.skip = 0xFFFFFFFFu; rr.flags = 0u; rr.wx = rr.wy = rr.wz = 0.0f;
   q0[i] = rr;
-  keys[i] = hitKey(rr.tmax, 0xFFFFFFFFu);
+  tRange[i] = make_float2(r[6], r[7]);      // these rays bring their own interval
+  keys[i] = hitKey(r[7], 0xFFFFFFFFu);
 }
 __global__ void exportTestHits(const FrameParams* __restrict__ fpp, const RayRec* __restrict__ rays, const HitKey* __restrict__ hits, uint32_t n,
                                const float4* __restrict__ fat0, const float4* __restrict__ fat1, float* __restrict__ out) {
@@ -560,8 +562,11 @@ int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays,
   if (n > c->numBinsMax * RT_BIN) { setError("rtggx_trace_rays: at most %u rays per launch", c->numBinsMax * RT_BIN); return -1; }
   const uint32_t numBins = (((n + RT_BIN - 1u) / RT_BIN) + 3u) & ~3u;   // whole tiles of four bins
   RT_HIP(hipMemsetAsync(c->binCount, 0, (size_t)numBins * 4, s));
-  hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, (HitKey*)c->hitQueue, c->binCount);
-  { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u, chooseSliceShift(c, false, numBins), -1); if (r) return r; }
+  // the rays' own (TMin, TMax): one float2 per slot, kept for the context's lifetime once a caller has used this entry point
+  if (!c->testRayRange) RT_HIP(hipMalloc(&c->testRayRange, (size_t)c->numBinsMax * RT_BIN * sizeof(float2)));
+  hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, (HitKey*)c->hitQueue, c->binCount, (float2*)c->testRayRange);
+  c->traceRayRange = c->testRayRange;
+  { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u, chooseSliceShift(c, false, numBins), -1); c->traceRayRange = nullptr; if (r) return r; }
   hipLaunchKernelGGL(exportTestHits, dim3((n + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, (const RayRec*)c->rayQueue, (const HitKey*)c->hitQueue, n,
                      (const float4*)c->mesh[0].fat, (const float4*)c->mesh[1].fat, dOut);
   RT_HIP(hipGetLastError());

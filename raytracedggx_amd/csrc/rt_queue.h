@@ -34,12 +34,17 @@ namespace rt {
 #define RT_SPLIT_MAX_SHIFT 1u   // ... up to 2^this
 #endif
 
-// 64-byte ray record
+// 48-byte ray record (three 16-byte words; the traversal reads the first two).  Every ray of a frame has the shader's interval
+// (TMin, TMax) = (1e-5, 10000) (RayTracing.hlsl:183-198 with the literals of :441,:504): it is not stored.  Rays handed in through
+// rtggx_trace_rays bring their own interval in a side array (TraceArgs::tRange).  Round 1's record was 64 bytes: written by ray
+// generation, read by the traversal and by shading, a sixth of the frame's memory traffic.
+#define RT_RAY_TMIN 1e-5f
+#define RT_RAY_TMAX 10000.0f
 struct __attribute__((aligned(16))) RayRec {
-  float ox, oy, oz, tmin;
-  float dx, dy, dz, tmax;
-  uint32_t pixel, skip /* (inst<<24)|prim the ray starts on, ~0 none */, flags /* bit0: diffuse hit group */, pad;
-  float wx, wy, wz, wpad;   // BRDF weight applied to the returned radiance
+  float ox, oy, oz, dx;
+  float dy, dz; uint32_t pixel, skip /* (inst<<24)|prim the ray starts on, ~0 none */;
+  float wx, wy, wz;   // BRDF weight applied to the returned radiance
+  uint32_t flags;     // bit0: diffuse hit group
 };
 // 8-byte hit key of a ray slot: (bits of t << 32) | id, id = (inst<<24)|prim, ~0 = miss.  t > 0, so keys order like
 // (t, id): the closest-hit rule (smaller t, ties to the smaller id) is a 64-bit unsigned min, and every job that

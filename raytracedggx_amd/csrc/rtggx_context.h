@@ -190,6 +190,7 @@ struct rtggx_context {
   void* hitQueue = nullptr;
   uint32_t* binCount = nullptr;         // rays in each bin
   uint32_t numBinsMax = 0;
+  void *testRayRange = nullptr, *traceRayRange = nullptr;      // rtggx_trace_rays: the rays' own (TMin, TMax); set only around that entry point's launch
   int32_t* stackOverflow = nullptr;     // traversal-stack spill area (entries beyond the LDS stack), sized from
   uint32_t spillEntries = 0;            // the depth of the built trees: [spillEntries][numBinsMax * 128] words
   void* dummyRecord = nullptr;          // 128 zero bytes: record base for meshes without nodes / absent meshes

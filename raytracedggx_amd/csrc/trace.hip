@@ -41,6 +41,7 @@ struct TraceArgs {
   int32_t root0, root1;
   uint32_t haveMesh0, haveMesh1;
   const RayRec* rays; HitKey* hits;
+  const float2* tRange;      // (TMin, TMax) per ray slot for rtggx_trace_rays; null: the shader's constants (rt_queue.h)
   const uint32_t* binCount; uint32_t numBins;
   int32_t* overflow;        // [entry][numBinsMax * RT_BIN] spill area for stacks deeper than RT_STACK
   uint32_t* rayTotals;       // 256 per-frame partial counters (the current frame parity's half)
@@ -168,11 +169,13 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
   const bool hasRay = lane < raysPerWave && rayIndex < count;
 
   // ---- the ray (world space) ------------------------------------------------------------------------------------
-  const float4* rp = reinterpret_cast<const float4*>(A.rays + (hasRay ? slot : bin * RT_BIN));
-  const float4 ra = rp[0], rb = rp[1];
-  const uint4 rc = reinterpret_cast<const uint4*>(rp)[2];
-  const float tmin0 = ra.w;
-  float bestT = rb.w;
+  const uint32_t raySlot = hasRay ? slot : bin * RT_BIN;
+  const float4* rp = reinterpret_cast<const float4*>(A.rays + raySlot);
+  const float4 q0 = rp[0], q1 = rp[1];      // origin + dx | dy dz pixel skip
+  const float4 ra = make_float4(q0.x, q0.y, q0.z, 0.0f), rb = make_float4(q0.w, q1.x, q1.y, 0.0f);
+  const uint4 rc = make_uint4(__float_as_uint(q1.z), __float_as_uint(q1.w), 0u, 0u);
+  float tmin0 = RT_RAY_TMIN, bestT = RT_RAY_TMAX;
+  if (A.tRange != nullptr) { const float2 tr = A.tRange[raySlot]; tmin0 = tr.x; bestT = tr.y; }
   uint32_t bestId = 0xFFFFFFFFu;
   {
     const uint32_t row = rc.x / A.width;
@@ -477,7 +480,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.nodes1 = (const float4*)(have1 && c->mesh[1].nodes4 ? (const void*)c->mesh[1].nodes4 : c->dummyRecord);
   T.tris1 = (const float4*)(have1 ? (const void*)c->mesh[1].tris : c->dummyRecord);
   T.root0 = c->mesh[0].root; T.root1 = c->mesh[1].root; T.haveMesh0 = have0; T.haveMesh1 = have1;
-  T.rays = (const RayRec*)c->rayQueue; T.hits = (HitKey*)c->hitQueue;
+  T.rays = (const RayRec*)c->rayQueue; T.hits = (HitKey*)c->hitQueue; T.tRange = (const float2*)c->traceRayRange;
   T.binCount = c->binCount; T.numBins = numBins;
   // stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get
   // (a 4-wide node leaves at most 3 entries behind, and there is one per two levels of the binary tree)
