@@ -183,6 +183,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   for (int i = 0; i < RT_SETS; ++i) {
     RT_HIP(hipMalloc(&c->visDepthBuf[i], n * 8)); RT_HIP(hipMemset(c->visDepthBuf[i], 0, n * 8));
     RT_HIP(hipMalloc(&c->normalBuf[i], n * 4)); RT_HIP(hipMemset(c->normalBuf[i], 0, n * 4));
+    RT_HIP(hipMalloc(&c->depth32Buf[i], n * 4)); RT_HIP(hipMemset(c->depth32Buf[i], 0, n * 4));
     RT_HIP(hipMalloc(&c->velocityBuf[i], n * 4)); RT_HIP(hipMemset(c->velocityBuf[i], 0, n * 4));
     RT_HIP(hipMalloc(&c->rtReflBuf[i], n * 4)); RT_HIP(hipMemset(c->rtReflBuf[i], 0, n * 4));
     RT_HIP(hipMalloc(&c->rtDiffBuf[i], n * 4)); RT_HIP(hipMemset(c->rtDiffBuf[i], 0, n * 4));
@@ -257,7 +258,7 @@ void rtggx_destroy(rtggx_context* c) {
     hipFree(m.indices); hipFree(m.dCost); if (m.hCost) hipHostFree(m.hCost); if (m.evCost) hipEventDestroy(m.evCost);
   }
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->backbuffer);
-  for (int i = 0; i < RT_SETS; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
+  for (int i = 0; i < RT_SETS; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->depth32Buf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
@@ -722,7 +723,7 @@ static int bufferInfo(rtggx_context* c, int id, void** ptr, size_t* bytes) {
     case RTGGX_BUF_RT_DIFF: *ptr = c->rtDiff; *bytes = n * 4; return 0;
     case RTGGX_BUF_TSS0: *ptr = c->tss[0]; *bytes = n * 8; return 0;
     case RTGGX_BUF_TSS1: *ptr = c->tss[1]; *bytes = n * 8; return 0;
-    case RTGGX_BUF_FLT_RFL: *ptr = c->fltRfl; *bytes = n * 8; return 0;
+    case RTGGX_BUF_FLT_RFL: *ptr = c->fltRflIsFltDff ? c->fltDff : c->fltRfl; *bytes = n * 8; return 0;      // identical images when no diffuse pass ran: only one was written (denoise.hip launchDenoise)
     case RTGGX_BUF_FLT_DFF: *ptr = c->fltDff; *bytes = n * 8; return 0;
     case RTGGX_BUF_BACKBUFFER: *ptr = c->backbuffer; *bytes = n * 4; return 0;
     case RTGGX_BUF_SH_COEFFS: *ptr = c->sh; *bytes = 108; return 0;
@@ -786,6 +787,7 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
     if (!r && hipStreamSynchronize(c->streamMain) != hipSuccess) { setError("upload: stream sync failed"); r = -2; }
     if (!r) { hipError_t e = hipMemcpy(id == RTGGX_BUF_VISIBILITY ? dVis : dDepth, src, need, hipMemcpyHostToDevice); if (e != hipSuccess) { setError("hipMemcpy: %s", hipGetErrorString(e)); r = -2; } }
     if (!r) r = packVisDepth(c, dVis, dDepth, c->streamMain);
+    if (!r && id == RTGGX_BUF_DEPTH && hipMemcpy(c->depth32, src, need, hipMemcpyHostToDevice) != hipSuccess) { setError("upload: depth copy failed"); r = -2; }      // the filters' copy (ray generation writes it otherwise)
     hipStreamSynchronize(c->streamMain);
     hipFree(dVis); hipFree(dDepth);
     return r;

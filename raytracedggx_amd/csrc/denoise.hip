@@ -36,7 +36,7 @@ RT_DEV float rcpFast(float x) { return __builtin_amdgcn_rcpf(x); }
 
 struct GTexel { float nx, ny, nz, nw, rough, metal, depth; };
 
-RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restrict__ roughMetal, const unsigned long long* __restrict__ visDepth,
+RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restrict__ roughMetal, const uint32_t* __restrict__ depth32,
                     int x, int y, int W, int H) {
   GTexel g;
   if (x < 0 || y < 0 || x >= W || y >= H) { g.nx = g.ny = g.nz = -1.0f; g.nw = 0.0f; g.rough = 0.0f; g.metal = 0.0f; g.depth = 0.0f; return g; }
@@ -48,13 +48,13 @@ RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restr
   g.nw = (float)(n >> 30) * (1.0f / 3.0f);
   const uint32_t rm = roughMetal[i];
   g.rough = (float)(rm & 0xFFu) * (1.0f / 255.0f); g.metal = (rm >> 8) == 255u ? 1.0f : (float)(rm >> 8) * (1.0f / 255.0f);
-  g.depth = (float)(uint32_t)(visDepth[i] >> 32) * (1.0f / 16777215.0f);
+  g.depth = (float)depth32[i] * (1.0f / 16777215.0f);
   return g;
 }
 RT_DEV f3 TM3(f3 c) { const float r = rcpFast(1.0f + ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f)); return mk3(c.x * r, c.y * r, c.z * r); }     // FilterCommon.hlsli:14-19
 RT_DEV f3 ITM3(f3 c) { const float r = rcpFast(1.0f - ((c.x * 0.25f + c.y * 0.5f) + c.z * 0.25f)); return mk3(c.x * r, c.y * r, c.z * r); }    // :24-27
 struct Targets {
-  const uint32_t* normal; const uint16_t* roughMetal; const unsigned long long* visDepth; const uint32_t* velocity;
+  const uint32_t* normal; const uint16_t* roughMetal; const uint32_t* depth32; const uint32_t* velocity;
   const uint32_t* rtRefl; const uint32_t* rtDiff;
   uint2* scratch; const uint2* history; uint2* fltRfl; uint2* fltDff; uint32_t* backbuffer;
   int W, H, rowBegin, rowEnd;
@@ -101,7 +101,7 @@ RT_DEV void storeFiltered(const Targets& T, size_t pix, float mx, float my, floa
   const float rw = rcpFast(wsum);
   f3 mu = mk3(mx * rw, my * rw, mz * rw);
   if (MODE == 0 || MODE == 2) T.scratch[pix] = packRGBA16F(mu.x, mu.y, mu.z, 0.0f);
-  if (MODE == 1) { mu = ITM3(mu); const uint2 v = packRGBA16F(mu.x, mu.y, mu.z, 1.0f); T.fltRfl[pix] = v; T.fltDff[pix] = v; }
+  if (MODE == 1) { mu = ITM3(mu); const uint2 v = packRGBA16F(mu.x, mu.y, mu.z, 1.0f); if (T.fltRfl) T.fltRfl[pix] = v; T.fltDff[pix] = v; }
   if (MODE == 3) {
     const f4 dest = unpackRGBA16F(T.fltRfl[pix]);
     mu = ITM3(mu);
@@ -113,7 +113,7 @@ RT_DEV void storeFiltered(const Targets& T, size_t pix, float mx, float my, floa
 // only touches the pixels it filters (on the all-metal default scene: none) instead of copying the whole image.
 template <int MODE>
 RT_DEV void storeSkipped(const Targets& T, size_t pix) {
-  if (MODE == 1) { const f3 s = unpackR11G11B10F(T.rtRefl[pix]); const uint2 v = packRGBA16F(s.x, s.y, s.z, 0.0f); T.fltRfl[pix] = v; T.fltDff[pix] = v; }
+  if (MODE == 1) { const f3 s = unpackR11G11B10F(T.rtRefl[pix]); const uint2 v = packRGBA16F(s.x, s.y, s.z, 0.0f); if (T.fltRfl) T.fltRfl[pix] = v; T.fltDff[pix] = v; }
 }
 // Source colour of a tap: the ray-traced result tone-mapped (H passes) or the H pass's scratch (V passes).
 template <int MODE>
@@ -131,14 +131,14 @@ __global__ void __launch_bounds__(256) spatialDirectKernel(Targets T) {
   const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= T.W || y >= T.rowEnd) return;
   const size_t pix = (size_t)y * T.W + x;
-  const GTexel gc = loadG(T.normal, T.roughMetal, T.visDepth, x, y, T.W, T.H);
+  const GTexel gc = loadG(T.normal, T.roughMetal, T.depth32, x, y, T.W, T.H);
   if (diffuse ? (gc.nw <= 0.0f || gc.metal >= 1.0f) : (gc.nw <= 0.0f)) { storeSkipped<MODE>(T, pix); return; }
   const Centre c = makeCentre<diffuse>(gc.nx, gc.ny, gc.nz, gc.depth, gc.rough, T.W, T.H);
   float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
   for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
     const int tx = vertical ? x : x + i, ty = vertical ? y + i : y;
     const bool inside = tx >= 0 && ty >= 0 && tx < T.W && ty < T.H;
-    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);     // zeros outside: normal -1, flag 0
+    const GTexel g = loadG(T.normal, T.roughMetal, T.depth32, tx, ty, T.W, T.H);     // zeros outside: normal -1, flag 0
     if (diffuse && (g.nw <= 0.0f || g.metal >= 1.0f)) continue;
     const f3 src = inside ? tapColour<MODE>(T, (size_t)ty * T.W + tx) : mk3(0.0f, 0.0f, 0.0f);
     const float w = tapWeight<diffuse>(c, i, g.nx, g.ny, g.nz, g.depth, g.nw > 0.0f ? g.rough : __uint_as_float(__float_as_uint(g.rough) | 0x80000000u));
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
     const int tx = ox + t % TW, ty = oy + t / TW;
     float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const bool inside = tx >= 0 && ty >= 0 && tx < T.W && ty < T.H;
-    const GTexel g = loadG(T.normal, T.roughMetal, T.visDepth, tx, ty, T.W, T.H);       // zeros outside
+    const GTexel g = loadG(T.normal, T.roughMetal, T.depth32, tx, ty, T.W, T.H);       // zeros outside
     v[3] = g.depth; v[4] = g.rough;
     if (diffuse) {
       if (g.nw > 0.0f && g.metal < 1.0f) {
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
 
 static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass) {
   Targets T;
-  T.normal = c->normal; T.roughMetal = c->roughMetal; T.visDepth = c->visDepth; T.velocity = c->velocity;
+  T.normal = c->normal; T.roughMetal = c->roughMetal; T.depth32 = c->depth32; T.velocity = c->velocity;
   T.rtRefl = c->rtRefl; T.rtDiff = c->rtDiff;
   T.scratch = c->tss[c->frameParity]; T.history = c->tss[c->frameParity ^ 1u]; T.fltRfl = c->fltRfl; T.fltDff = c->fltDff; T.backbuffer = c->backbuffer;
   T.W = (int)fp.W; T.H = (int)fp.H;
@@ -491,16 +491,20 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
   // to do (the reflection V pass already wrote FilteredOut1) and are not launched.  RTGGX_KEEP_EMPTY_DIFFUSE=1 launches them.
   static const bool keepEmpty = getenv("RTGGX_KEEP_EMPTY_DIFFUSE") && atoi(getenv("RTGGX_KEEP_EMPTY_DIFFUSE")) != 0;
   const bool anyDiffuse = keepEmpty || fp.mat.RoughMetals[0][1] < 1.0f || fp.mat.RoughMetals[1][1] < 1.0f;
+  // FilteredOut is read by the diffuse V pass only.  Without diffuse passes the reflection V pass writes FilteredOut1 alone (the two
+  // images would be identical, 8 bytes per pixel each); rtggx_readback(RTGGX_BUF_FLT_RFL) then returns FilteredOut1 (capi.hip).
+  c->fltRflIsFltDff = !anyDiffuse;
+  Targets TVr = TV; if (!anyDiffuse) TVr.fltRfl = nullptr;
   if (useLds) {
     hipLaunchKernelGGL(spatialTiledKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
-    hipLaunchKernelGGL(spatialTiledKernel<1>, grid(TV, RT_VBW, RT_VBH), block, 0, s, TV); mark(5);
+    hipLaunchKernelGGL(spatialTiledKernel<1>, grid(TV, RT_VBW, RT_VBH), block, 0, s, TVr); mark(5);
     if (anyDiffuse) hipLaunchKernelGGL(spatialTiledKernel<2>, grid(TH, 64, 4), block, 0, s, TH);
     mark(6);
     if (anyDiffuse) hipLaunchKernelGGL(spatialTiledKernel<3>, grid(TV, RT_VBW, RT_VBH), block, 0, s, TV);
     mark(7);
   } else if (!anyDiffuse) {
     hipLaunchKernelGGL(spatialDirectKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
-    hipLaunchKernelGGL(spatialDirectKernel<1>, grid(TV, 64, 4), block, 0, s, TV); mark(5); mark(6); mark(7);
+    hipLaunchKernelGGL(spatialDirectKernel<1>, grid(TV, 64, 4), block, 0, s, TVr); mark(5); mark(6); mark(7);
   } else {
     hipLaunchKernelGGL(spatialDirectKernel<0>, grid(TH, 64, 4), block, 0, s, TH); mark(4);
     hipLaunchKernelGGL(spatialDirectKernel<1>, grid(TV, 64, 4), block, 0, s, TV); mark(5);

@@ -197,7 +197,7 @@ RT_DEV f2 calcBarycentrics(const f4 p[3], f2 ndc) {   // :204-225
 // Kernel 1: ray generation
 // =========================================================================================================
 struct GenArgs {
-  const unsigned long long* visDepth;
+  const unsigned long long* visDepth; uint32_t* depthOut;
   uint32_t* normalOut; uint16_t* roughMetalOut; uint32_t* velocityOut; uint32_t* reflOut; uint32_t* diffOut;
   const uint16_t* roughMetalPrev;   // the previous frame's input set = what this target held before this frame
   const float4* fat0; const float4* fat1;
@@ -229,7 +229,9 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
     const uint32_t W = fp.W, H = fp.H;
     const size_t pix = (size_t)py * W + px;
     // getPrimarySurface :277-333
-    uint32_t visibility = (uint32_t)A.visDepth[pix];
+    const unsigned long long visWord = A.visDepth[pix];
+    uint32_t visibility = (uint32_t)visWord;
+    A.depthOut[pix] = (uint32_t)(visWord >> 32);      // the filters read depth four bytes at a time instead of every other word of an 8-byte array
     f2 screenPos; screenPos.x = ((float)px + 0.5f) / (float)W * 2.0f - 1.0f; screenPos.y = ((float)py + 0.5f) / (float)H * 2.0f - 1.0f;
     screenPos.y = -screenPos.y;
     const f3 eye = mk3(fp.rg.EyePt[0], fp.rg.EyePt[1], fp.rg.EyePt[2]);
@@ -462,7 +464,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   if (re <= rb) return 0;
   const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
   GenArgs G;
-  G.visDepth = c->visDepth; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
+  G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
   G.fat0 = c->mesh[0].fat; G.fat1 = c->mesh[1].fat;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;

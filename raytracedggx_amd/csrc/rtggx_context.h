@@ -139,6 +139,7 @@ struct rtggx_context {
   hipEvent_t evRefit = nullptr;   // vertices of the current set uploaded and the tree refitted (stream B -> stream C)
   hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
   bool setReadRecorded[RT_SETS] = {};
+  bool fltRflIsFltDff = false;          // the last denoise ran without diffuse passes: FilteredOut == FilteredOut1 and only the latter was written
   bool externalStream = false;
 
   rt::MeshDev mesh[2];
@@ -154,13 +155,14 @@ struct rtggx_context {
   uint32_t *normal = nullptr, *velocity = nullptr, *rtRefl = nullptr, *rtDiff = nullptr, *backbuffer = nullptr;
   uint16_t* roughMetal = nullptr;
   unsigned long long* visDepthBuf[RT_SETS] = {};
+  uint32_t* depth32 = nullptr; uint32_t* depth32Buf[RT_SETS] = {};      // the D24 word of visDepth once more, 4 bytes per pixel, for the spatial filters (written by ray generation)
   uint32_t *normalBuf[RT_SETS] = {}, *velocityBuf[RT_SETS] = {}, *rtReflBuf[RT_SETS] = {}, *rtDiffBuf[RT_SETS] = {};
   uint16_t* roughMetalBuf[RT_SETS] = {};
   uint32_t setIndex = 0;
   void *rayQueueBuf[RT_SETS] = {}, *hitQueueBuf[RT_SETS] = {};   // ray bins: written on stream B, shaded on the main stream
   uint32_t* binCountBuf[RT_SETS] = {};
   void selectSet(uint32_t i) {
-    setIndex = i; visDepth = visDepthBuf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
+    setIndex = i; visDepth = visDepthBuf[i]; depth32 = depth32Buf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
     splitList = splitListBuf[i]; splitCount = largeCount ? largeCount + 1 + i : nullptr;
     for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.fat = m.fatBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.top = m.topBuf[i]; m.tris = m.trisBuf[i]; }
