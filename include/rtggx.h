@@ -89,7 +89,8 @@ enum {
   RTGGX_BUF_RT_DIFF = 6,     /* uint32  R11G11B10_FLOAT, RayTracingOut1 */
   RTGGX_BUF_TSS0 = 7,        /* uint64  R16G16B16A16_FLOAT, TemporalSSOut0 */
   RTGGX_BUF_TSS1 = 8,        /* uint64  TemporalSSOut1 */
-  RTGGX_BUF_FLT_RFL = 9,     /* uint64  FilteredOut */
+  RTGGX_BUF_FLT_RFL = 9,     /* uint64  FilteredOut (with no diffuse pass to read it -- both instances fully metallic -- it equals FilteredOut1
+                                bit for bit and only that one is written: readback and buffer_ptr then return FilteredOut1) */
   RTGGX_BUF_FLT_DFF = 10,    /* uint64  FilteredOut1 */
   RTGGX_BUF_BACKBUFFER = 11, /* uint32  R8G8B8A8_UNORM */
   RTGGX_BUF_SH_COEFFS = 12,  /* 27 floats: 9 x float3 */

@@ -195,3 +195,35 @@ def test_camera_handlers_orbit_and_dolly(built):
     np.testing.assert_allclose(view, v, atol=5e-5); np.testing.assert_allclose(eye, e, atol=5e-4)
     eye2, _ = app.camera(W, H, ev + [(4, 4.0, 0)])                       # wheel +4: a quarter closer
     assert abs(np.linalg.norm(eye2 - focus) - 0.75 * d0) < 1e-3
+
+
+def test_bvh4_top_table_checker_on_a_synthetic_tree():
+    """tests/bvh_checks.py: bvh4_top_check is what the GPU tests trust for the LDS table of the trace kernel (RTGGX_BUF_BVH4_TOP*).
+    A small 4-wide tree by hand, its table for several capacities, and three ways of getting the table wrong."""
+    import bvh_checks
+    E = 0x7FFFFFFF
+    n4 = np.zeros((8, 32), np.uint32)
+    def node(i, refs):
+        n4[i, :24] = np.arange(24) + 100 * i + 1
+        n4[i, 24:28] = np.array(refs, np.int32).view(np.uint32)
+    node(0, [2, 4, -1, E]); node(2, [6, -2, -3, E]); node(4, [-4, -5, E, E]); node(6, [-6, -7, -8, -9])
+    order = [0, 2, 4, 6]
+    def table(cap):
+        used = order[:cap]
+        t = n4[used].copy()
+        for k in range(len(used)):
+            r = t[k, 24:28].view(np.int32)
+            for e in range(4):
+                if 0 <= r[e] != E and r[e] in used:
+                    r[e] = bvh_checks.TOP_FLAG | used.index(int(r[e]))
+        return t
+    for cap, want in ((1, 1), (2, 2), (3, 3), (4, 4), (16, 4)):
+        assert bvh_checks.bvh4_top_check(n4, table(cap), 0, cap) == want
+    bad = table(4); bad[1, 3] ^= 1                                   # a box bit
+    with pytest.raises(AssertionError):
+        bvh_checks.bvh4_top_check(n4, bad, 0, 4)
+    bad = table(4); bad[0, 24] = 2                                   # a reference into the table left raw
+    with pytest.raises(AssertionError):
+        bvh_checks.bvh4_top_check(n4, bad, 0, 4)
+    with pytest.raises(AssertionError):                              # too few entries for the capacity
+        bvh_checks.bvh4_top_check(n4, table(2), 0, 4)
