@@ -833,6 +833,39 @@ def test_small_frames_two_traversals_in_flight_equal_synchronised(built):
             a.OnDestroy(); b.OnDestroy()
 
 
+def test_trace_workgroup_size_changes_nothing(built):
+    """The traversal's resident workgroup has 12 waves, or 14 / 16 when a trial says so (trace.hip steerTraceWaves); launches with few
+    rays use single-wave workgroups.  rtggx_debug_trace_residency pins the size: five frames of the turning dragon with diffuse rays at
+    every size against the default -- every ray-dependent target bit-identical, the ray totals equal; an unsupported size is an error."""
+    from raytracedggx_amd import app, capi
+    args = ["-mesh", assets.path("dragon.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 1280, "-height", 720, "-sharedmem", "-dt", 0.1, "-metallic", 0.25, 0.5]
+    ref = app.RayTracedGGX(args)
+    try:
+        for f in range(5):
+            ref.OnUpdate(); ref.OnRender()
+        ref.context.sync()
+        want = {bid: ref.context.readback(bid) for bid in (capi.BUF_RT_REFL, capi.BUF_RT_DIFF, capi.BUF_FLT_DFF, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_BACKBUFFER)}
+        total = ref.context.ray_total()
+        assert ref.context.trace_residency()[0] in (12, 14, 16)
+        with pytest.raises(capi.RtggxError):
+            ref.context.trace_residency(11)
+    finally:
+        ref.OnDestroy()
+    for waves in (10, 12, 14, 16):
+        a = app.RayTracedGGX(args)
+        try:
+            assert a.context.trace_residency(waves)[0] == waves
+            for f in range(5):
+                a.OnUpdate(); a.OnRender()
+            a.context.sync()
+            assert a.context.trace_residency()[0] == waves, "a pinned size stays"
+            assert a.context.ray_total() == total
+            for bid, w in want.items():
+                np.testing.assert_array_equal(a.context.readback(bid), w, err_msg="%d waves, buffer %d" % (waves, bid))
+        finally:
+            a.OnDestroy()
+
+
 def test_update_as_after_render_visibility(built):
     """The C ABI allows rtggx_update_as after rtggx_render_visibility of the same frame (the sample overlaps the two on its two
     queues, RayTracedGGX.cpp:304-339): the visibility pass has then carried the slot to the device with the previous frame's TLAS,
