@@ -141,6 +141,9 @@ int  rtggx_history_overreach(rtggx_context* ctx, uint32_t* rows, int reset);
  * visibility pass, ray generation and traversal keep running ahead on the context's internal stream B, joined
  * to the main stream by events.  NULL (also the handle of the null stream) restores the context's own stream. */
 int  rtggx_set_stream(rtggx_context* ctx, void* hip_stream);
+/* The context's main stream (its own, or the one handed in): what a host enqueues there -- the per-frame RCCL exchange of the
+ * multi-GPU host, host/Strips.cpp -- is ordered behind the frame's tone map and before the next frame's temporal pass. */
+int  rtggx_get_stream(rtggx_context* ctx, void** hip_stream);
 
 /* The sample's asynchronous-compute toggle (m_asyncCompute, key [A]: RayTracedGGX.cpp:304-353 issues the frame over two
  * queues, :513-556 as one command list).  enable = 0: every pass is issued to the main stream in submission order (no

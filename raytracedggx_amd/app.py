@@ -15,7 +15,8 @@ HOST_EXPORTS = ["rtggx_app_last_error", "rtggx_app_create", "rtggx_app_destroy",
                 "rtggx_app_on_key_up", "rtggx_app_set_time_step", "rtggx_app_context", "rtggx_app_size",
                 "rtggx_app_frame_constants", "rtggx_app_save_image", "rtggx_host_obj_import", "rtggx_host_obj_copy",
                 "rtggx_host_halton", "rtggx_host_frame_constants", "rtggx_host_write_png", "rtggx_host_camera",
-                "rtggx_app_on_lbutton_down", "rtggx_app_on_lbutton_up", "rtggx_app_on_mouse_move", "rtggx_app_on_mouse_wheel", "rtggx_app_load_track"]
+                "rtggx_app_on_lbutton_down", "rtggx_app_on_lbutton_up", "rtggx_app_on_mouse_move", "rtggx_app_on_mouse_wheel", "rtggx_app_load_track",
+                "rtggx_host_exchange_plan", "rtggx_host_balanced_bounds"]
 
 _lib = None
 

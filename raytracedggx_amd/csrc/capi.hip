@@ -308,6 +308,8 @@ int rtggx_set_stream(rtggx_context* c, void* stream) {
   return 0;
 }
 
+int rtggx_get_stream(rtggx_context* c, void** stream) { RT_CHECK_CTX(c); if (!stream) { setError("rtggx_get_stream: null"); return -1; } *stream = (void*)c->streamMain; return 0; }
+
 // The sample's [A] toggle / m_asyncCompute (RayTracedGGX.cpp:304-353 vs the single command list of :513-556).  Off: every
 // pass of a frame is issued to ONE stream in submission order -- no stream B, no stream C, no overlap between the
 // ray-tracing half of one frame and the denoising half of the previous one.  Results are identical either way.

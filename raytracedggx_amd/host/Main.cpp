@@ -6,11 +6,16 @@
 #include <cstdio>
 #include <exception>
 #include "RayTracedGGX.h"
+#include "Strips.h"
 
 int main(int argc, char* argv[]) {
   RayTracedGGX app(1280, 720, "DXR Ray-Traced GGX");   // Main.cpp:17
   try {
     app.ParseCommandLineArgs(argv, argc);
+    // several GPUs: one process per GPU (nothing has touched a GPU yet: the launcher may restart the executable), each a strip of rows
+    if (app.GetNumGpus() > 1 && app.GetRank() < 0) return strips::LaunchRanks(app.GetNumGpus(), argc, argv);
+    if (app.GetNumGpus() > 1) return strips::RunRank(app, app.GetRank(), app.GetNumGpus(), app.GetIdFile(), app.GetBalance());
+    if (app.GetNumStrips() > 1) return strips::RunStripsInOneProcess(app, app.GetNumStrips(), app.GetBalance(), argc, argv);
     app.OnInit();
     rtggx_context* ctx = app.GetContext();
     const auto t0 = std::chrono::steady_clock::now();

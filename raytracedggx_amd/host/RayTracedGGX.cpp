@@ -178,7 +178,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     return (arg[0] == '-' || arg[0] == '/') && lower(arg + 1) == lower(name);
   };
   // On POSIX an absolute path also starts with '/': such a token is a flag only when it names one.
-  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus", "track", "deform"};
+  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus", "track", "deform", "rank", "idfile", "strips", "balance"};
   const auto isFlagName = [&](const char* name) { for (const char* f : kFlags) if (lower(name) == f) return true; return false; };
   const auto hasNextArgValue = [&](int i) {
     if (i + 1 >= argc) return false;
@@ -205,13 +205,14 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     else if (isArgMatched(i, "dump")) { if (hasNextArgValue(i)) m_dumpPrefix = argv[++i]; }
     else if (isArgMatched(i, "deform")) { nextFloat(i, m_deformAmplitude); }
     else if (isArgMatched(i, "track")) { if (hasNextArgValue(i)) m_trackFileName = argv[++i]; }
-    else if (isArgMatched(i, "gpus")) {
-      // One process drives one GPU.  Several GPUs = one process per GPU, each rendering a strip of rows and exchanging the
-      // temporal history over RCCL (raytracedggx_amd/strips.py; bench.py under torch.distributed.run): say so, loudly.
-      const int n = hasNextArgValue(i) ? std::atoi(argv[++i]) : 1;
-      if (n != 1) throw std::runtime_error("-gpus " + std::to_string(n) + ": this executable drives one GPU; run one process per GPU: "
-                                           "python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N");
-    }
+    // Several GPUs = one process per GPU, each rendering a strip of rows and exchanging the temporal history over RCCL
+    // (host/Strips.cpp; Main.cpp restarts the executable once per rank).  -rank / -idfile are what the launcher passes on;
+    // -strips N renders N strips in THIS process on one GPU (the exchange code without N GPUs); -balance 0: equal strips.
+    else if (isArgMatched(i, "gpus")) { if (hasNextArgValue(i)) m_gpus = std::atoi(argv[++i]); if (m_gpus < 1 || m_gpus > 64) throw std::runtime_error("-gpus: 1 .. 64"); }
+    else if (isArgMatched(i, "rank")) { if (hasNextArgValue(i)) m_rank = std::atoi(argv[++i]); }
+    else if (isArgMatched(i, "idfile")) { if (hasNextArgValue(i)) m_idFile = argv[++i]; }
+    else if (isArgMatched(i, "strips")) { if (hasNextArgValue(i)) m_strips = std::atoi(argv[++i]); if (m_strips < 1 || m_strips > 64) throw std::runtime_error("-strips: 1 .. 64"); }
+    else if (isArgMatched(i, "balance")) { if (hasNextArgValue(i)) m_balance = std::atoi(argv[++i]) != 0; }
   }
 }
 

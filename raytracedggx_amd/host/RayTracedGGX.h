@@ -2,7 +2,7 @@
 // DXFramework virtuals RayTracedGGX/Common/DXFramework.h:23-26): OnInit / OnUpdate / OnRender /
 // OnDestroy, the same command line (RayTracedGGX.cpp:462-511) and the same defaults
 // (RayTracedGGX.cpp:37-39, camera :19-23, 267-277).  What the window supplied interactively is
-// supplied by extra flags: -width -height -frames -dt -metallic -sharedmem -sync -device -dump -track -deform.
+// supplied by extra flags: -width -height -frames -dt -metallic -sharedmem -sync -device -dump -track -deform -gpus -strips -balance.
 #pragma once
 #include <vector>
 #include <cstdint>
@@ -44,6 +44,12 @@ class RayTracedGGX {
   uint32_t GetHeight() const { return m_height; }
   uint32_t GetNumFrames() const { return m_numFrames; }
   const std::string& GetDumpPrefix() const { return m_dumpPrefix; }
+  // multi-GPU (host/Strips.h): -gpus N (one process per GPU), what the launcher hands a rank, the single-process mode
+  int GetNumGpus() const { return m_gpus; }
+  int GetRank() const { return m_rank; }
+  const std::string& GetIdFile() const { return m_idFile; }
+  int GetNumStrips() const { return m_strips; }
+  bool GetBalance() const { return m_balance; }
   RayTracer* GetRayTracer() const { return m_rayTracer.get(); }
   rtggx_context* GetContext() const { return m_rayTracer ? m_rayTracer->GetContext() : nullptr; }
   void SetFixedTimeStep(float dt) { m_fixedTimeStep = dt; }
@@ -85,6 +91,7 @@ class RayTracedGGX {
   float m_fixedTimeStep = 1.0f / 60.0f;   // the reference steps by the wall clock (StepTimer); fixed here for reproducible runs
   int m_device = 0;
   std::string m_dumpPrefix;
+  int m_gpus = 1, m_rank = -1, m_strips = 1; bool m_balance = true; std::string m_idFile;
   bool m_hasMetallicOverride = false;
   // -deform <amplitude>: the model breathes -- a travelling sine wave through its vertices, DeformPeriod key shapes computed once
   // at start-up and handed to RayTracer::UpdateMesh one per frame (per-frame host cost: one copy of the vertex array)

@@ -1,0 +1,273 @@
+// Multi-GPU host: see Strips.h.  The plan functions mirror raytracedggx_amd/strips.py line for line in meaning.
+#include "Strips.h"
+#include <dlfcn.h>
+#include <strings.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <thread>
+#include "RayTracedGGX.h"
+
+namespace strips {
+
+std::pair<uint32_t, uint32_t> StripRows(uint32_t height, int rank, int world, const std::vector<uint32_t>* bounds) {
+  if (bounds && !bounds->empty()) return {(*bounds)[rank], (*bounds)[rank + 1]};
+  return {(uint32_t)(((uint64_t)rank * height) / world), (uint32_t)(((uint64_t)(rank + 1) * height) / world)};
+}
+
+std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int world, uint32_t minRows) {
+  const uint32_t height = (uint32_t)rowCost.size();
+  if (height < (uint32_t)world * minRows) throw std::runtime_error(std::to_string(height) + " rows cannot hold " + std::to_string(world) + " strips of at least " + std::to_string(minRows) + " rows");
+  std::vector<double> csum(height + 1, 0.0);
+  for (uint32_t y = 0; y < height; ++y) csum[y + 1] = csum[y] + rowCost[y];
+  std::vector<uint32_t> bounds{0};
+  for (int k = 1; k < world; ++k) {
+    // first index whose running cost reaches k / world of the total (numpy.searchsorted, side = "left")
+    const double want = csum[height] * k / world;
+    uint32_t b = (uint32_t)(std::lower_bound(csum.begin(), csum.end(), want) - csum.begin());
+    b = std::max(b, bounds.back() + minRows);                          // room for this strip ...
+    b = std::min(b, height - (uint32_t)(world - k) * minRows);         // ... and for the ones that follow
+    bounds.push_back(b);
+  }
+  bounds.push_back(height);
+  return bounds;
+}
+
+std::vector<Op> ExchangePlan(uint32_t height, int rank, int world, uint32_t apron, const std::vector<uint32_t>* bounds) {
+  const auto [b, e] = StripRows(height, rank, world, bounds);
+  std::vector<Op> ops;
+  if (rank > 0) {                      // the upper neighbour owns [.., b)
+    ops.push_back({true, true, b, std::min(b + apron, e), rank - 1});
+    ops.push_back({false, true, b > apron ? b - apron : 0u, b, rank - 1});
+  }
+  if (rank < world - 1) {              // the lower neighbour owns [e, ..)
+    ops.push_back({true, true, std::max(e > apron ? e - apron : 0u, b), e, rank + 1});
+    ops.push_back({false, true, e, std::min(e + apron, height), rank + 1});
+  }
+  if (rank == 0) {                     // frame assembly on rank 0
+    for (int r = 1; r < world; ++r) { const auto [rb, re] = StripRows(height, r, world, bounds); ops.push_back({false, false, rb, re, r}); }
+  } else ops.push_back({true, false, b, e, 0});
+  return ops;
+}
+
+// ---- RCCL, loaded at run time ---------------------------------------------------------------------------------------------
+namespace {
+struct UniqueId { char internal[128]; };      // rccl.h: NCCL_UNIQUE_ID_BYTES
+constexpr int kUint8 = 1;                     // ncclUint8
+using FnGetUniqueId = int (*)(UniqueId*);
+using FnCommInitRank = int (*)(void**, int, UniqueId, int);
+using FnCommDestroy = int (*)(void*);
+using FnSendRecv = int (*)(void*, size_t, int, int, void*, void*);
+using FnGroup = int (*)();
+using FnErrorString = const char* (*)(int);
+enum { kGetUniqueId, kCommInitRank, kCommDestroy, kSend, kRecv, kGroupStart, kGroupEnd, kErrorString };
+const char* const kNames[8] = {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"};
+}  // namespace
+
+Rccl::Rccl() {
+  const char* env = std::getenv("RTGGX_RCCL_LIBRARY");
+  const char* const candidates[] = {env, "librccl.so", "/opt/rocm/lib/librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* c : candidates) if (c && (m_lib = dlopen(c, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!m_lib) throw std::runtime_error(std::string("RCCL: librccl.so not found (set RTGGX_RCCL_LIBRARY): ") + dlerror());
+  for (int i = 0; i < 8; ++i) if (!(m_fn[i] = dlsym(m_lib, kNames[i]))) throw std::runtime_error(std::string("RCCL: no symbol ") + kNames[i]);
+}
+Rccl::~Rccl() {
+  if (m_comm) reinterpret_cast<FnCommDestroy>(m_fn[kCommDestroy])(m_comm);
+  // the library stays loaded: it owns threads
+}
+static void check(void* const* fn, int rc, const char* what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + reinterpret_cast<FnErrorString>(fn[kErrorString])(rc));
+}
+void Rccl::InitRank(int rank, int world, const std::string& idFile) {
+  UniqueId id;
+  std::memset(&id, 0, sizeof id);
+  if (rank == 0) {
+    check(m_fn, reinterpret_cast<FnGetUniqueId>(m_fn[kGetUniqueId])(&id), "ncclGetUniqueId");
+    if (world > 1) {      // hand it to the other ranks: write beside, then rename (a reader never sees half a file)
+      const std::string tmp = idFile + ".tmp";
+      FILE* f = std::fopen(tmp.c_str(), "wb");
+      if (!f || std::fwrite(&id, sizeof id, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+      std::fclose(f);
+      if (std::rename(tmp.c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+    }
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      struct stat st;
+      if (stat(idFile.c_str(), &st) == 0 && (size_t)st.st_size == sizeof id) {
+        FILE* f = std::fopen(idFile.c_str(), "rb");
+        if (f && std::fread(&id, sizeof id, 1, f) == 1) { std::fclose(f); break; }
+        if (f) std::fclose(f);
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) throw std::runtime_error("rank " + std::to_string(rank) + ": no ncclUniqueId in " + idFile + " after 120 s");
+      std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+  }
+  check(m_fn, reinterpret_cast<FnCommInitRank>(m_fn[kCommInitRank])(&m_comm, world, id, rank), "ncclCommInitRank");
+}
+void Rccl::Exchange(const std::vector<RawOp>& ops, void* stream) {
+  if (ops.empty()) return;
+  check(m_fn, reinterpret_cast<FnGroup>(m_fn[kGroupStart])(), "ncclGroupStart");
+  for (const RawOp& o : ops) {
+    const int rc = reinterpret_cast<FnSendRecv>(m_fn[o.send ? kSend : kRecv])(o.ptr, o.bytes, kUint8, o.peer, m_comm, stream);
+    if (rc != 0) { reinterpret_cast<FnGroup>(m_fn[kGroupEnd])(); check(m_fn, rc, o.send ? "ncclSend" : "ncclRecv"); }
+  }
+  check(m_fn, reinterpret_cast<FnGroup>(m_fn[kGroupEnd])(), "ncclGroupEnd");
+}
+
+// ---- one application = one strip ----------------------------------------------------------------------------------------------
+static void abi(int rc, const char* what) { if (rc != 0) throw std::runtime_error(std::string(what) + ": " + rtggx_last_error()); }
+
+static RawOp rawOp(const Op& o, RayTracedGGX& app, bool send, int peer) {
+  rtggx_context* ctx = app.GetContext();
+  uint32_t parity = 0; abi(rtggx_frame_parity(ctx, &parity), "rtggx_frame_parity");
+  void* base = nullptr;
+  abi(rtggx_buffer_ptr(ctx, o.history ? (parity ? RTGGX_BUF_TSS1 : RTGGX_BUF_TSS0) : RTGGX_BUF_BACKBUFFER, &base), "rtggx_buffer_ptr");
+  const size_t rowBytes = (size_t)app.GetWidth() * (o.history ? 8u : 4u);
+  return {send, static_cast<char*>(base) + (size_t)o.rowBegin * rowBytes, (size_t)(o.rowEnd - o.rowBegin) * rowBytes, peer};
+}
+std::vector<RawOp> PlanToRaw(const std::vector<Op>& plan, RayTracedGGX& app) {
+  std::vector<RawOp> raw;
+  for (const Op& o : plan) raw.push_back(rawOp(o, app, o.send, o.peer));
+  return raw;
+}
+
+std::vector<uint32_t> ProfileBounds(RayTracedGGX& app, int world, uint32_t apron) {
+  for (uint32_t f = 0; f < ProfileFrames; ++f) { app.OnUpdate(); app.OnRender(); }
+  rtggx_context* ctx = app.GetContext();
+  abi(rtggx_sync(ctx), "rtggx_sync");
+  const uint32_t W = app.GetWidth(), H = app.GetHeight();
+  std::vector<uint32_t> vis((size_t)W * H);
+  abi(rtggx_readback(ctx, RTGGX_BUF_VISIBILITY, vis.data(), vis.size() * 4), "rtggx_readback");
+  std::vector<double> cost(H);
+  for (uint32_t y = 0; y < H; ++y) {
+    uint32_t covered = 0;
+    for (uint32_t x = 0; x < W; ++x) covered += vis[(size_t)y * W + x] != 0u;
+    cost[y] = covered + SkyRowWeight * W;
+  }
+  return BalancedBounds(cost, world, apron);
+}
+
+static std::pair<uint32_t, uint32_t> takeStrip(RayTracedGGX& app, int rank, int world, const std::vector<uint32_t>& bounds, uint32_t apron) {
+  const auto rows = StripRows(app.GetHeight(), rank, world, &bounds);
+  if (rows.second - rows.first < apron) throw std::runtime_error("strips of " + std::to_string(rows.second - rows.first) + " rows are thinner than the " + std::to_string(apron) + "-row history apron");
+  abi(rtggx_set_strip(app.GetContext(), rows.first, rows.second), "rtggx_set_strip");
+  abi(rtggx_set_history_apron(app.GetContext(), apron), "rtggx_set_history_apron");
+  return rows;
+}
+
+static void dumpIfAsked(RayTracedGGX& app) {
+  if (app.GetDumpPrefix().empty()) return;
+  std::string name = app.GetDumpPrefix();
+  const bool hasExt = name.size() >= 4 && (name.compare(name.size() - 4, 4, ".png") == 0 || name.compare(name.size() - 4, 4, ".ppm") == 0);
+  if (!hasExt) name += ".ppm";
+  if (app.SaveImage(name.c_str())) std::printf("wrote %s\n", name.c_str());
+}
+
+int LaunchRanks(int world, int argc, char* argv[]) {
+  char idFile[64];
+  std::snprintf(idFile, sizeof idFile, "/tmp/rtggx_nccl_id_%d", (int)getpid());
+  std::remove(idFile);
+  bool hasDevice = false;
+  for (int i = 1; i < argc; ++i) if (!strcasecmp(argv[i] + 1, "device") && (argv[i][0] == '-' || argv[i][0] == '/')) hasDevice = true;
+  std::vector<pid_t> pids;
+  for (int r = 0; r < world; ++r) {
+    const pid_t pid = fork();
+    if (pid < 0) { std::perror("fork"); break; }
+    if (pid == 0) {      // the child has touched no GPU: it may become the rank
+      const std::string rank = std::to_string(r);
+      std::vector<char*> args(argv, argv + argc);
+      char fRank[] = "-rank", fId[] = "-idfile", fDev[] = "-device";
+      args.push_back(fRank); args.push_back(const_cast<char*>(rank.c_str()));
+      args.push_back(fId); args.push_back(idFile);
+      if (!hasDevice) { args.push_back(fDev); args.push_back(const_cast<char*>(rank.c_str())); }      // rank r drives GPU r
+      args.push_back(nullptr);
+      execv("/proc/self/exe", args.data());
+      std::perror("execv");
+      _exit(127);
+    }
+    pids.push_back(pid);
+  }
+  int worst = (int)pids.size() == world ? 0 : 1;
+  for (const pid_t pid : pids) {
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) worst = WIFEXITED(status) && WEXITSTATUS(status) ? WEXITSTATUS(status) : 1;
+  }
+  std::remove(idFile);
+  return worst;
+}
+
+int RunRank(RayTracedGGX& app, int rank, int world, const std::string& idFile, bool balance) {
+  app.OnInit();
+  rtggx_context* ctx = app.GetContext();
+  const std::vector<uint32_t> bounds = balance ? ProfileBounds(app, world) : std::vector<uint32_t>();
+  const auto rows = takeStrip(app, rank, world, bounds, HistoryApron);
+  Rccl rccl;
+  rccl.InitRank(rank, world, idFile);
+  void* stream = nullptr; abi(rtggx_get_stream(ctx, &stream), "rtggx_get_stream");
+  const std::vector<Op> plan = ExchangePlan(app.GetHeight(), rank, world, HistoryApron, &bounds);
+  std::vector<RawOp> raw[2]; bool have[2] = {false, false};      // the pointers depend on the history target only: built once per parity
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t f = 0; f < app.GetNumFrames(); ++f) {
+    app.OnUpdate(); app.OnRender();
+    uint32_t parity = 0; abi(rtggx_frame_parity(ctx, &parity), "rtggx_frame_parity");
+    if (!have[parity]) { raw[parity] = PlanToRaw(plan, app); have[parity] = true; }
+    rccl.Exchange(raw[parity], stream);
+  }
+  uint64_t rays = 0; abi(rtggx_ray_count(ctx, &rays), "rtggx_ray_count");      // synchronises
+  abi(rtggx_sync(ctx), "rtggx_sync");
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  uint32_t over = 0; abi(rtggx_history_overreach(ctx, &over, 1), "rtggx_history_overreach");
+  std::printf("rank %d of %d: rows [%u, %u), %u frames %ux%u: %.3f ms/frame, last frame %llu rays in its rows%s\n", rank, world, rows.first, rows.second, app.GetNumFrames(),
+              app.GetWidth(), app.GetHeight(), ms / app.GetNumFrames(), (unsigned long long)rays,
+              over ? (", history read " + std::to_string(over) + " rows beyond the exchanged apron: the strips differ from the single-GPU frame").c_str() : "");
+  if (rank == 0) dumpIfAsked(app);      // rank 0 holds the assembled frame
+  app.OnDestroy();
+  return 0;
+}
+
+int RunStripsInOneProcess(RayTracedGGX& first, int world, bool balance, int argc, char* argv[]) {
+  std::vector<std::unique_ptr<RayTracedGGX>> owned;
+  std::vector<RayTracedGGX*> apps{&first};
+  for (int r = 1; r < world; ++r) {
+    owned.emplace_back(new RayTracedGGX(first.GetWidth(), first.GetHeight(), "strip"));
+    owned.back()->ParseCommandLineArgs(argv, argc);
+    apps.push_back(owned.back().get());
+  }
+  for (RayTracedGGX* a : apps) a->OnInit();
+  std::vector<uint32_t> bounds;
+  if (balance) for (RayTracedGGX* a : apps) bounds = ProfileBounds(*a, world);      // every strip renders the profile frames as whole frames, like every rank would
+  std::vector<std::vector<Op>> plans;
+  for (int r = 0; r < world; ++r) { takeStrip(*apps[r], r, world, bounds, HistoryApron); plans.push_back(ExchangePlan(first.GetHeight(), r, world, HistoryApron, &bounds)); }
+  Rccl rccl;
+  rccl.InitRank(0, 1, "");
+  const auto syncAll = [&]() { for (RayTracedGGX* a : apps) abi(rtggx_sync(a->GetContext()), "rtggx_sync"); };
+  for (uint32_t f = 0; f < first.GetNumFrames(); ++f) {
+    for (RayTracedGGX* a : apps) { a->OnUpdate(); a->OnRender(); }
+    syncAll();
+    for (int r = 0; r < world; ++r) {      // every receive of strip r, paired with the send its peer's plan holds for it
+      std::vector<RawOp> ops;
+      for (const Op& o : plans[r]) if (!o.send) { ops.push_back(rawOp(o, *apps[o.peer], true, 0)); ops.push_back(rawOp(o, *apps[r], false, 0)); }
+      void* stream = nullptr; abi(rtggx_get_stream(apps[r]->GetContext(), &stream), "rtggx_get_stream");
+      rccl.Exchange(ops, stream);
+    }
+    syncAll();
+  }
+  uint64_t rays = 0, total = 0;
+  for (RayTracedGGX* a : apps) { abi(rtggx_ray_count(a->GetContext(), &rays), "rtggx_ray_count"); total += rays; }
+  std::printf("%d strips in one process, %u frames %ux%u, boundaries", world, first.GetNumFrames(), first.GetWidth(), first.GetHeight());
+  for (int r = 0; r <= world; ++r) std::printf(" %u", r < world ? StripRows(first.GetHeight(), r, world, &bounds).first : first.GetHeight());
+  std::printf(": last frame %llu rays\n", (unsigned long long)total);
+  dumpIfAsked(first);
+  for (RayTracedGGX* a : apps) a->OnDestroy();
+  return 0;
+}
+
+}  // namespace strips

@@ -941,6 +941,44 @@ def test_headless_executable_with_the_bat_file_arguments(built, tmp_path):
     assert r.returncode != 0 and "cannot import" in r.stderr
 
 
+def test_executable_strips_in_one_process_equal_the_single_frame(built, tmp_path):
+    """The C++ multi-GPU host (host/Strips.cpp; `-gpus N` restarts the executable once per GPU) in its single-process mode:
+    `-strips N` renders N strips with N contexts on the one GPU of the box and carries out every rank's exchange plan through real
+    ncclSend / ncclRecv (a one-rank communicator: across processes only the peer numbers differ).  The frame rank 0 assembles --
+    equal strips, and strips balanced by two profile frames -- is the single-context frame, byte for byte; the plan functions
+    agree with raytracedggx_amd/strips.py."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import imgdiff
+    from raytracedggx_amd import app
+    exe = os.path.join(os.path.dirname(os.path.abspath(app.HOST_LIB_PATH)), "RayTracedGGX")
+    bin_dir = assets.asset_dir()
+    common = ["-mesh", "Assets/bunny.obj", "-width", "640", "-height", "360", "-sharedmem", "-dt", "0.05"]
+    def run(extra, name):
+        shot = tmp_path / name
+        r = subprocess.run([exe] + common + extra + ["-dump", str(shot)], cwd=bin_dir, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return imgdiff.load(str(shot)), r.stdout
+    single5, _ = run(["-frames", "5"], "single5.png")
+    equal4, out = run(["-frames", "5", "-strips", "4", "-balance", "0"], "equal4.png")
+    assert "4 strips in one process" in out and "boundaries 0 90 180 270 360" in out
+    np.testing.assert_array_equal(equal4, single5)
+    single7, _ = run(["-frames", "7"], "single7.png")
+    balanced6, out = run(["-frames", "5", "-strips", "6"], "balanced6.png")      # + the two profile frames every strip renders whole
+    np.testing.assert_array_equal(balanced6, single7)
+    bounds = [int(x) for x in out.split("boundaries")[1].split(":")[0].split()]
+    assert len(bounds) == 7 and bounds[0] == 0 and bounds[-1] == 360 and bounds != [(r * 360) // 6 for r in range(7)]
+    # the same boundaries as the Python host cuts from the same profile
+    from raytracedggx_amd import capi
+    from raytracedggx_amd.strips import StripRenderer
+    s = StripRenderer(640, 360, assets.path("bunny.obj"), assets.path("rnl_cross.dds"), rank=0, world=6, transport=lambda *_: None, extra_args=("-sharedmem", "-dt", 0.05), balance=True)
+    try:
+        assert s.bounds == bounds
+    finally:
+        s.close()
+
+
 def test_history_apron_guard_reports_fast_motion(built, tmp_path):
     """SURVEY 8e "clamp and report": strips exchange HISTORY_APRON (18) rows of last frame's temporal result, enough for 16 px of
     vertical reprojection per frame.  An orbit drag (-track) moves the image faster: the temporal pass of a strip then reads

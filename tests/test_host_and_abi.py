@@ -116,11 +116,56 @@ def test_headless_executable_reports_missing_gpu(built):
     assert r.returncode != 0 and "no HIP device" in r.stderr
 
 
-def test_headless_executable_refuses_gpus_flag_with_instructions(built):
-    """-gpus N: the executable drives one GPU; N > 1 is the per-GPU-process strip path and the flag says so."""
+def test_headless_executable_gpus_flag_starts_one_process_per_gpu(built):
+    """-gpus N: the executable restarts itself once per GPU (host/Strips.cpp LaunchRanks) and returns the worst exit code.
+    Without a GPU every rank must fail loudly -- there is no CPU path -- and so must the launcher."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
     exe = os.path.join(ROOT, "raytracedggx_amd", "RayTracedGGX")
-    r = subprocess.run([exe, "-gpus", "8", "-mesh", assets.path("triangle.obj")], capture_output=True, text=True)
-    assert r.returncode == 1 and "one process per GPU" in r.stderr and "bench.py --gpus N" in r.stderr
+    r = subprocess.run([exe, "-gpus", "3", "-mesh", assets.path("triangle.obj"), "-env", assets.path("rnl_cross.dds"), "-width", "64", "-height", "64"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and r.stderr.count("no HIP device") >= 3, r.stderr
+    r = subprocess.run([exe, "-gpus", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "-gpus: 1 .. 64" in r.stderr
+
+
+def test_cpp_strip_plans_equal_the_python_ones(built):
+    """host/Strips.cpp (the executable's multi-GPU host) and raytracedggx_amd/strips.py (what bench.py drives) must cut the frame
+    and pair the transfers identically: exchange plans for every rank of 2..8 strips over equal and uneven boundaries, balanced
+    boundaries from random and from degenerate row costs, and the errors for frames too small to hold the strips."""
+    import ctypes as C
+    from raytracedggx_amd import app, strips
+    L = app.load()
+    L.rtggx_host_exchange_plan.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    L.rtggx_host_balanced_bounds.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(5)
+    def cpp_plan(H, rank, world, apron, bounds):
+        ops = np.zeros((64, 5), np.int32)
+        b = None if bounds is None else np.asarray(bounds, np.uint32)
+        n = L.rtggx_host_exchange_plan(H, rank, world, apron, None if b is None else b.ctypes.data, ops.ctypes.data, 64)
+        assert n >= 0
+        return [("send" if o[0] else "recv", "history" if o[1] else "backbuffer", int(o[2]), int(o[3]), int(o[4])) for o in ops[:n]]
+    for H in (272, 1080, 2160):
+        for world in range(2, 9):
+            cost = rng.random(H) * 100 + 1
+            want = strips.balanced_bounds(cost, world)
+            got = np.zeros(world + 1, np.uint32)
+            assert L.rtggx_host_balanced_bounds(cost.ctypes.data, H, world, strips.HISTORY_APRON, got.ctypes.data) == 0
+            assert got.tolist() == want
+            for bounds in (None, want):
+                for apron in (strips.HISTORY_APRON, 30):
+                    if any(b1 - b0 < apron for b0, b1 in zip(want[:-1], want[1:])) and bounds is not None:
+                        continue
+                    for rank in range(world):
+                        assert cpp_plan(H, rank, world, apron, bounds) == strips.exchange_plan(H, rank, world, apron=apron, bounds=bounds)
+    # all the cost in one row: the minimum strip height decides
+    cost = np.zeros(360); cost[200] = 1.0
+    got = np.zeros(7, np.uint32)
+    assert L.rtggx_host_balanced_bounds(cost.ctypes.data, 360, 6, 18, got.ctypes.data) == 0 and got.tolist() == strips.balanced_bounds(cost, 6)
+    assert L.rtggx_host_balanced_bounds(cost.ctypes.data, 100, 6, 18, got.ctypes.data) == -1 and b"cannot hold" in L.rtggx_app_last_error()
+    with pytest.raises(ValueError):
+        strips.balanced_bounds(cost[:100], 6)
 
 
 def test_png_writer_and_image_diff_tool(built, tmp_path):
