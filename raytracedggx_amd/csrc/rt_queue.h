@@ -24,7 +24,8 @@ namespace rt {
 // (2400 -> 3200): every extra wave of a split bin is wave-slot time the other two stages want.  The trace kernel alone gets slower
 // (0.120 -> 0.134 ms), the frame faster (0.2207 -> 0.2119 ms; dragon -5 %, 4K -3 %).
 #ifndef RT_SPLIT_FRONT
-#define RT_WIDE_RAYS 200000u     // launches with fewer rays than this: single-wave workgroups, two traversals in flight (trace.hip, capi.hip)
+#define RT_WIDE_RAYS 200000u     // launches with fewer rays than this: two traversals in flight (capi.hip rtggx_ray_trace)
+#define RT_TINY_RAYS 40000u      // ... and with fewer than this: single-wave workgroups, one per item (trace.hip launchTrace)
 #define RT_SPLIT_FRONT 300u  // above this a bin goes on the list: the launch starts with the listed bins
 #endif
 #ifndef RT_SPLIT_WORK

@@ -443,7 +443,7 @@ static void steerTraceWaves(rtggx_context* c, const unsigned long long* stamps, 
   c->traceShare = (float)dSum / (float)dStart;
   static const bool log = getenv("RTGGX_TRACE_LOG") != nullptr;
   if (log) fprintf(stderr, "[rtggx] trace sample at launch %u: %u launches, period %.1f us, share %.3f, waves %u, trial %u (base %.1f us), cooldown %u\n", launch, launches, period * 0.01f, c->traceShare, c->traceWaves, c->traceTrial, c->traceTrialBase * 0.01f, c->traceCooldown);
-  if (c->traceWavesForced) return;
+  if (c->traceWavesForced || c->lastTraceSmall) { c->traceTrial = 0u; return; }      // (two launches in flight: their stamps overlap)
   if (c->traceTrial != 0u) {
     if (++c->traceTrial == 2u) return;                 // the first sample after the change mixes both sizes (frames in flight)
     if (period < 0.97f * c->traceTrialBase) c->traceCooldown = 8u;                       // the new size stays
@@ -510,12 +510,15 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   static const bool noTop = getenv("RTGGX_TRACE_NO_TOP") && atoi(getenv("RTGGX_TRACE_NO_TOP")) != 0;      // measurement: every node from global memory
   if (noTop) T.topCount0 = T.topCount1 = 0u;
   if (T.topCount0 > RT_TOP_SLOT0 || T.topCount1 > RT_TOP_SLOT1) { setError("launchTrace: tree tables of %u / %u nodes exceed the LDS slots", T.topCount0, T.topCount1); return -1; }
-  // Which variant.  A full-size launch gets ONE workgroup of traceWaves (12, see steerTraceWaves) waves per CU: see the kernel.  A launch with few rays
-  // (a small frame, a thin strip: sliceShift > 0) lasts as long as its longest chain of dependent steps; it is alone on the chip for
-  // most of that time and wants every wave slot at once: single-wave workgroups without the table, one per item, as in round 1
-  // (0.058 ms for a 1920x171 frame against 0.064 with 3 x 8 resident waves and 0.066 with 16; profiles/r02_j_resident_trace.txt).
+  // Which variant.  A launch of a frame gets ONE workgroup of traceWaves (12, see steerTraceWaves) waves per CU: see the kernel.
+  // Below RT_WIDE_RAYS rays two such launches are in flight (capi.hip rtggx_ray_trace).  A launch with fewer than RT_TINY_RAYS rays
+  // lasts as long as its longest chain of dependent steps and wants every wave slot at once: single-wave workgroups without the
+  // table, one per item, as in round 1 (256x144, 9 000 rays: 0.050 ms per frame against 0.063; 1920x171, 13 000 rays: 0.063 against
+  // 0.071; from 40 000 rays on the resident workgroups are as fast or faster -- a strip of the 1080p frame with 70 000-150 000 rays:
+  // 0.076 / 0.087 ms for the slowest of 8 / 4 strips against 0.082 / 0.092; profiles/r02_j_resident_trace.txt section 5).
   static const int forced = getenv("RTGGX_TRACE_WAVES") ? atoi(getenv("RTGGX_TRACE_WAVES")) : 0;      // measurement: 1, 10, 12, 14, 16
-  const uint32_t waves = forced ? (uint32_t)forced : (sliceShift > 0u || !countRays || c->lastTraceSmall) ? 1u : c->traceWaves;
+  static const uint32_t tinyRays = getenv("RTGGX_TINY_RAYS") ? (uint32_t)atoi(getenv("RTGGX_TINY_RAYS")) : RT_TINY_RAYS;
+  const uint32_t waves = forced ? (uint32_t)forced : (!countRays || c->lastFrameRays < tinyRays) ? 1u : c->traceWaves;
   const uint32_t perCu = waves == 1u ? 0x10000u : 1u;      // single-wave workgroups: one per item, the dispatcher deals them
   if (waves == 1u) T.topCount0 = T.topCount1 = 0u;
   T.stamps = waves == 1u ? nullptr : c->traceStamps; T.launch = c->traceStampLaunch++;      // (thousands of workgroups stamping one word would take longer than the launch)

@@ -103,7 +103,9 @@ def run_exchange(dist, plan, buffers, ops=None):
 
 class StripRenderer:
     PROFILE_FRAMES = 2         # full frames every rank renders first when it balances the strips itself
-    SKY_ROW_WEIGHT = 0.3       # cost of a row = covered pixels + this x width (rows without a surface are not free); 0.05 .. 0.6 tried
+    # cost of a row = covered pixels + this x width (rows without a surface are not free).  0.3 until the traversal got cheaper relative to
+    # the per-pixel passes; 0.5 now: slowest of 8 strips at 4K 0.158 -> 0.145 ms, of 4 at 1080p 0.089 -> 0.085 (profiles/r02_n_strip_projection.txt)
+    SKY_ROW_WEIGHT = float(os.environ.get("RTGGX_SKY_ROW_WEIGHT", 0.5))
 
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
                  transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON):
