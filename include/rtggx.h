@@ -144,6 +144,10 @@ int  rtggx_set_stream(rtggx_context* ctx, void* hip_stream);
 /* The context's main stream (its own, or the one handed in): what a host enqueues there -- the per-frame RCCL exchange of the
  * multi-GPU host, host/Strips.cpp -- is ordered behind the frame's tone map and before the next frame's temporal pass. */
 int  rtggx_get_stream(rtggx_context* ctx, void** hip_stream);
+/* Ordering of the back buffer.  A context left to itself may run a frame's tone map beside the NEXT frame's filters on another
+ * stream (DESIGN.md "The frame on the device"): the back buffer is complete after rtggx_sync / rtggx_readback.  A caller that consumes
+ * it by other means says so by calling rtggx_set_stream, rtggx_get_stream or rtggx_buffer_ptr(RTGGX_BUF_BACKBUFFER | TSS*): from then
+ * on every kernel whose output it may read runs on the main stream, in order. */
 
 /* The sample's asynchronous-compute toggle (m_asyncCompute, key [A]: RayTracedGGX.cpp:304-353 issues the frame over two
  * queues, :513-556 as one command list).  enable = 0: every pass is issued to the main stream in submission order (no

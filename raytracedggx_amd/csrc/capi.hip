@@ -68,7 +68,15 @@ static void invert4x4(const float* a /*row-major*/, float* out) {
 }
 
 static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
+// A tone map that rtggx_tone_map has put aside for the next frame (see there) and no next frame has claimed: on the main stream, now.
+#define RT_TONE_ASIDE_PIXELS (2560ull * 1440ull)
+static void flushToneMap(rtggx_context* c) {
+  if (!c->tonePending) return;
+  c->tonePending = false;
+  launchPreparedToneMap(c, c->tonePrepared, c->streamMain, nullptr);
+}
 static hipError_t syncStreams(rtggx_context* c) {
+  flushToneMap(c);      // whoever waits for the streams wants the back buffer complete
   hipError_t e = c->ownVis ? hipStreamSynchronize(c->ownVis) : hipSuccess;
   if (e == hipSuccess && c->streamRefit) e = hipStreamSynchronize(c->streamRefit);
   if (e == hipSuccess) e = hipStreamSynchronize(c->ownAS);
@@ -179,6 +187,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : c->evTone) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
   for (int i = 0; i < RT_SETS; ++i) {
     RT_HIP(hipMalloc(&c->visDepthBuf[i], n * 8)); RT_HIP(hipMemset(c->visDepthBuf[i], 0, n * 8));
@@ -251,6 +260,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
 
 void rtggx_destroy(rtggx_context* c) {
   if (!c) return;
+  if (getenv("RTGGX_TRACE_LOG")) fprintf(stderr, "[rtggx] tone maps put aside: %u, launched beside the next frame: %u\n", c->toneAsideCount, c->toneBesideCount);
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (auto& m : c->mesh) {
@@ -268,7 +278,7 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
-  hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
+  hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e); for (auto e : c->evTone) hipEventDestroy(e);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->ownAS); if (c->ownVis) hipStreamDestroy(c->ownVis);
   hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit); hipEventDestroy(c->evGen); for (auto e : c->evTraceRing) hipEventDestroy(e);
   if (c->streamRefit) hipStreamDestroy(c->streamRefit);
@@ -308,7 +318,13 @@ int rtggx_set_stream(rtggx_context* c, void* stream) {
   return 0;
 }
 
-int rtggx_get_stream(rtggx_context* c, void** stream) { RT_CHECK_CTX(c); if (!stream) { setError("rtggx_get_stream: null"); return -1; } *stream = (void*)c->streamMain; return 0; }
+int rtggx_get_stream(rtggx_context* c, void** stream) {
+  RT_CHECK_CTX(c);
+  if (!stream) { setError("rtggx_get_stream: null"); return -1; }
+  flushToneMap(c); c->callerOrdersOnMain = true;      // the caller will order work of its own behind the frame on this stream: the tone map stays on it from now on
+  *stream = (void*)c->streamMain;
+  return 0;
+}
 
 // The sample's [A] toggle / m_asyncCompute (RayTracedGGX.cpp:304-353 vs the single command list of :513-556).  Off: every
 // pass of a frame is issued to ONE stream in submission order -- no stream B, no stream C, no overlap between the
@@ -523,6 +539,7 @@ int rtggx_render_visibility(rtggx_context* c) {
   if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
   if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamAS); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
   ++c->frameCounter;
+  c->denoiseIssued = false;
   c->selectSet((c->setIndex + 1u) % RT_SETS);
   // the set was last read three frames ago: normally long done; a host that has run further ahead than that waits here
   static const bool gpuSideWait = getenv("RTGGX_SET_WAIT_ON_GPU") != nullptr;      // the cross-queue wait instead (measurement)
@@ -600,6 +617,15 @@ int rtggx_ray_trace(rtggx_context* c) {
   // from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
   if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain, c->evSetRead[c->setIndex]);
   c->setReadRecorded[c->setIndex] = true;
+  if (c->tonePending) {      // the previous frame's tone map: beside this frame's filters (rtggx_tone_map)
+    if (c->attachEvents && c->streamRefit != nullptr && !(c->mesh[0].deforming || c->mesh[1].deforming) && !alternate && c->streamMain == c->ownMain) {
+      c->tonePending = false;
+      RT_HIP(hipStreamWaitEvent(c->streamRefit, c->evSetRead[c->setIndex], 0));      // completes with the shading kernel just launched
+      const int rt2 = launchPreparedToneMap(c, c->tonePrepared, c->streamRefit, c->evTone[c->toneParity]);
+      if (rt2) return rt2;
+      c->toneRecorded[c->toneParity] = true; ++c->toneBesideCount;
+    } else flushToneMap(c);
+  }
   if (c->timing) hipEventRecord(c->tev[14], c->streamMain);
   return r;
 }
@@ -608,6 +634,10 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_denoise: no frame constants"); return -1; }
   if (c->timing) hipEventRecord(c->tev[9], c->streamMain);   // start of denoise
+  { const uint32_t p = (c->frameParity ^ 1u) & 1u;      // the image this frame's temporal pass writes: a tone map on the refit stream may still be reading it
+    if (c->tonePending && c->toneParity == p) flushToneMap(c);
+    if (c->toneRecorded[p]) { RT_HIP(hipStreamWaitEvent(c->streamMain, c->evTone[p], 0)); c->toneRecorded[p] = false; } }
+  c->denoiseIssued = true;
   const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, c->evSetRead[c->setIndex]);
   c->setReadRecorded[c->setIndex] = true;
   return r;
@@ -616,7 +646,25 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
 int rtggx_tone_map(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_tone_map: no frame constants"); return -1; }
-  const int r = launchToneMap(c, c->slots[c->slot], c->streamMain);
+  // The tone map of a full-size frame does not run at the end of the main stream's chain (shading, filters, temporal pass: the chain
+  // the frame waits for) but beside the NEXT frame's filters, on the refit stream: it needs the temporal pass's result only, moves
+  // many bytes with little arithmetic, and the horizontal filter it then overlaps does the opposite.  It is prepared here and
+  // launched by the next rtggx_ray_trace behind that frame's shading kernel (waitable: the kernel carries evSetRead); whoever
+  // synchronises first (rtggx_sync, a read-back, ...) gets it on the main stream at once (flushToneMap).  The temporal pass two
+  // frames on overwrites the image it reads: rtggx_denoise makes the main stream wait for evTone.  Strips, small launches, deforming
+  // meshes (the refit stream is busy), a caller-owned main stream and the timing modes keep the tone map where it was; so do frames
+  // where it does not pay: while the traversal, not the main stream, is the longest stage (its share of the period above 0.92 until it
+  // falls below 0.85: trace.hip steerTraceWaves), and at 4K, where every stage moves four times the bytes (bunny 1080p 0.197 -> 0.189
+  // or 0.196 ms -- two stable states, a run falls into one --, with diffuse rays 0.304 -> 0.296; dragon 0.222 -> 0.225, dragon with
+  // diffuse rays 0.357 -> 0.387 and bunny 4K 0.696 -> 0.702 if it were used there: profiles/r02_c_ab_pipeline.txt block 9).
+  flushToneMap(c);
+  static const bool toneAside = !(getenv("RTGGX_TONEMAP_ASIDE") && atoi(getenv("RTGGX_TONEMAP_ASIDE")) == 0);
+  const FrameParams& fp = c->slots[c->slot];
+  const bool aside = toneAside && !c->callerOrdersOnMain && c->toneAsideAllowed && c->pipeline != 0 && c->asyncCompute && c->attachEvents && c->streamMain == c->ownMain && c->streamRefit != nullptr && !c->timing
+                     && !(c->mesh[0].deforming || c->mesh[1].deforming) && !c->lastTraceSmall && fp.rowBegin == 0u && fp.rowEnd == fp.H && c->denoiseIssued
+                     && (uint64_t)fp.W * fp.H <= RT_TONE_ASIDE_PIXELS;
+  if (aside && prepareToneMap(c, fp, &c->tonePrepared)) { c->tonePending = true; c->toneParity = c->frameParity & 1u; ++c->toneAsideCount; return 0; }
+  const int r = launchToneMap(c, fp, c->streamMain);
   if (c->timing) { hipEventRecord(c->tev[10], c->streamMain); c->timingsPending = true; }
   return r;
 }
@@ -749,6 +797,7 @@ int rtggx_buffer_ptr(rtggx_context* c, int id, void** dptr) {
   if (r) return r;
   if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) *dptr = c->visDepth;   // packed u64: (depth << 32) | visibility
   if (!*dptr) { setError("buffer %d has no device storage", id); return -1; }
+  if (id == RTGGX_BUF_BACKBUFFER || id == RTGGX_BUF_TSS0 || id == RTGGX_BUF_TSS1) { flushToneMap(c); c->callerOrdersOnMain = true; }      // a consumer outside the library: see rtggx_get_stream
   return 0;
 }
 

@@ -16,6 +16,7 @@
 // exponentials merged into one exp2 -- ~35 VALU instructions per tap instead of ~400 with libm calls.  The passes
 // are VALU-bound (33 taps per covered pixel); their HBM traffic (22-30 B/pixel/pass) is ~5% of the
 // time.  Out-of-range texels are the zeros D3D returns.
+#include <cstring>
 #include <hip/hip_ext.h>
 #include "rtggx_context.h"
 
@@ -518,13 +519,28 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
   return 0;
 }
 
-int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
-  if (fp.rowEnd <= fp.rowBegin) return 0;
+// The tone map of a frame, prepared (prepareToneMap: everything the kernel needs, by value) and launched (launchPreparedToneMap) in
+// two steps: capi.hip may launch it later and elsewhere than where rtggx_tone_map was called.
+bool prepareToneMap(rtggx_context* c, const FrameParams& fp, PreparedToneMap* out) {
+  if (fp.rowEnd <= fp.rowBegin) return false;
+  static_assert(sizeof(Targets) <= sizeof(out->targets), "PreparedToneMap::targets too small");
   const Targets T = makeTargets(c, fp, ROWS_FINAL);
-  const dim3 grid((fp.W + 63) / 64, (T.rowEnd - T.rowBegin + RT_TM_ROWS - 1) / RT_TM_ROWS), block(256);
-  hipLaunchKernelGGL(toneMapKernel, grid, block, 0, s, T);
+  std::memcpy(out->targets, &T, sizeof T);
+  out->gridX = (fp.W + 63) / 64; out->gridY = (uint32_t)(T.rowEnd - T.rowBegin + RT_TM_ROWS - 1) / RT_TM_ROWS;
+  return true;
+}
+int launchPreparedToneMap(rtggx_context* c, const PreparedToneMap& p, hipStream_t s, hipEvent_t done) {
+  Targets T; std::memcpy(&T, p.targets, sizeof T);
+  const dim3 grid(p.gridX, p.gridY), block(256);
+  if (done && c->attachEvents) hipExtLaunchKernelGGL(toneMapKernel, grid, block, 0, s, nullptr, done, 0, T);
+  else { hipLaunchKernelGGL(toneMapKernel, grid, block, 0, s, T); if (done) RT_HIP(hipEventRecord(done, s)); }
   RT_HIP(hipGetLastError());
   return 0;
+}
+int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
+  PreparedToneMap p;
+  if (!prepareToneMap(c, fp, &p)) return 0;
+  return launchPreparedToneMap(c, p, s, nullptr);
 }
 
 }  // namespace rt

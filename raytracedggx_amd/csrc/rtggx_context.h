@@ -109,6 +109,8 @@ struct Scene {
 
 }  // namespace rt
 
+namespace rt { struct PreparedToneMap { alignas(16) unsigned char targets[192]; uint32_t gridX, gridY; }; }      // a tone map ready to launch (denoise.hip)
+
 struct rtggx_context {
   int device = 0;
   uint32_t W = 0, H = 0;
@@ -139,6 +141,9 @@ struct rtggx_context {
   hipEvent_t evRefit = nullptr;   // vertices of the current set uploaded and the tree refitted (stream B -> stream C)
   hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
   bool setReadRecorded[RT_SETS] = {};
+  // a tone map that waits to be launched beside the NEXT frame's filters (capi.hip rtggx_tone_map), and the events of those launched that way
+  bool tonePending = false, denoiseIssued = false, callerOrdersOnMain = false, toneAsideAllowed = true; rt::PreparedToneMap tonePrepared; uint32_t toneParity = 0;
+  hipEvent_t evTone[2] = {}; bool toneRecorded[2] = {}; uint32_t toneAsideCount = 0, toneBesideCount = 0;
   bool fltRflIsFltDff = false;          // the last denoise ran without diffuse passes: FilteredOut == FilteredOut1 and only the latter was written
   bool externalStream = false;
 
@@ -271,6 +276,8 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
 int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s);
 int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done = nullptr);
 int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s);
+bool prepareToneMap(rtggx_context* c, const FrameParams& fp, PreparedToneMap* out);      // false: nothing to do (empty strip)
+int launchPreparedToneMap(rtggx_context* c, const PreparedToneMap& p, hipStream_t s, hipEvent_t done);
 int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* hostData, size_t bytes, hipStream_t s);
 int projectSH(rtggx_context* c, hipStream_t s);
 int unpackVisDepth(rtggx_context* c, uint32_t* dVis, uint32_t* dDepth, hipStream_t s);

@@ -441,6 +441,8 @@ static void steerTraceWaves(rtggx_context* c, const unsigned long long* stamps, 
   if (!usable) { c->traceTrial = 0u; return; }
   const float period = (float)dStart / (float)launches;
   c->traceShare = (float)dSum / (float)dStart;
+  // the tone map beside the next frame's filters (capi.hip rtggx_tone_map) pays while the main stream is the longest stage, not the traversal
+  if (c->traceShare > 0.92f) c->toneAsideAllowed = false; else if (c->traceShare < 0.85f) c->toneAsideAllowed = true;
   static const bool log = getenv("RTGGX_TRACE_LOG") != nullptr;
   if (log) fprintf(stderr, "[rtggx] trace sample at launch %u: %u launches, period %.1f us, share %.3f, waves %u, trial %u (base %.1f us), cooldown %u\n", launch, launches, period * 0.01f, c->traceShare, c->traceWaves, c->traceTrial, c->traceTrialBase * 0.01f, c->traceCooldown);
   if (c->traceWavesForced || c->lastTraceSmall) { c->traceTrial = 0u; return; }      // (two launches in flight: their stamps overlap)
