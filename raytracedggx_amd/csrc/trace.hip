@@ -425,11 +425,11 @@ __global__ void stampKernel(uint32_t* stats) { *reinterpret_cast<unsigned long l
 // with 14; profiles/r02_j_resident_trace.txt).  The kernel stamps its own start and end and keeps a running sum of its durations;
 // with the ray counters (every 16th frame) the host gets, for the launches since the last sample, the PERIOD between launches and
 // the SHARE of it the traversal ran.  The share alone does not tell the workloads apart that gain from more waves from those that
-// lose (0.92 against 0.88-0.91), so the size is tried: with a share above RT_WAVES_TRY two more waves for two samples; they stay if
+// lose (0.92 against 0.88-0.91), so the size is tried: with a share above RT_WAVES_TRY (0.90) two more waves for two samples; they stay if
 // the period fell by 3 %, else the old size returns and the next trial waits RT_WAVES_RETRY samples (the workload drifts: a turning
 // model changes the period by 30 % over a few hundred frames).  A share below RT_WAVES_SHRINK
 // takes two waves away again (down to 12).  Results never depend on any of this.
-#define RT_WAVES_TRY 0.88f
+#define RT_WAVES_TRY 0.90f
 #define RT_WAVES_SHRINK 0.70f
 #define RT_WAVES_RETRY 16u
 static void steerTraceWaves(rtggx_context* c, const unsigned long long* stamps, uint32_t launch) {
