@@ -866,6 +866,39 @@ def test_trace_workgroup_size_changes_nothing(built):
             a.OnDestroy()
 
 
+def test_tone_map_beside_the_next_frame_equals_the_one_on_the_main_stream(built):
+    """A full-size static frame's tone map is launched by the NEXT frame's rtggx_ray_trace on the refit stream, beside that frame's
+    filters (capi.hip rtggx_tone_map); a synchronisation flushes a pending one onto the main stream instead.  Twelve free-running
+    frames, then only the first half of a thirteenth (update, visibility, ray trace: that launches the twelfth's tone map the
+    deferred way and nothing afterwards touches the back buffer) -- against twelve frames synchronised one by one, whose tone maps
+    all ran on the main stream.  Then the contract for callers with work of their own: after rtggx_get_stream nothing is deferred."""
+    from raytracedggx_amd import app, capi
+    args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 1920, "-height", 1080, "-sharedmem"]
+    a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+    try:
+        for f in range(12):
+            a.OnUpdate(); a.OnRender(); a.context.sync()
+            b.OnUpdate(); b.OnRender()
+        b.OnUpdate()
+        c = b.context
+        c.update_as(); c.render_visibility(); c.ray_trace()
+        c.sync()
+        for bid in (capi.BUF_BACKBUFFER, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_FLT_DFF):
+            np.testing.assert_array_equal(a.context.readback(bid), c.readback(bid), err_msg="buffer %d" % bid)
+        # finish the thirteenth frame, hand the stream out, render on: still the same frames
+        c.denoise(True); c.tone_map()
+        a.OnUpdate(); a.OnRender(); a.context.sync()
+        assert c.stream() != 0
+        for f in range(6):
+            a.OnUpdate(); a.OnRender(); a.context.sync()
+            b.OnUpdate(); b.OnRender()
+        c.sync()
+        for bid in (capi.BUF_BACKBUFFER, capi.BUF_TSS0, capi.BUF_TSS1):
+            np.testing.assert_array_equal(a.context.readback(bid), c.readback(bid), err_msg="after rtggx_get_stream, buffer %d" % bid)
+    finally:
+        a.OnDestroy(); b.OnDestroy()
+
+
 def test_update_as_after_render_visibility(built):
     """The C ABI allows rtggx_update_as after rtggx_render_visibility of the same frame (the sample overlaps the two on its two
     queues, RayTracedGGX.cpp:304-339): the visibility pass has then carried the slot to the device with the previous frame's TLAS,
