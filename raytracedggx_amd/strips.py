@@ -222,9 +222,10 @@ class StripRenderer:
         return max(self.b - 18, 0), min(self.e + 18, self.H)
 
     def trace_kernel_algorithmic_bytes(self, rays_per_launch):
-        """DESIGN.md "Roofline": what one launch of traceKernel has to move if every byte moved once -- a 64-byte ray
-        record in and an 8-byte hit key out per ray, plus the acceleration structure once (the 4-wide nodes in use
-        and the leaf triangles of both instances)."""
+        """DESIGN.md "Roofline": what one launch of traceKernel has to move if every byte moved once, by SURVEY.md 8(d)'s
+        per-ray figure -- a 64-byte ray record in and an 8-byte hit key out -- plus the acceleration structure once (the
+        4-wide nodes in use and the leaf triangles of both instances).  The yardstick stays fixed; the kernel itself has
+        read 32 bytes of a 48-byte record per ray since round 2 (csrc/rt_queue.h)."""
         return 72 * rays_per_launch + self.bvh_bytes()
 
     def bvh_bytes(self):
