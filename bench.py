@@ -178,8 +178,7 @@ def main():
                           + (("-deform", args.deform) if args.deform else ()))
         ctx = r.context
         device = "cuda"
-        # the box's attainable HBM bandwidth (float4 copy, 2 x 1 GiB): quoted beside the vendor peak
-        peak_measured = ctx.copy_bandwidth(1 << 30, 6) if rank == 0 else None
+        peak_measured = None
 
         def barrier():
             if world > 1:
@@ -195,6 +194,15 @@ def main():
         ctx.trace_residency(args.trace_waves)
     for _ in range(0 if args.stub else args.prime_frames):
         r.frame()
+    if not args.stub:
+        # the box's attainable HBM bandwidth, quoted beside the vendor peak: a float4 copy kernel, 2 x 1 GiB per launch, 128 launches
+        # (>= 50 ms) AFTER the priming frames -- i.e. with the compute clock ramped like the timed region's (round 2 measured 8 launches
+        # right after set-up, inside the clock ramp, and read 4.6 TB/s)
+        if rank == 0:
+            ctx.sync()
+            peak_measured = ctx.copy_bandwidth(1 << 30, 128)
+        for _ in range(16):       # (the copy evicted everything: a few frames to refill the caches before the warm-up steps)
+            r.frame()
     for _ in range(args.warmup):
         r.frame()
     if not args.stub:
@@ -243,12 +251,15 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
     kernel_ms = r.ray_kernel_ms_since_reset()
     rows = r.strip_rows_with_apron()
     rays_per_launch = own_rays / max(args.steps, 1)     # rays of this rank's strip (apron rays of a strip are not counted)
-    alg_bytes = r.trace_kernel_algorithmic_bytes(rays_per_launch)
-    frame_bytes = r.frame_algorithmic_bytes(rows, metallic_lt_1=bool(args.metallic) and min(args.metallic) < 1.0)
+    alg_bytes = r.trace_kernel_algorithmic_bytes(rays_per_launch)              # 40 B per ray (32 read + 8-byte key) + the tree once
+    alg_bytes_r01 = r.trace_kernel_algorithmic_bytes(rays_per_launch, per_ray=72)   # round 1's yardstick (64-byte record), for continuity
+    diffuse = bool(args.metallic) and min(args.metallic) < 1.0
+    frame_bytes = r.frame_algorithmic_bytes(rows, metallic_lt_1=diffuse)                      # the passes this frame launches
+    frame_bytes_survey = r.frame_algorithmic_bytes(rows, metallic_lt_1=diffuse, survey=True)  # 146 B/px, incl. the diffuse passes an all-metal frame skips
     k_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
     # HBM bytes per launch from hardware counters: collected in separate rocprofv3 --pmc runs of this same workload
     # (tools/pmc.sh), committed under profiles/; null for other workloads
-    traffic, traffic_source, valu, pmc_name = None, None, None, None
+    traffic, traffic_source, valu, pmc_name, l1 = None, None, None, None, None
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if tfiles and (W, H, args.mesh, world, args.metallic, args.deform) == (1920, 1080, "bunny.obj", 1, None, 0.0):
         with open(tfiles[-1]) as f:
@@ -256,6 +267,7 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
         pmc_name = os.path.basename(tfiles[-1])
         traffic = pmc["kernels"].get("rt::traceKernel", {}).get("traffic_bytes")
         valu = pmc.get("valu_instructions_per_frame")
+        l1 = pmc.get("trace_kernel_l1")      # vector-L1 requests of the trace kernel per CU and cycle (tools/make_profiles.sh)
         traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)" % pmc_name
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms == k_ms and k_ms > 0 else None
     # The same kernel with nothing beside it (after the timed region: 32 frames issued to ONE stream, rtggx_set_async_compute(0)): in the
@@ -284,17 +296,21 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
                    "trace_workgroup_waves": None if residency is None else residency[0], "trace_share_of_period": None if residency is None else round(residency[1], 3)},
         "roofline": {"bound": "hbm", "kernel": "rt::traceKernel", "achieved": None if achieved is None else round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "algorithmic_bytes_per_ray": 40, "algorithmic_bytes_r01": int(alg_bytes_r01), "l1_requests": l1, "kernel_ms": round(k_ms, 4),
                      "kernel_ms_alone": None if k_alone != k_alone else round(k_alone, 4),
                      "frac_alone": None if k_alone != k_alone else round(alg_bytes / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "peak_measured": None if peak_measured is None else round(peak_measured, 1),
-                     "peak_measured_how": "float4 copy kernel, 2 x 1 GiB, read + written bytes (rtggx_copy_bandwidth) on this box, before the warm-up",
+                     "peak_measured_how": "float4 copy kernel, 2 x 1 GiB per launch, 128 launches (>= 50 ms), read + written bytes (rtggx_copy_bandwidth), on this box after the set-up priming frames",
                      "note": "traversal is a dependent gather from an L2-resident tree, not a stream: the fraction is reported because the contract asks for it. "
                              "kernel_ms is the duration DURING the timed region, beside two other pipeline stages and at low stream priority (the frame is bound by "
                              "wave-slot time, so the launch is tuned for few wave-cycles, not for its own duration); kernel_ms_alone is the same launch with the chip to "
                              "itself. DESIGN.md 'Roofline accounting', profiles/r02_d_limiter.txt",
-                     "frame": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5),
-                               "frac_of_measured_peak": None if not peak_measured else round(frame_gbs / peak_measured, 5)}},
+                     "frame": {"algorithmic_bytes": int(frame_bytes), "bytes_per_pixel": 178 if diffuse else 118, "achieved": round(frame_gbs, 2), "frac": round(frame_gbs / HBM_PEAK_GBS, 5),
+                               "frac_of_measured_peak": None if not peak_measured else round(frame_gbs / peak_measured, 5),
+                               "algorithmic_bytes_survey": int(frame_bytes_survey), "bytes_per_pixel_survey": 178 if diffuse else 146,
+                               "frac_survey": round(frame_bytes_survey / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                               "note": "algorithmic_bytes counts the passes this frame LAUNCHES (all-metal: the two diffuse filter passes, 28 B/px of SURVEY 8(d)'s 146, are skipped); *_survey is SURVEY's sum"}},
         # one EXTRA, fully instrumented frame after the timed region: an event before and after every pass.  These are per-pass
         # latencies of a single frame with nothing overlapping it (queueing included) -- not the throughput figures above.
         "instrumented_frame_ms": dict(r.last_timings(), note="one extra frame with events around every pass, nothing overlapped: latencies, not throughput; 'frame' = first pass start to tone map end"),

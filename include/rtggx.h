@@ -163,18 +163,25 @@ int  rtggx_set_env(rtggx_context* ctx, int format, uint32_t size, uint32_t mips,
 int  rtggx_set_material(rtggx_context* ctx, uint32_t mesh, const float base_color[4], float roughness, float metallic);
 int  rtggx_set_metallic(rtggx_context* ctx, uint32_t mesh, float metallic);
 
-/* LBVH build of both bottom-level structures on the context's build stream. */
+/* Build of both bottom-level structures (RayTracer::buildAccelerationStructures / BuildAccelerationStructures, RayTracer.cpp:676-716,
+ * 158-233; the sample records the builds on the GPU timeline and waits once, RayTracedGGX.cpp:236): every step of the build --
+ * Morton codes, sort, PLOC clustering, the refit schedule, the node arrays -- is a kernel launch on the context's build stream
+ * with no host round trip between them; the call waits once, at the end. */
 int  rtggx_build_as(rtggx_context* ctx);
 
 /* Deforming mesh: `num_verts` new vertices (same layout, same count, same indices as the last rtggx_set_mesh) for mesh `slot`.
  * Replaces, for shape changes, what RayTracer::UpdateAccelerationStructure (RayTracer.cpp:326-341) does for the rigid instance
- * motion of the sample: the acceleration structure follows the new positions WITHOUT a rebuild and without a synchronisation.
+ * motion of the sample: the acceleration structure follows the new positions without a synchronisation.
  * The vertices are copied (staged) before the call returns; the upload, the new leaf triangles and the bottom-up box refit of
- * the existing tree run on the context's stream B at the start of the next frame (rtggx_render_visibility), overlapping the
- * previous frame's shading and denoising.  When the refitted tree's cost exceeds 1.6 x that of the last build, the call
- * rebuilds instead (synchronous, like rtggx_build_as).  rtggx_refit_stats: cost of the current tree relative to the last
- * build, refits and rebuilds so far; synchronises. */
+ * the existing tree run on the context's refit stream at the start of the next frame (rtggx_render_visibility), overlapping the
+ * previous frame's shading and denoising.  A refit keeps the topology of the last build; when the refitted tree's cost exceeds
+ * `rebuild_ratio` x that of the last build (rtggx_set_refit_policy, default 1.2), the mesh is REBUILT from its newest shape beside
+ * the frames: `steps_per_frame` kernel launches of the build per frame (default 16; ~75 for the bunny) behind that frame's refit,
+ * the new topology taking over between two frames when the last one has ended.  Neither call waits for the GPU (the first
+ * rtggx_refit_as of a mesh allocates its per-set buffers).  rtggx_refit_stats: cost of the current tree relative to the last
+ * build, refits and rebuilds so far; synchronises (a rebuild in progress stays in progress). */
 int  rtggx_refit_as(rtggx_context* ctx, uint32_t slot, const float* verts, uint32_t num_verts);
+int  rtggx_set_refit_policy(rtggx_context* ctx, float rebuild_ratio, uint32_t steps_per_frame);
 int  rtggx_refit_stats(rtggx_context* ctx, uint32_t slot, float* cost_ratio, uint32_t* refits, uint32_t* rebuilds);
 
 /* Per-frame constants; copied into the next slot of a ring of (input sets + 1) = 5. */

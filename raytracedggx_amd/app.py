@@ -16,7 +16,7 @@ HOST_EXPORTS = ["rtggx_app_last_error", "rtggx_app_create", "rtggx_app_destroy",
                 "rtggx_app_frame_constants", "rtggx_app_save_image", "rtggx_host_obj_import", "rtggx_host_obj_copy",
                 "rtggx_host_halton", "rtggx_host_frame_constants", "rtggx_host_write_png", "rtggx_host_camera",
                 "rtggx_app_on_lbutton_down", "rtggx_app_on_lbutton_up", "rtggx_app_on_mouse_move", "rtggx_app_on_mouse_wheel", "rtggx_app_load_track",
-                "rtggx_host_exchange_plan", "rtggx_host_balanced_bounds"]
+                "rtggx_host_exchange_plan", "rtggx_host_balanced_bounds", "rtggx_app_set_dump_prefix", "rtggx_app_last_screen_shot"]
 
 _lib = None
 
@@ -41,6 +41,9 @@ def load():
         L.rtggx_app_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rtggx_app_frame_constants.argtypes = [C.c_void_p, C.c_void_p]
         L.rtggx_app_save_image.argtypes = [C.c_void_p, C.c_char_p]
+        L.rtggx_app_set_dump_prefix.argtypes = [C.c_void_p, C.c_char_p]
+        L.rtggx_app_last_screen_shot.argtypes = [C.c_void_p]
+        L.rtggx_app_last_screen_shot.restype = C.c_char_p
         L.rtggx_host_obj_import.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
         L.rtggx_host_obj_copy.argtypes = [C.c_void_p, C.c_void_p]
         L.rtggx_host_halton.argtypes = [C.c_uint32, C.c_void_p]
@@ -157,6 +160,14 @@ class RayTracedGGX:
 
     def save_image(self, path):
         return self.L.rtggx_app_save_image(self.h, path.encode()) == 0
+
+    def set_dump_prefix(self, prefix):
+        """Where [F11] screen shots go: <prefix>_f<frame>.png (the -dump flag)."""
+        self.L.rtggx_app_set_dump_prefix(self.h, prefix.encode())
+
+    def last_screen_shot(self):
+        """The file the most recent [F11] (key code 0x7A, `key F11` in a -track script) wrote; '' if none."""
+        return self.L.rtggx_app_last_screen_shot(self.h).decode()
 
     def OnDestroy(self):
         if self.h:

@@ -30,7 +30,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_debug_shader_clock"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -61,6 +61,7 @@ def load():
     L.rtggx_set_history_apron.argtypes = [vp, C.c_uint32]
     L.rtggx_debug_shader_clock.argtypes = [vp, C.POINTER(C.c_double)]
     L.rtggx_refit_as.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
+    L.rtggx_set_refit_policy.argtypes = [vp, C.c_float, C.c_uint32]
     L.rtggx_refit_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rtggx_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.rtggx_history_overreach.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
@@ -160,6 +161,9 @@ class Context:
         """New vertex positions / normals for an unchanged topology: staged now, uploaded and refitted on stream B by the next frame."""
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 6)
         self._check(self.L.rtggx_refit_as(self.h, slot, _p(v), v.shape[0]))
+
+    def set_refit_policy(self, rebuild_ratio=1.2, steps_per_frame=16):
+        self._check(self.L.rtggx_set_refit_policy(self.h, rebuild_ratio, steps_per_frame))
 
     def refit_stats(self, slot=1):
         ratio, refits, rebuilds = C.c_float(), C.c_uint32(), C.c_uint32()

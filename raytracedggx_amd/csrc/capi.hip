@@ -9,6 +9,12 @@
 #include "rtggx_context.h"
 #include "rt_queue.h"
 
+#ifndef RT_REFIT_REBUILD_RATIO
+#define RT_REFIT_REBUILD_RATIO 1.2f      // a refitted tree whose cost has grown by this factor since its build is rebuilt (rtggx_refit_as)
+#endif
+#ifndef RT_REBUILD_STEPS
+#define RT_REBUILD_STEPS 16u             // launches of such a rebuild issued per frame (the bunny's build is ~75: five frames)
+#endif
 namespace rt {
 static thread_local char g_err[512] = "";
 void setError(const char* fmt, ...) {
@@ -70,9 +76,15 @@ static void invert4x4(const float* a /*row-major*/, float* out) {
 static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
 // A tone map that rtggx_tone_map has put aside for the next frame (see there) and no next frame has claimed: on the main stream, now.
 #define RT_TONE_ASIDE_PIXELS (2560ull * 1440ull)
+// A tone map on the main stream writes the back buffer a tone map put aside earlier (on the refit stream, evTone) may still be writing: the
+// older frame must not land last.
+static void orderMainBehindTones(rtggx_context* c) {
+  for (uint32_t p = 0; p < 2u; ++p) if (c->toneRecorded[p]) { hipStreamWaitEvent(c->streamMain, c->evTone[p], 0); c->toneRecorded[p] = false; }
+}
 static void flushToneMap(rtggx_context* c) {
   if (!c->tonePending) return;
   c->tonePending = false;
+  orderMainBehindTones(c);
   launchPreparedToneMap(c, c->tonePrepared, c->streamMain, nullptr);
 }
 static hipError_t syncStreams(rtggx_context* c) {
@@ -87,6 +99,9 @@ static hipError_t syncStreams(rtggx_context* c) {
 // The constants go up on stream B (which also runs the visibility pass); everything on the main stream that
 // consumes them is ordered behind the event.
 static int uploadParamsStreamB(rtggx_context* c) {
+  // (a visibility pass that has carried this slot to the device already -- rtggx_update_as came after it -- writes the same words from
+  // its first workgroup, on another stream: this upload, the newer TLAS, must land second)
+  if (c->evVisStream && c->evVisStream != c->streamAS) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evVis, 0));
   const int r = uploadParams(c, c->slot, c->streamAS);
   if (r) return r;
   c->slotUploaded = true;
@@ -109,6 +124,7 @@ static void freeMeshVerts(MeshDev& m) {
 static int setMeshImpl(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv, const uint32_t* idx, uint32_t ni) {
   MeshDev& m = c->mesh[slot];
   RT_HIP(syncStreams(c));       // frames in flight on any of the streams still read the buffers freed below
+  abandonRebuild(c, slot); m.wantRebuild = false;
   freeMeshVerts(m);
   freeBuildProducts(m);
   if (m.indices) { hipFree(m.indices); m.indices = nullptr; }
@@ -184,13 +200,14 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   { const int pr = getenv("RTGGX_PRIORITY_R") ? atoi(getenv("RTGGX_PRIORITY_R")) : 1;      // stream R: 0 low, 1 mid, 2 high
     RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, pr == 0 ? prioLeast : pr == 2 ? prioGreatest : prioMid)); }
   c->pipeline = getenv("RTGGX_PIPELINE") ? atoi(getenv("RTGGX_PIPELINE")) : 1;
+  c->rebuildRatio = getenv("RTGGX_REBUILD_RATIO") ? (float)atof(getenv("RTGGX_REBUILD_RATIO")) : RT_REFIT_REBUILD_RATIO;
+  c->rebuildSteps = getenv("RTGGX_REBUILD_STEPS") ? (uint32_t)atoi(getenv("RTGGX_REBUILD_STEPS")) : RT_REBUILD_STEPS;
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->evTone) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
   for (int i = 0; i < RT_SETS; ++i) {
-    RT_HIP(hipMalloc(&c->visDepthBuf[i], n * 8)); RT_HIP(hipMemset(c->visDepthBuf[i], 0, n * 8));
     RT_HIP(hipMalloc(&c->normalBuf[i], n * 4)); RT_HIP(hipMemset(c->normalBuf[i], 0, n * 4));
     RT_HIP(hipMalloc(&c->depth32Buf[i], n * 4)); RT_HIP(hipMemset(c->depth32Buf[i], 0, n * 4));
     RT_HIP(hipMalloc(&c->velocityBuf[i], n * 4)); RT_HIP(hipMemset(c->velocityBuf[i], 0, n * 4));
@@ -198,13 +215,15 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     RT_HIP(hipMalloc(&c->rtDiffBuf[i], n * 4)); RT_HIP(hipMemset(c->rtDiffBuf[i], 0, n * 4));
     RT_HIP(hipMalloc(&c->roughMetalBuf[i], n * 2)); RT_HIP(hipMemset(c->roughMetalBuf[i], 0, n * 2));
   }
+  for (auto& b : c->visDepthBuf) { RT_HIP(hipMalloc(&b, n * 8)); RT_HIP(hipMemset(b, 0, n * 8)); }
   c->selectSet(0);
   RT_HIP(hipMalloc(&c->backbuffer, n * 4));
   RT_HIP(hipMalloc(&c->tss[0], n * 8)); RT_HIP(hipMalloc(&c->tss[1], n * 8)); RT_HIP(hipMalloc(&c->fltRfl, n * 8)); RT_HIP(hipMalloc(&c->fltDff, n * 8));
   RT_HIP(hipMemset(c->backbuffer, 0, n * 4));
   RT_HIP(hipMemset(c->tss[0], 0, n * 8)); RT_HIP(hipMemset(c->tss[1], 0, n * 8)); RT_HIP(hipMemset(c->fltRfl, 0, n * 8)); RT_HIP(hipMemset(c->fltDff, 0, n * 8));
   c->largeCapacity = 1u << 16;
-  RT_HIP(hipMalloc(&c->largeTris, (size_t)c->largeCapacity * 56)); RT_HIP(hipMalloc(&c->largeCount, 4 * (1 + RT_SETS))); RT_HIP(hipMemset(c->largeCount, 0, 4 * (1 + RT_SETS)));
+  for (auto& b : c->largeTrisBuf) RT_HIP(hipMalloc(&b, (size_t)c->largeCapacity * 56));
+  RT_HIP(hipMalloc(&c->largeCountBase, 4 * (2 + RT_SETS))); RT_HIP(hipMemset(c->largeCountBase, 0, 4 * (2 + RT_SETS)));
   RT_HIP(hipMalloc(&c->rayCounter, 512 * 8)); RT_HIP(hipMemset(c->rayCounter, 0, 512 * 8));
   RT_HIP(hipMalloc(&c->rayCounterBuf, 1792 * 4)); RT_HIP(hipMemset(c->rayCounterBuf, 0, 1792 * 4));      // [4][256] per-frame counters + 768 statistics words
   c->rayCounter32 = c->lastRayCounter32 = c->rayCounterBuf;
@@ -268,9 +287,10 @@ void rtggx_destroy(rtggx_context* c) {
     hipFree(m.indices); hipFree(m.dCost); if (m.hCost) hipHostFree(m.hCost); if (m.evCost) hipEventDestroy(m.evCost);
   }
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->backbuffer);
-  for (int i = 0; i < RT_SETS; ++i) { hipFree(c->visDepthBuf[i]); hipFree(c->depth32Buf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
+  for (auto b : c->visDepthBuf) hipFree(b);
+  for (int i = 0; i < RT_SETS; ++i) { hipFree(c->depth32Buf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
   hipFree(c->tss[0]); hipFree(c->tss[1]);
-  hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTris); hipFree(c->largeCount); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
+  hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTrisBuf[0]); hipFree(c->largeTrisBuf[1]); hipFree(c->largeCountBase); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
   hipFree(c->binWorkBuf[0]); hipFree(c->binWorkBuf[1]); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
   hipFree(c->stackOverflow); hipFree(c->testRayRange); hipFree(c->dummyRecord); hipFree(c->histReach);
@@ -370,20 +390,22 @@ int rtggx_set_metallic(rtggx_context* c, uint32_t mesh, float metallic) {   // R
 int rtggx_build_as(rtggx_context* c) {
   RT_CHECK_CTX(c);
   RT_HIP(syncStreams(c));
-  for (uint32_t i = 0; i < 2; ++i) { const int r = buildLbvh(c, i, c->streamAS); if (r) return r; }
+  // (a mesh that deforms keeps its per-set vertex buffers: it is built from its newest shape, and every input set gets the tree of
+  // that set's own vertices -- lbvh.hip buildLbvh; a rebuild in progress beside the frames is dropped)
+  for (uint32_t i = 0; i < 2; ++i) { abandonRebuild(c, i); c->mesh[i].wantRebuild = false; const int r = buildLbvh(c, i, c->streamAS); if (r) return r; }
+  c->selectSet(c->setIndex);
   c->asBuilt = true; c->sceneDirty = true;
   return 0;
 }
 
 // Deforming meshes (the sample itself only turns a rigid instance, RayTracer.cpp:326-341): new vertices for an
 // unchanged topology.  The call only STAGES them (one copy into pinned memory); the upload and the refit of the acceleration
-// structure are issued by the next rtggx_render_visibility on stream B -- behind the previous frame's traversal, beside that
+// structure are issued by the next rtggx_render_visibility on stream R -- behind the previous frame's traversal, beside that
 // frame's shading and denoising on the main stream -- without a synchronisation.  The topology stays the one the last build
-// chose; when the tree's cost has grown by RT_REFIT_REBUILD_RATIO since that build, this call rebuilds instead (synchronous).
-static int splitBvhPerSet(MeshDev& m);
-#ifndef RT_REFIT_REBUILD_RATIO
-#define RT_REFIT_REBUILD_RATIO 1.6f
-#endif
+// chose; when the tree's cost has grown by RT_REFIT_REBUILD_RATIO since that build, the mesh is REBUILT beside the frames (round 3;
+// lbvh.hip startRebuild: a few launches per frame behind the frame's refit, the new topology swapped in between two frames).  This call
+// never waits for the GPU -- except the first one for a mesh, which allocates the per-set buffers.
+static int splitBvhPerSet(rtggx_context* c, uint32_t slot);
 int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t nv) {
   RT_CHECK_CTX(c);
   if (slot >= RTGGX_NUM_MESH || !verts) { setError("rtggx_refit_as: bad arguments"); return -1; }
@@ -393,33 +415,42 @@ int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
   const size_t bytes = sizeof(float) * 6 * (size_t)nv;
   if (!m.deforming) {        // first time: one vertex buffer per input set (rtggx_context.h), a staging ring
     RT_HIP(syncStreams(c));
-    for (int i = 1; i < RT_SETS; ++i) { RT_HIP(hipMalloc(&m.vertsBuf[i], bytes)); RT_HIP(hipMemcpy(m.vertsBuf[i], m.vertsBuf[0], bytes, hipMemcpyDeviceToDevice)); }
-    { const size_t fb = sizeof(float4) * 5 * (size_t)m.numTris; for (int i = 1; i < RT_SETS; ++i) { RT_HIP(hipMalloc(&m.fatBuf[i], fb)); RT_HIP(hipMemcpy(m.fatBuf[i], m.fatBuf[0], fb, hipMemcpyDeviceToDevice)); } }
-    for (auto& st : m.stage) RT_HIP(hipHostMalloc(&st, bytes));
-    { const int r = splitBvhPerSet(m); if (r) return r; }
+    float* nv2[RT_SETS] = {}; float4* nf[RT_SETS] = {}; float* st[RT_SLOTS] = {};
+    const size_t fb = sizeof(float4) * 5 * (size_t)m.numTris;
+    bool ok = true;
+    for (int i = 1; i < RT_SETS && ok; ++i) ok = hipMalloc(&nv2[i], bytes) == hipSuccess && hipMalloc(&nf[i], fb) == hipSuccess;
+    for (int i = 0; i < RT_SLOTS && ok; ++i) ok = hipHostMalloc(&st[i], bytes) == hipSuccess;
+    if (!ok) {       // nothing half-done is left behind
+      for (int i = 1; i < RT_SETS; ++i) { hipFree(nv2[i]); hipFree(nf[i]); }
+      for (auto p : st) if (p) hipHostFree(p);
+      setError("rtggx_refit_as: out of memory for the per-set vertex buffers of mesh %u", slot); return -2;
+    }
+    for (int i = 1; i < RT_SETS; ++i) {
+      m.vertsBuf[i] = nv2[i]; m.fatBuf[i] = nf[i];
+      RT_HIP(hipMemcpy(m.vertsBuf[i], m.vertsBuf[0], bytes, hipMemcpyDeviceToDevice)); RT_HIP(hipMemcpy(m.fatBuf[i], m.fatBuf[0], fb, hipMemcpyDeviceToDevice));
+    }
+    for (int i = 0; i < RT_SLOTS; ++i) m.stage[i] = st[i];
+    { const int r = splitBvhPerSet(c, slot); if (r) return r; }
     m.deforming = true; m.latestSet = c->setIndex;
     c->selectSet(c->setIndex);
   }
   // the cost of the tree after an earlier refit has arrived: has the shape drifted too far from the one the topology was built for?
   if (m.costInFlight && hipEventQuery(m.evCost) == hipSuccess) { m.lastCost = *m.hCost; m.costInFlight = false; }
-  if (m.builtCost > 0.0f && m.lastCost > RT_REFIT_REBUILD_RATIO * m.builtCost) {
-    RT_HIP(syncStreams(c));
-    for (int i = 0; i < RT_SETS; ++i) { RT_HIP(hipMemcpy(m.vertsBuf[i], verts, bytes, hipMemcpyHostToDevice)); m.vertsVersion[i] = m.version + 1; }
-    ++m.version; m.pendingStage = -1; m.costInFlight = false;
-    for (int k = 0; k < 3; ++k) { m.bmin[k] = 3.4e38f; m.bmax[k] = -3.4e38f; }
-    for (uint32_t v = 0; v < nv; ++v) for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; if (x < m.bmin[k]) m.bmin[k] = x; if (x > m.bmax[k]) m.bmax[k] = x; }
-    const uint32_t refits = m.refits, rebuilds = m.rebuilds;
-    for (uint32_t i = 0; i < RT_SETS; ++i) { const int rf = buildFatTris(c, slot, i, c->streamAS); if (rf) return rf; }
-    int r = buildLbvh(c, slot, c->streamAS);        // one tree again, aliased by all sets ...
-    if (!r) r = splitBvhPerSet(m);                   // ... and a copy per set for the refits to come
-    c->selectSet(c->setIndex);
-    m.refits = refits; m.rebuilds = rebuilds + 1;
-    return r;
-  }
-  const uint32_t st = m.stageNext; m.stageNext = (m.stageNext + 1u) % RT_SLOTS;
-  // a staging buffer is reused RT_SLOTS calls later; its copy was issued before the frame RT_SETS frames back was fenced
+  if (m.builtCost > 0.0f && m.lastCost > c->rebuildRatio * m.builtCost) m.wantRebuild = true;      // started by the next frame (issuePendingRefits)
+  // A shape that no frame has picked up yet (two calls between frames, calls without frames) is simply replaced: its staging buffer has
+  // no copy in flight.  Otherwise the next buffer of the ring: it was last consumed RT_SLOTS frames ago, and the copy that read it was
+  // ordered before a traversal whose frame the host has since waited for (the set fence of rtggx_render_visibility).
+  uint32_t st;
+  if (m.pendingStage >= 0) st = (uint32_t)m.pendingStage;
+  else { st = m.stageNext; m.stageNext = (m.stageNext + 1u) % RT_SLOTS; }
   memcpy(m.stage[st], verts, bytes);
   m.pendingStage = (int)st;
+  return 0;
+}
+int rtggx_set_refit_policy(rtggx_context* c, float rebuildRatio, uint32_t stepsPerFrame) {
+  RT_CHECK_CTX(c);
+  if (!(rebuildRatio > 1.0f) || stepsPerFrame == 0u) { setError("rtggx_set_refit_policy: a ratio above 1 and at least one step per frame"); return -1; }
+  c->rebuildRatio = rebuildRatio; c->rebuildSteps = stepsPerFrame;
   return 0;
 }
 int rtggx_refit_stats(rtggx_context* c, uint32_t slot, float* costRatio, uint32_t* refits, uint32_t* rebuilds) {
@@ -435,14 +466,16 @@ int rtggx_refit_stats(rtggx_context* c, uint32_t slot, float* costRatio, uint32_
 }
 
 // The boxes and leaf triangles of a deforming mesh once per input set (rtggx_context.h): copies of the tree just built.
-static int splitBvhPerSet(MeshDev& m) {
-  const size_t n = m.numTris, nn = n > 1 ? n - 1 : 1;
+static int splitBvhPerSet(rtggx_context* c, uint32_t slot) {
+  MeshDev& m = c->mesh[slot];
+  const size_t n = m.numTris, nn = n > 1 ? n - 1 : 1, topCap = slot == 0 ? RT_TOP_SLOT0 : RT_TOP_SLOT1;
   for (int i = 1; i < RT_SETS; ++i) {
     if (m.trisBuf[i] != m.trisBuf[0]) continue;
     RT_HIP(hipMalloc(&m.trisBuf[i], sizeof(BvhTri) * n)); RT_HIP(hipMemcpy(m.trisBuf[i], m.trisBuf[0], sizeof(BvhTri) * n, hipMemcpyDeviceToDevice));
     RT_HIP(hipMalloc(&m.nodesBuf[i], sizeof(BvhNode) * nn)); RT_HIP(hipMemcpy(m.nodesBuf[i], m.nodesBuf[0], sizeof(BvhNode) * nn, hipMemcpyDeviceToDevice));
     RT_HIP(hipMalloc(&m.nodes4Buf[i], sizeof(Bvh4Node) * nn)); RT_HIP(hipMemcpy(m.nodes4Buf[i], m.nodes4Buf[0], sizeof(Bvh4Node) * nn, hipMemcpyDeviceToDevice));
-    if (m.topCount) { RT_HIP(hipMalloc(&m.topBuf[i], sizeof(Bvh4Node) * m.topCount)); RT_HIP(hipMemcpy(m.topBuf[i], m.topBuf[0], sizeof(Bvh4Node) * m.topCount, hipMemcpyDeviceToDevice)); }
+    RT_HIP(hipMalloc(&m.topBuf[i], sizeof(Bvh4Node) * topCap)); RT_HIP(hipMemcpy(m.topBuf[i], m.topBuf[0], sizeof(Bvh4Node) * topCap, hipMemcpyDeviceToDevice));
+    m.topCountBuf[i] = m.topCountBuf[0];
   }
   return 0;
 }
@@ -452,21 +485,33 @@ static int splitBvhPerSet(MeshDev& m) {
 static int issuePendingRefits(rtggx_context* c, bool* touched) {
   *touched = false;
   const hipStream_t s = c->asyncCompute ? c->streamRefit : c->streamMain;
+  const uint32_t stepsPerFrame = c->rebuildSteps;
   for (uint32_t slot = 0; slot < RTGGX_NUM_MESH; ++slot) {
     MeshDev& m = c->mesh[slot];
     if (!m.deforming) continue;
+    // a rebuild beside the frames: has it ended (then this frame's refit is the first on the new topology)?  otherwise its next launches
+    bool swapped = false;
+    { const int r = continueRebuild(c, slot, s, stepsPerFrame, &swapped); if (r) return r; }
     const size_t bytes = sizeof(float) * 6 * (size_t)m.numVerts;
     const uint32_t set = c->setIndex;
+    bool refit = true;
     if (m.pendingStage >= 0) {
       RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.stage[m.pendingStage], bytes, hipMemcpyHostToDevice, s));
       m.pendingStage = -1; ++m.version;
     } else if (m.vertsVersion[set] != m.version) {      // no new shape this frame: this set still holds an older one
       RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.vertsBuf[m.latestSet], bytes, hipMemcpyDeviceToDevice, s));
-    } else continue;
-    m.vertsVersion[set] = m.version; m.latestSet = set;
-    const int r = refitLbvh(c, slot, set, s);           // this set's leaf triangles and nodes from this set's vertices
-    if (r) return r;
-    *touched = true;
+    } else refit = false;
+    if (refit) {
+      m.vertsVersion[set] = m.version; m.latestSet = set;
+      const int r = refitLbvh(c, slot, set, s);           // this set's leaf triangles and nodes from this set's vertices
+      if (r) return r;
+      *touched = true;
+    }
+    if (m.wantRebuild && !swapped) {      // (the cost that asked for it was the old topology's)
+      const int r = startRebuild(c, slot, m.latestSet);
+      if (r < 0) return r;
+      if (r == 1) { m.wantRebuild = false; bool sw; const int r2 = continueRebuild(c, slot, s, stepsPerFrame, &sw); if (r2) return r2; }      // its first launches: the copy of the vertices it starts from
+    } else if (swapped) m.wantRebuild = false;
   }
   return 0;
 }
@@ -541,12 +586,9 @@ int rtggx_render_visibility(rtggx_context* c) {
   ++c->frameCounter;
   c->denoiseIssued = false;
   c->selectSet((c->setIndex + 1u) % RT_SETS);
-  // the set was last read three frames ago: normally long done; a host that has run further ahead than that waits here
-  static const bool gpuSideWait = getenv("RTGGX_SET_WAIT_ON_GPU") != nullptr;      // the cross-queue wait instead (measurement)
-  if (c->setReadRecorded[c->setIndex]) {
-    if (gpuSideWait) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evSetRead[c->setIndex], 0));
-    else if (hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
-  }
+  // the set was last read three frames ago: normally long done; a host that has run further ahead than that waits here (also what makes
+  // it safe for this frame's ray generation to clear the NEXT frame's visibility target: rtggx_context.h RT_VIS_RING)
+  if (c->setReadRecorded[c->setIndex] && hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
   c->refitIssued = false;
   { const int r = issuePendingRefits(c, &c->refitIssued); if (r) return r; }
   if (c->refitIssued && c->asyncCompute) RT_HIP(hipEventRecord(c->evRefit, c->streamRefit));
@@ -565,6 +607,11 @@ int rtggx_render_visibility(rtggx_context* c) {
     s = small ? c->streamVis : c->streamAS;
   }
   if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on the other stream
+  // MEASUREMENT (profiles/r03_b_sync_pipeline.txt): the three stages in lock step -- stage C of frame f does not start before the main
+  // stream's chain of frame f - 3 has ended, the traversal of frame f not before that of frame f - 2 (rtggx_ray_trace): what a frame
+  // submitted as ONE graph of three branches per iteration would do to the GPU side.
+  static const bool syncPipe = getenv("RTGGX_SYNC_PIPE") && atoi(getenv("RTGGX_SYNC_PIPE")) != 0;
+  if (syncPipe && pipelined && c->setReadRecorded[(c->setIndex + 1u) % RT_SETS]) RT_HIP(hipStreamWaitEvent(s, c->evSetRead[(c->setIndex + 1u) % RT_SETS], 0));
   // constants already on their way on stream B (timing mode uploads them in rtggx_update_as): a pass on stream C reads
   // dParams[slot] and has to be ordered behind that upload (evAS); on stream B it follows it anyway
   if (c->slotUploaded && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evAS, 0));
@@ -605,6 +652,8 @@ int rtggx_ray_trace(rtggx_context* c) {
     if (c->slotUploaded) RT_HIP(hipStreamWaitEvent(sGen, c->evAS, 0));
   }
   if (c->refitIssued && c->asyncCompute) RT_HIP(hipStreamWaitEvent(sTrace, c->evRefit, 0));      // this set's tree
+  { static const bool syncPipe = getenv("RTGGX_SYNC_PIPE") && atoi(getenv("RTGGX_SYNC_PIPE")) != 0;      // see rtggx_render_visibility
+    if (syncPipe && c->pipeline != 0 && c->setReadRecorded[(c->setIndex + 2u) % RT_SETS]) RT_HIP(hipStreamWaitEvent(sTrace, c->evSetRead[(c->setIndex + 2u) % RT_SETS], 0)); }
   if (c->timing) hipEventRecord(c->tev[3], sGen);
   hipEvent_t evDone = c->evTraceRing[f & 3u];
   int r = launchRayTrace(c, c->slots[c->slot], sGen, sTrace, evDone);
@@ -664,6 +713,7 @@ int rtggx_tone_map(rtggx_context* c) {
                      && !(c->mesh[0].deforming || c->mesh[1].deforming) && !c->lastTraceSmall && fp.rowBegin == 0u && fp.rowEnd == fp.H && c->denoiseIssued
                      && (uint64_t)fp.W * fp.H <= RT_TONE_ASIDE_PIXELS;
   if (aside && prepareToneMap(c, fp, &c->tonePrepared)) { c->tonePending = true; c->toneParity = c->frameParity & 1u; ++c->toneAsideCount; return 0; }
+  orderMainBehindTones(c);
   const int r = launchToneMap(c, fp, c->streamMain);
   if (c->timing) { hipEventRecord(c->tev[10], c->streamMain); c->timingsPending = true; }
   return r;

@@ -1,15 +1,21 @@
 // Bottom-level acceleration structures: the gfx950 replacement of the driver-side BLAS build the
 // reference requests in RayTracer::buildAccelerationStructures / BuildAccelerationStructures
 // (RayTracedGGX/Content/RayTracer.cpp:676-716, 158-233; PREFER_FAST_TRACE, one triangle geometry
-// per mesh, R32G32B32_FLOAT positions at stride 24, 32-bit indices).
+// per mesh, R32G32B32_FLOAT positions at stride 24, 32-bit indices) and of its per-frame update (:326-341).
 //
-// LBVH (Karras 2012): 30-bit Morton codes of triangle-box centres -> stable LSD radix sort
-// (4 x 8 bits, wave64 ballot ranking) -> radix-tree hierarchy, one lane per internal node ->
-// bottom-up box fit with one arrival counter per node -> 64-byte nodes that carry both child
-// boxes, and 64-byte leaf triangles in Morton order.  The build runs on the context's build stream with host round trips
-// (PLOC rounds) and is off the per-frame path; what IS on it, for meshes that change shape, is refitLbvh at the end of
-// this file: new leaf triangles and boxes for the existing topology, five kernels on stream B, no host involvement.
+// The build, all of it on the device (round 3; rounds 1 and 2 drove the clustering from the host, one synchronisation per round):
+//   vertex bounds -> 30-bit Morton codes of the triangle-box centres -> stable LSD radix sort (4 x 8 bits, wave64 ballot ranking)
+//   -> PLOC clustering (Meister & Bittner 2018): a fixed number of multi-workgroup rounds, each three kernels that read the number of
+//      clusters left from device memory, then ONE workgroup that finishes whatever is left (normally <= 2048 clusters) round by round
+//   -> the refit schedule ("treelets"), the list of nodes at the tree's top, the tree's depth and cost
+//   -> 64-byte binary nodes (for the oracle / tests), their 4-wide collapse (for the trace kernel), 64-byte leaf triangles in Morton order.
+// ~75 kernel launches on one stream for the bunny, no host round trip; the host reads five counts (BuildResult) when the last one has
+// ended.  rtggx_build_as issues them all and waits once; a mesh that deforms is REBUILT the same way beside the frames (startRebuild /
+// continueRebuild: a few launches per frame on the refit stream, the new topology swapped in between two frames).  What is on the
+// per-frame path of such a mesh is refitLbvh: new leaf triangles and boxes for the existing topology, six kernels, no host involvement.
 #include <algorithm>
+#include <cstring>
+#include <functional>
 #include <utility>
 #include "rtggx_context.h"
 
@@ -23,11 +29,28 @@ RT_DEV uint32_t expandBits10(uint32_t v) {
   return v;
 }
 
+// Vertex bounds (the Morton normalisation box) on the device: floats ordered as unsigned integers, one atomic per wave and bound.
+RT_DEV uint32_t orderedBits(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+RT_DEV float fromOrderedBits(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+__global__ void boundsKernel(const float* __restrict__ verts, uint32_t nv, uint32_t* __restrict__ bounds /* min[3] max[3], ordered bits */) {
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x)
+    for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; mn[k] = fminf(mn[k], x); mx[k] = fmaxf(mx[k], x); }
+  for (int k = 0; k < 3; ++k) {
+    for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_down(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_down(mx[k], o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&bounds[k], orderedBits(mn[k])); atomicMax(&bounds[3 + k], orderedBits(mx[k])); }
+  }
+}
 __global__ void mortonKernel(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t n,
-                             float3 bmin, float3 invExt, uint32_t* __restrict__ codes, uint32_t* __restrict__ order,
+                             const uint32_t* __restrict__ bounds, uint32_t* __restrict__ codes, uint32_t* __restrict__ order,
                              float* __restrict__ triBox) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  float3 bmin, invExt;
+  { const float x0 = fromOrderedBits(bounds[0]), y0 = fromOrderedBits(bounds[1]), z0 = fromOrderedBits(bounds[2]);
+    const float x1 = fromOrderedBits(bounds[3]), y1 = fromOrderedBits(bounds[4]), z1 = fromOrderedBits(bounds[5]);
+    bmin = make_float3(x0, y0, z0);
+    invExt = make_float3(x1 > x0 ? 1.0f / (x1 - x0) : 0.0f, y1 > y0 ? 1.0f / (y1 - y0) : 0.0f, z1 > z0 ? 1.0f / (z1 - z0) : 0.0f); }
   float mn[3], mx[3];
   for (int k = 0; k < 3; ++k) {
     const float a = verts[6 * (size_t)idx[3 * i] + k], b = verts[6 * (size_t)idx[3 * i + 1] + k], c = verts[6 * (size_t)idx[3 * i + 2] + k];
@@ -61,11 +84,15 @@ __global__ void __launch_bounds__(1024) scanExclusive(uint32_t* __restrict__ dat
   const uint32_t b = threadIdx.x * per, e = min(b + per, count);
   uint32_t s = 0;
   for (uint32_t i = b; i < e; ++i) s += data[i];
-  partial[threadIdx.x] = s;
+  // exclusive scan of the 1024 partial sums: inside each wave with shuffles, then over the 16 wave totals
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = s;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += v; }
+  if (lane == 63u) partial[wave] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 1024; ++i) { const uint32_t v = partial[i]; partial[i] = run; run += v; } }
-  __syncthreads();
-  uint32_t run = partial[threadIdx.x];
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; ++w) base += partial[w];
+  uint32_t run = base + inc - s;
   for (uint32_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
 }
 __global__ void __launch_bounds__(256) radixScatter(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t n, int shift,
@@ -152,13 +179,35 @@ __global__ void fitKernel(int n, const uint32_t* __restrict__ order, const float
 // Agglomerative build over the Morton-ordered triangles: every cluster looks RT_PLOC_RADIUS positions to either side
 // for the partner that gives the smallest merged box; mutual choices merge into a new node; the survivors are
 // compacted (order kept) and the step repeats until one cluster is left.  Trees come out close to a SAH sweep
-// build -- on the bunny a third fewer traversal steps per ray than the Karras radix tree (profiles/r01_d) -- and the
-// build is off the frame path.  Everything is deterministic: ties go to the lower position, node indices come from
-// prefix sums.
+// build -- on the bunny a third fewer traversal steps per ray than the Karras radix tree (profiles/r01_d).
+// Everything is deterministic: ties go to the lower position, node indices come from prefix sums.
+//
+// Device-driven (round 3).  How many clusters a round leaves is known on the device only, so nothing on the host depends on it:
+// the host issues a FIXED number of rounds sized from the triangle count (each round: plocNearest, plocCount, plocScatter, all with
+// the grid of the first round -- workgroups beyond the clusters left leave at once), then plocFinal, ONE workgroup that runs rounds
+// until a single cluster is left, whatever it is handed (normally <= 2048 clusters; if the fixed rounds merged less than expected it
+// simply has more to do).  The state between rounds -- clusters left, next node index, rounds so far -- lives in a two-entry ring in
+// device memory (round r reads entry r & 1 and writes the other); roundBase[k] = first node of round k, for the refit schedule.
 #define RT_PLOC_RADIUS 16
+#define RT_MAX_ROUNDS 1024
+#define RT_TREELET_NODES 1024
+struct PlocState { uint32_t m, nodeBase, rounds, pad; };
+struct PlocArrays {      // what a round reads and writes (by value to the kernels)
+  int32_t* clRef[2]; float* clBox[2]; int32_t* nn;
+  int32_t *left, *right, *nodeParent, *leafParent; float* nodeBox; uint32_t* cnt[RT_TREELET_LEVELS];
+  uint32_t* roundBase; BuildResult* res;
+};
 RT_DEV float mergedArea(const float* a, const float* b) {
   const float ex = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), ey = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), ez = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
   return (ex * ey + ey * ez) + ez * ex;
+}
+// first kernel of a build: the device records start clean
+__global__ void buildBegin(uint32_t n, PlocState* state, BuildResult* res, uint32_t* bounds) {
+  if (threadIdx.x == 0) {
+    state[0].m = n; state[0].nodeBase = 0u; state[0].rounds = 0u; state[0].pad = 0u; state[1] = state[0];
+    BuildResult z{}; *res = z;
+    for (int k = 0; k < 3; ++k) { bounds[k] = 0xFFFFFFFFu; bounds[3 + k] = 0u; }
+  }
 }
 __global__ void plocInit(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, int32_t* __restrict__ clRef, float* __restrict__ clBox) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,9 +215,7 @@ __global__ void plocInit(int n, const uint32_t* __restrict__ order, const float*
   clRef[s] = ~s;
   for (int k = 0; k < 6; ++k) clBox[6 * (size_t)s + k] = triBox[6 * (size_t)order[s] + k];
 }
-__global__ void plocNearest(int m, int radius, const float* __restrict__ clBox, int32_t* __restrict__ nn) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
+RT_DEV int plocNearestOf(int i, int m, int radius, const float* __restrict__ clBox) {
   float mine[6];
   for (int k = 0; k < 6; ++k) mine[k] = clBox[6 * (size_t)i + k];
   float best = __builtin_inff(); int bj = -1;
@@ -178,42 +225,122 @@ __global__ void plocNearest(int m, int radius, const float* __restrict__ clBox, 
     const float d = mergedArea(mine, clBox + 6 * (size_t)j);
     if (d < best) { best = d; bj = j; }
   }
-  nn[i] = bj;
+  return bj;
 }
-__global__ void plocFlags(int m, const int32_t* __restrict__ nn, uint32_t* __restrict__ keep, uint32_t* __restrict__ merge) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const int j = nn[i];
-  const bool mutual = j >= 0 && nn[j] == i;
-  merge[i] = mutual && i < j ? 1u : 0u;        // the lower position carries the new node
-  keep[i] = mutual && i > j ? 0u : 1u;         // the higher one disappears
+__global__ void __launch_bounds__(256) plocNearest(const PlocState* __restrict__ state, uint32_t r, int radius, PlocArrays A) {
+  const int m = (int)state[r & 1u].m;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (m <= 1 || i >= m) return;
+  A.nn[i] = plocNearestOf(i, m, radius, A.clBox[r & 1u]);
 }
-// keepPos / mergePos: exclusive prefix sums of the flags (the flags themselves are recovered from nn)
-__global__ void plocScatter(int m, int nodeBase, const int32_t* __restrict__ nn, const uint32_t* __restrict__ keepPos, const uint32_t* __restrict__ mergePos,
-                            const int32_t* __restrict__ clRef, const float* __restrict__ clBox, int32_t* __restrict__ clRefOut, float* __restrict__ clBoxOut,
-                            int32_t* __restrict__ left, int32_t* __restrict__ right, int32_t* __restrict__ nodeParent, int32_t* __restrict__ leafParent,
-                            float* __restrict__ nodeBox) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// keep / merge flags of position i: mutual nearest neighbours merge, the lower position carries the new node, the higher one disappears
+RT_DEV void plocFlags(int i, int m, const int32_t* __restrict__ nn, int& j, bool& mutual, uint32_t& keep, uint32_t& merge) {
+  j = -1; mutual = false; keep = 0u; merge = 0u;
   if (i >= m) return;
-  const int j = nn[i];
-  const bool mutual = j >= 0 && nn[j] == i;
-  if (mutual && i > j) return;
-  const uint32_t p = keepPos[i];
+  j = nn[i];
+  mutual = j >= 0 && nn[j] == i;
+  merge = mutual && i < j ? 1u : 0u;
+  keep = mutual && i > j ? 0u : 1u;
+}
+__global__ void __launch_bounds__(256) plocCount(const PlocState* __restrict__ state, uint32_t r, const int32_t* __restrict__ nn, uint2* __restrict__ blockCounts) {
+  const int m = (int)state[r & 1u].m;
+  if (m <= 1 || (int)(blockIdx.x * 256) >= m) return;
+  int j; bool mutual; uint32_t keep, merge;
+  plocFlags(blockIdx.x * 256 + threadIdx.x, m, nn, j, mutual, keep, merge);
+  __shared__ uint32_t wk[4], wm[4];
+  const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u);
+  if ((threadIdx.x & 63u) == 0u) { wk[threadIdx.x >> 6] = (uint32_t)__popcll(bk); wm[threadIdx.x >> 6] = (uint32_t)__popcll(bm); }
+  __syncthreads();
+  if (threadIdx.x == 0) blockCounts[blockIdx.x] = make_uint2(wk[0] + wk[1] + wk[2] + wk[3], wm[0] + wm[1] + wm[2] + wm[3]);
+}
+// Position i survives at position p of the next round's list: as itself, or merged with j into node `node`.  A new node also gets, per
+// treelet level, the number of nodes of its subtree that level still has to place (its children are older: their counts are final).
+RT_DEV void plocEmit(int i, int j, bool mutual, uint32_t p, int node, const int32_t* __restrict__ clRef, const float* __restrict__ clBox,
+                     int32_t* __restrict__ clRefOut, float* __restrict__ clBoxOut, const PlocArrays& A) {
   if (mutual) {
-    const int node = nodeBase + (int)mergePos[i];
     const int32_t L = clRef[i], R = clRef[j];
-    left[node] = L; right[node] = R;
-    if (L < 0) leafParent[~L] = node; else nodeParent[L] = node;
-    if (R < 0) leafParent[~R] = node; else nodeParent[R] = node;
+    A.left[node] = L; A.right[node] = R;
+    if (L < 0) A.leafParent[~L] = node; else A.nodeParent[L] = node;
+    if (R < 0) A.leafParent[~R] = node; else A.nodeParent[R] = node;
     for (int k = 0; k < 3; ++k) {
       const float mn = fminf(clBox[6 * (size_t)i + k], clBox[6 * (size_t)j + k]), mx = fmaxf(clBox[6 * (size_t)i + 3 + k], clBox[6 * (size_t)j + 3 + k]);
-      nodeBox[6 * (size_t)node + k] = mn; nodeBox[6 * (size_t)node + 3 + k] = mx;
+      A.nodeBox[6 * (size_t)node + k] = mn; A.nodeBox[6 * (size_t)node + 3 + k] = mx;
       clBoxOut[6 * (size_t)p + k] = mn; clBoxOut[6 * (size_t)p + 3 + k] = mx;
     }
     clRefOut[p] = node;
+    uint32_t below = 0xFFFFFFFFu;      // level 0 places every node
+    for (int l = 0; l < RT_TREELET_LEVELS; ++l) {
+      const uint32_t c = below > RT_TREELET_NODES ? 1u + (L >= 0 ? A.cnt[l][L] : 0u) + (R >= 0 ? A.cnt[l][R] : 0u) : 0u;
+      A.cnt[l][node] = c; below = c;
+    }
   } else {
     clRefOut[p] = clRef[i];
     for (int k = 0; k < 6; ++k) clBoxOut[6 * (size_t)p + k] = clBox[6 * (size_t)i + k];
+  }
+}
+__global__ void __launch_bounds__(256) plocScatter(PlocState* __restrict__ state, uint32_t r, const uint2* __restrict__ blockCounts, PlocArrays A) {
+  const PlocState st = state[r & 1u];
+  const int m = (int)st.m;
+  if (m <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) state[(r + 1u) & 1u] = st; return; }      // done: the state is handed on as it is
+  const uint32_t nblocks = ((uint32_t)m + 255u) / 256u;
+  if (blockIdx.x >= nblocks) return;
+  // kept positions / merges in the workgroups before this one
+  __shared__ uint32_t redK[4], redM[4], wk[4], wm[4];
+  uint32_t ok = 0, om = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) { const uint2 c = blockCounts[b]; ok += c.x; om += c.y; }
+  for (int o = 32; o > 0; o >>= 1) { ok += __shfl_down(ok, o); om += __shfl_down(om, o); }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int j; bool mutual; uint32_t keep, merge;
+  plocFlags(i, m, A.nn, j, mutual, keep, merge);
+  const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u), below = (1ull << lane) - 1ull;
+  if (lane == 0u) { redK[wave] = ok; redM[wave] = om; wk[wave] = (uint32_t)__popcll(bk); wm[wave] = (uint32_t)__popcll(bm); }
+  __syncthreads();
+  const uint32_t baseK = redK[0] + redK[1] + redK[2] + redK[3], baseM = redM[0] + redM[1] + redM[2] + redM[3];
+  uint32_t rk = (uint32_t)__popcll(bk & below), rm = (uint32_t)__popcll(bm & below);
+  for (uint32_t w = 0; w < wave; ++w) { rk += wk[w]; rm += wm[w]; }
+  if (keep) plocEmit(i, j, mutual, baseK + rk, (int)(st.nodeBase + baseM + rm), A.clRef[r & 1u], A.clBox[r & 1u], A.clRef[(r + 1u) & 1u], A.clBox[(r + 1u) & 1u], A);
+  if (blockIdx.x == nblocks - 1u && threadIdx.x == 0) {      // the last workgroup knows the totals
+    PlocState nx;
+    nx.m = baseK + wk[0] + wk[1] + wk[2] + wk[3]; nx.nodeBase = st.nodeBase + baseM + wm[0] + wm[1] + wm[2] + wm[3]; nx.rounds = st.rounds + 1u; nx.pad = 0u;
+    if (st.rounds < RT_MAX_ROUNDS) A.roundBase[st.rounds] = st.nodeBase; else atomicOr(&A.res->error, 1u);
+    state[(r + 1u) & 1u] = nx;
+  }
+}
+// One workgroup finishes the clustering: rounds until one cluster is left (each merges at least one pair: it ends), then the root's
+// parent, the last roundBase entry and the round count.  `r`: the rounds issued before it (it reads state entry r & 1).
+__global__ void __launch_bounds__(1024) plocFinal(const PlocState* __restrict__ state, uint32_t r, int radius, uint32_t n, PlocArrays A) {
+  __shared__ uint32_t wk[16], wm[16];
+  const PlocState st = state[r & 1u];
+  uint32_t m = st.m, nodeBase = st.nodeBase, rounds = st.rounds, p = r & 1u;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  while (m > 1u) {
+    const int32_t* clRef = A.clRef[p]; const float* clBox = A.clBox[p];
+    for (uint32_t i = threadIdx.x; i < m; i += 1024u) A.nn[i] = plocNearestOf((int)i, (int)m, radius, clBox);
+    __syncthreads();
+    uint32_t keptBase = 0, mergedBase = 0;
+    for (uint32_t c0 = 0; c0 < m; c0 += 1024u) {
+      const int i = (int)(c0 + threadIdx.x);
+      int j; bool mutual; uint32_t keep, merge;
+      plocFlags(i, (int)m, A.nn, j, mutual, keep, merge);
+      const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u);
+      if (lane == 0u) { wk[wave] = (uint32_t)__popcll(bk); wm[wave] = (uint32_t)__popcll(bm); }
+      __syncthreads();
+      uint32_t rk = (uint32_t)__popcll(bk & below), rm = (uint32_t)__popcll(bm & below), totK = 0, totM = 0;
+      for (uint32_t w = 0; w < 16u; ++w) { if (w < wave) { rk += wk[w]; rm += wm[w]; } totK += wk[w]; totM += wm[w]; }
+      if (keep) plocEmit(i, j, mutual, keptBase + rk, (int)(nodeBase + mergedBase + rm), clRef, clBox, A.clRef[p ^ 1u], A.clBox[p ^ 1u], A);
+      keptBase += totK; mergedBase += totM;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (rounds < RT_MAX_ROUNDS) A.roundBase[rounds] = nodeBase; else atomicOr(&A.res->error, 1u); }
+    ++rounds; nodeBase += mergedBase; m = keptBase; p ^= 1u;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    A.roundBase[rounds < RT_MAX_ROUNDS ? rounds : RT_MAX_ROUNDS] = nodeBase;
+    A.res->numRounds = rounds < RT_MAX_ROUNDS ? rounds : RT_MAX_ROUNDS;
+    if (n > 1u) A.nodeParent[n - 2u] = -1;      // the last node created is the root
   }
 }
 
@@ -297,14 +424,151 @@ __global__ void emitTop(int count, const int32_t* __restrict__ topList, const in
   top[k] = nd;
 }
 
+// ---- the list of nodes at the tree's top (for the trace kernel's LDS table), on the device -----------------------------------------
+// The first `capacity` 4-wide nodes in breadth-first order (4-wide nodes = the binary nodes of even depth, rtggx_device.h): their list
+// and every node's rank in it (topRank: -1 elsewhere, cleared by the caller).  One workgroup walks the tree level by level; the order
+// is the one a queue would give: a node's internal grandchildren left to right, nodes in list order.
+__global__ void __launch_bounds__(128) planTopKernel(uint32_t capacity, int32_t root, uint32_t numNodes, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
+                                                     int32_t* __restrict__ topList, int32_t* __restrict__ topRank, BuildResult* res) {
+  __shared__ int32_t list[128]; __shared__ uint32_t offs[128]; __shared__ uint32_t sCount, sHead;
+  if (capacity > 128u) capacity = 128u;
+  if (threadIdx.x == 0) { sCount = 0u; sHead = 0u; if (root >= 0 && numNodes > 0u && capacity > 0u) { list[0] = root; sCount = 1u; } }
+  __syncthreads();
+  for (;;) {
+    const uint32_t head = sHead, count = sCount;
+    if (head >= count || count >= capacity) break;
+    int32_t g[4]; uint32_t k = 0;
+    if (head + threadIdx.x < count) {
+      const int32_t v = list[head + threadIdx.x];
+      const int32_t ch[2] = {left[v], right[v]};
+      for (int side = 0; side < 2; ++side) {
+        if (ch[side] < 0) continue;
+        const int32_t gg[2] = {left[ch[side]], right[ch[side]]};
+        for (int q = 0; q < 2; ++q) if (gg[q] >= 0) g[k++] = gg[q];
+      }
+    }
+    offs[threadIdx.x] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < count - head; ++t) { const uint32_t v = offs[t]; offs[t] = run; run += v; } sHead = count; sCount = min(capacity, count + run); }
+    __syncthreads();
+    for (uint32_t q = 0; q < k; ++q) { const uint32_t pos = count + offs[threadIdx.x] + q; if (pos < capacity) list[pos] = g[q]; }
+    __syncthreads();
+  }
+  const uint32_t count = sCount;
+  if (threadIdx.x < count) { topList[threadIdx.x] = list[threadIdx.x]; topRank[list[threadIdx.x]] = (int32_t)threadIdx.x; }
+  if (threadIdx.x == 0) res->topCount = count;
+}
+
+// ---- the refit schedule, on the device ("treelets") -------------------------------------------------------------------------------
+// A bottom-up box refit needs a node's children before the node.  The tree is cut into TREELETS of at most RT_TREELET_NODES internal
+// nodes; one workgroup refits one treelet round by round of the PLOC build (a node's children belong to earlier rounds) with the
+// treelet's boxes in LDS and a workgroup barrier between rounds; what is left above the treelet roots is cut the same way again
+// (level 1, level 2): two launches for the bunny and the dragon, no global synchronisation (refitTreelets below).
+// The cut needs, per node and level, how many nodes of its subtree that level still has to place: cnt[l] of plocEmit.  A node is
+// PENDING at level l if level l - 1 could not place it (cnt[l-1] > RT_TREELET_NODES; at level 0 every node is pending); it ROOTS a
+// treelet of level l if it is pending, its count fits, and its parent's does not.  The treelet is the pending part of its subtree.
+// An item of a treelet: (node, left ref, right ref); a ref is >= 0: position of another item of the same treelet (its box is in LDS);
+// 0xC0000000 | s: leaf slot s (the primitive's box); 0x80000000 | n: node n placed by a lower level (its box is final in nodeBox).
+struct RefitTreelet { uint32_t itemBegin, roundBegin, numRounds, pad; };
+RT_DEV uint32_t treeletBase(const BuildResult* res, int level) { uint32_t b = 0; for (int l = 0; l < level; ++l) b += res->treelets[l]; return b; }
+__global__ void treeletRootsKernel(int numNodes, int level, const uint32_t* __restrict__ cntPrev, const uint32_t* __restrict__ cntCur, const int32_t* __restrict__ nodeParent,
+                                   int32_t* __restrict__ roots, BuildResult* res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numNodes) return;
+  if (level > 0 && cntPrev[i] <= RT_TREELET_NODES) return;      // placed by a lower level
+  const int32_t p = nodeParent[i];
+  if (cntCur[i] > RT_TREELET_NODES) { if (p < 0 && level == RT_TREELET_LEVELS - 1) atomicOr(&res->error, 2u); return; }
+  if (p >= 0 && cntCur[p] <= RT_TREELET_NODES) return;           // an inner node of somebody else's treelet
+  roots[treeletBase(res, level) + atomicAdd(&res->treelets[level], 1u)] = i;
+}
+__global__ void __launch_bounds__(256) buildTreeletsKernel(int level, const uint32_t* __restrict__ cntPrev, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
+                                                           const uint32_t* __restrict__ roundBase, const int32_t* __restrict__ roots,
+                                                           RefitTreelet* __restrict__ treelets, int4* __restrict__ items, uint32_t* __restrict__ rounds, BuildResult* res) {
+  __shared__ int32_t list[RT_TREELET_NODES];
+  __shared__ uint32_t sCount, sHead, sItemBegin, sRoundBegin, waveSum[4];
+  const uint32_t base = treeletBase(res, level), K = res->treelets[level], numRounds = res->numRounds;
+  const auto pending = [&](int32_t x) { return level == 0 || cntPrev[x] > RT_TREELET_NODES; };
+  for (uint32_t k = blockIdx.x; k < K; k += gridDim.x) {
+    // the pending nodes below the root, breadth first
+    if (threadIdx.x == 0) { list[0] = roots[base + k]; sCount = 1u; sHead = 0u; }
+    __syncthreads();
+    for (;;) {
+      const uint32_t head = sHead, count = sCount;
+      if (head >= count) break;
+      __syncthreads();      // everybody has read head / count
+      for (uint32_t idx = head + threadIdx.x; idx < count; idx += 256u) {
+        const int32_t v = list[idx];
+        const int32_t L = left[v], R = right[v];
+        if (L >= 0 && pending(L)) { const uint32_t q = atomicAdd(&sCount, 1u); if (q < RT_TREELET_NODES) list[q] = L; }
+        if (R >= 0 && pending(R)) { const uint32_t q = atomicAdd(&sCount, 1u); if (q < RT_TREELET_NODES) list[q] = R; }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) sHead = count;
+      __syncthreads();
+    }
+    const uint32_t count = min(sCount, (uint32_t)RT_TREELET_NODES);
+    // by node index = by PLOC round (indices are handed out round by round): bitonic sort of the padded list
+    for (uint32_t idx = count + threadIdx.x; idx < RT_TREELET_NODES; idx += 256u) list[idx] = 0x7FFFFFFF;
+    __syncthreads();
+    for (uint32_t kk = 2u; kk <= RT_TREELET_NODES; kk <<= 1)
+      for (uint32_t jj = kk >> 1; jj > 0u; jj >>= 1) {
+        for (uint32_t idx = threadIdx.x; idx < RT_TREELET_NODES; idx += 256u) {
+          const uint32_t ixj = idx ^ jj;
+          if (ixj > idx) {
+            const int32_t a = list[idx], b = list[ixj];
+            const bool asc = (idx & kk) == 0u;
+            if ((a > b) == asc) { list[idx] = b; list[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    if (threadIdx.x == 0) sItemBegin = atomicAdd(&res->itemCursor, count);
+    __syncthreads();
+    const auto position = [&](int32_t node) { uint32_t lo = 0, hi = count; while (lo + 1u < hi) { const uint32_t mid = (lo + hi) >> 1; if (list[mid] <= node) lo = mid; else hi = mid; } return (int32_t)lo; };
+    const auto ref = [&](int32_t ch) -> int32_t {
+      if (ch < 0) return (int32_t)(0xC0000000u | (uint32_t)~ch);
+      if (pending(ch)) return position(ch);
+      return (int32_t)(0x80000000u | (uint32_t)ch);
+    };
+    const auto roundOf = [&](int32_t node) { uint32_t lo = 0, hi = numRounds; while (lo + 1u < hi) { const uint32_t mid = (lo + hi) >> 1; if (roundBase[mid] <= (uint32_t)node) lo = mid; else hi = mid; } return lo; };
+    // items, and the positions at which a new round starts: four consecutive positions per thread, prefix sum over the workgroup
+    uint32_t flags[4], mine = 0;
+    for (uint32_t q = 0; q < 4u; ++q) {
+      const uint32_t idx = threadIdx.x * 4u + q;
+      flags[q] = 0u;
+      if (idx < count) {
+        const int32_t v = list[idx];
+        items[sItemBegin + idx] = make_int4(v, ref(left[v]), ref(right[v]), 0);
+        flags[q] = idx == 0u || roundOf(v) != roundOf(list[idx - 1u]) ? 1u : 0u;
+        mine += flags[q];
+      }
+    }
+    uint32_t inc = mine;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += v; }
+    if (lane == 63u) waveSum[wave] = inc;
+    __syncthreads();
+    uint32_t pos = inc - mine;
+    for (uint32_t w = 0; w < wave; ++w) pos += waveSum[w];
+    const uint32_t total = waveSum[0] + waveSum[1] + waveSum[2] + waveSum[3];
+    if (threadIdx.x == 0) sRoundBegin = atomicAdd(&res->roundCursor, total + 1u);
+    __syncthreads();
+    for (uint32_t q = 0; q < 4u; ++q) if (flags[q]) rounds[sRoundBegin + pos++] = threadIdx.x * 4u + q;
+    if (threadIdx.x == 0) { rounds[sRoundBegin + total] = count; RefitTreelet tl; tl.itemBegin = sItemBegin; tl.roundBegin = sRoundBegin; tl.numRounds = total; tl.pad = 0u; treelets[base + k] = tl; }
+    __syncthreads();
+  }
+}
+
 // ---- refit (rtggx_refit_as): same topology, new vertex positions ---------------------------------------------------------
-// Leaf slot s keeps its primitive (tris[s].prim): rewrite its three vertices and the primitive's box.
-__global__ void refitTris(int n, const float* __restrict__ verts, const uint32_t* __restrict__ idx, BvhTri* __restrict__ tris, float* __restrict__ triBox) {
+// Leaf slot s holds primitive order[s] (the topology's; the record may still hold another topology's): its three vertices and the primitive's box.
+__global__ void refitTris(int n, const uint32_t* __restrict__ order, const float* __restrict__ verts, const uint32_t* __restrict__ idx, BvhTri* __restrict__ tris, float* __restrict__ triBox) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const uint32_t prim = tris[s].prim;
+  const uint32_t prim = order[s];
   float mn[3], mx[3];
-  BvhTri t = tris[s];
+  BvhTri t;
+  t.prim = prim;
+  for (int k = 0; k < 3; ++k) { t.pad0[k] = 0; t.pad1[k] = 0; }
   for (int k = 0; k < 3; ++k) {
     const float a = verts[6 * (size_t)idx[3 * (size_t)prim] + k], b = verts[6 * (size_t)idx[3 * (size_t)prim + 1] + k], c = verts[6 * (size_t)idx[3 * (size_t)prim + 2] + k];
     t.v0[k] = a; t.v1[k] = b; t.v2[k] = c;
@@ -327,14 +591,7 @@ __global__ void treeCostKernel(int numNodes, const float* __restrict__ nodeBox, 
   if ((threadIdx.x & 63) == 0 && a != 0.0f) atomicAdd(cost, a);
 }
 
-// Bottom-up box refit without global synchronisation: TREELETS.  At build time the host cuts the tree into subtrees of at most
-// RT_TREELET_NODES internal nodes (planRefit below); one workgroup refits one treelet, round by round of the PLOC build (a node's
-// children belong to earlier rounds), with the treelet's boxes in LDS and a workgroup barrier between rounds.  What is left above
-// the treelet roots is cut the same way again, until one treelet holds the root: two launches for the bunny and the dragon.
-// A child reference of an item is: >= 0 the position of another item of the same treelet (its box is in LDS);
-// 0xC0000000 | s leaf slot s (the primitive's box); 0x80000000 | n node n of an earlier level (its box is final in nodeBox).
-#define RT_TREELET_NODES 1024
-struct RefitTreelet { uint32_t itemBegin, roundBegin, numRounds, pad; };
+// One workgroup refits one treelet (see "the refit schedule" above): round by round, the treelet's boxes in LDS.
 __global__ void __launch_bounds__(256) refitTreelets(const RefitTreelet* __restrict__ treelets, const int4* __restrict__ items, const uint32_t* __restrict__ roundOfs,
                                                      const uint32_t* __restrict__ order, const float* __restrict__ triBox, float* __restrict__ nodeBox) {
   __shared__ float box[RT_TREELET_NODES][6];
@@ -385,247 +642,294 @@ template <typename T> static void freeAliased(T* (&buf)[RT_SETS]) {
   for (int i = 0; i < RT_SETS; ++i) { bool dup = false; for (int j = 0; j < i; ++j) dup = dup || buf[j] == buf[i]; if (!dup && buf[i]) hipFree(buf[i]); }
   for (auto& b : buf) b = nullptr;
 }
-void freeBuildProducts(MeshDev& m) {
-  hipFree(m.order); hipFree(m.left); hipFree(m.right); hipFree(m.nodeParent); hipFree(m.leafParent); hipFree(m.nodeBox); hipFree(m.triBox); hipFree(m.dTreelets); hipFree(m.dRefitItems); hipFree(m.dRefitRounds);
-  m.order = nullptr; m.left = m.right = m.nodeParent = m.leafParent = nullptr; m.nodeBox = m.triBox = nullptr; m.dTreelets = nullptr; m.dRefitItems = nullptr; m.dRefitRounds = nullptr;
-  m.roundBase.clear(); m.refitLevels.clear();
-  freeAliased(m.nodesBuf); freeAliased(m.nodes4Buf); freeAliased(m.trisBuf); freeAliased(m.topBuf);
-  hipFree(m.topList); hipFree(m.topRank); m.topList = m.topRank = nullptr; m.topCount = 0;
-  m.nodes = nullptr; m.nodes4 = nullptr; m.tris = nullptr; m.top = nullptr;
+static void freeTopo(BvhTopo& t) {
+  hipFree(t.order); hipFree(t.left); hipFree(t.right); hipFree(t.nodeParent); hipFree(t.leafParent); hipFree(t.nodeBox); hipFree(t.triBox);
+  for (auto& c : t.cnt) { hipFree(c); c = nullptr; }
+  hipFree(t.roundBase); hipFree(t.dTreelets); hipFree(t.dRefitItems); hipFree(t.dRefitRounds); hipFree(t.treeletRoots); hipFree(t.topList); hipFree(t.topRank); hipFree(t.dResult);
+  if (t.hResult) hipHostFree(t.hResult);
+  t = BvhTopo{};
 }
+
+// ---- a build as a list of launches ------------------------------------------------------------------------------------------------
+struct BuildScratch {
+  uint32_t *codes[2] = {}, *order2 = nullptr, *hist = nullptr, *bounds = nullptr, *arrive = nullptr;
+  int32_t *clRef[2] = {}, *nn = nullptr; float* clBox[2] = {}; uint2* blockCounts = nullptr; PlocState* state = nullptr;
+  float* vertsSnapshot = nullptr;      // a rebuild beside the frames works on a copy of the vertices it started from
+};
+struct BuildJob {
+  BvhTopo topo;                        // what the build produces (swapped with the mesh's when it has ended)
+  BuildScratch s;
+  std::vector<std::function<void(hipStream_t)>> steps;      // one kernel launch (or copy) each
+  size_t next = 0;
+  hipEvent_t done = nullptr;
+  bool active = false, allIssued = false;
+  uint32_t numTris = 0, numVerts = 0;
+};
+static void freeScratch(BuildScratch& s) {
+  hipFree(s.codes[0]); hipFree(s.codes[1]); hipFree(s.order2); hipFree(s.hist); hipFree(s.bounds); hipFree(s.arrive);
+  hipFree(s.clRef[0]); hipFree(s.clRef[1]); hipFree(s.nn); hipFree(s.clBox[0]); hipFree(s.clBox[1]); hipFree(s.blockCounts); hipFree(s.state); hipFree(s.vertsSnapshot);
+  s = BuildScratch{};
+}
+void freeBuildProducts(MeshDev& m) {
+  if (m.job) { if (m.job->done) hipEventDestroy(m.job->done); freeTopo(m.job->topo); freeScratch(m.job->s); delete m.job; m.job = nullptr; }
+  freeTopo(m.topo);
+  freeAliased(m.nodesBuf); freeAliased(m.nodes4Buf); freeAliased(m.trisBuf); freeAliased(m.topBuf);
+  m.nodes = nullptr; m.nodes4 = nullptr; m.tris = nullptr; m.top = nullptr; m.topCount = 0;
+  for (auto& t : m.topCountBuf) t = 0;
+}
+static int allocTopo(BvhTopo& t, uint32_t n) {
+  const size_t nn = n > 1 ? n : 2;
+  t.numTris = n;
+  RT_HIP(hipMalloc(&t.order, 4 * nn)); RT_HIP(hipMalloc(&t.left, 4 * nn)); RT_HIP(hipMalloc(&t.right, 4 * nn));
+  RT_HIP(hipMalloc(&t.nodeParent, 4 * nn)); RT_HIP(hipMalloc(&t.leafParent, 4 * nn));
+  RT_HIP(hipMalloc(&t.nodeBox, 24 * nn)); RT_HIP(hipMalloc(&t.triBox, 24 * nn));
+  for (auto& c : t.cnt) RT_HIP(hipMalloc(&c, 4 * nn));
+  RT_HIP(hipMalloc(&t.roundBase, 4 * (RT_MAX_ROUNDS + 1)));
+  RT_HIP(hipMalloc(&t.dTreelets, sizeof(RefitTreelet) * nn)); RT_HIP(hipMalloc(&t.dRefitItems, sizeof(int4) * nn)); RT_HIP(hipMalloc(&t.dRefitRounds, 4 * (2 * nn + 64)));
+  RT_HIP(hipMalloc(&t.treeletRoots, 4 * nn));
+  RT_HIP(hipMalloc(&t.topList, 4 * 128)); RT_HIP(hipMalloc(&t.topRank, 4 * nn));
+  RT_HIP(hipMalloc(&t.dResult, sizeof(BuildResult))); RT_HIP(hipHostMalloc(&t.hResult, sizeof(BuildResult)));
+  memset(t.hResult, 0, sizeof(BuildResult));
+  return 0;
+}
+static int allocScratch(BuildScratch& s, uint32_t n, uint32_t nv, bool snapshot) {
+  const size_t nn = n > 1 ? n : 2, nb = (n + 255) / 256;
+  RT_HIP(hipMalloc(&s.codes[0], 4 * nn)); RT_HIP(hipMalloc(&s.codes[1], 4 * nn)); RT_HIP(hipMalloc(&s.order2, 4 * nn));
+  RT_HIP(hipMalloc(&s.hist, 4 * 256 * nb)); RT_HIP(hipMalloc(&s.bounds, 4 * 8)); RT_HIP(hipMalloc(&s.arrive, 4 * (nn + 1)));
+  RT_HIP(hipMalloc(&s.clRef[0], 4 * nn)); RT_HIP(hipMalloc(&s.clRef[1], 4 * nn)); RT_HIP(hipMalloc(&s.nn, 4 * nn));
+  RT_HIP(hipMalloc(&s.clBox[0], 24 * nn)); RT_HIP(hipMalloc(&s.clBox[1], 24 * nn));
+  RT_HIP(hipMalloc(&s.blockCounts, sizeof(uint2) * nb)); RT_HIP(hipMalloc(&s.state, 2 * sizeof(PlocState)));
+  if (snapshot) RT_HIP(hipMalloc(&s.vertsSnapshot, sizeof(float) * 6 * (size_t)nv));
+  return 0;
+}
+// How many multi-workgroup rounds the host issues: until ~2048 clusters are expected to be left, at the ~0.62 a round keeps on the bunny
+// and the dragon, plus two (a round that keeps more only leaves plocFinal more to do).
+static uint32_t plocRoundsFor(uint32_t n) {
+  uint32_t rounds = 0; double m = (double)n;
+  while (m > 2048.0) { m *= 0.66; ++rounds; }
+  return rounds ? rounds + 2u : 0u;
+}
+
+// The launches of one build of mesh `slot` from `verts` (device; the job's snapshot when `snapshotFrom` is given), into job.topo.
+static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const float* verts, const float* snapshotFrom) {
+  MeshDev& m = c->mesh[slot];
+  const uint32_t n = job.numTris, nv = job.numVerts, nb = (n + 255) / 256;
+  BvhTopo& t = job.topo; BuildScratch& s = job.s;
+  auto& steps = job.steps;
+  steps.clear(); job.next = 0; job.allIssued = false;
+  const uint32_t* indices = m.indices;
+  if (snapshotFrom) { steps.push_back([=](hipStream_t st) { hipMemcpyAsync(s.vertsSnapshot, snapshotFrom, sizeof(float) * 6 * (size_t)nv, hipMemcpyDeviceToDevice, st); }); verts = s.vertsSnapshot; }
+  steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(buildBegin, dim3(1), dim3(64), 0, st, n, s.state, t.dResult, s.bounds); });
+  steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(boundsKernel, dim3(std::min<uint32_t>((nv + 255) / 256, 512u)), dim3(256), 0, st, verts, nv, s.bounds); });
+  steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(mortonKernel, dim3(nb), dim3(256), 0, st, verts, indices, n, (const uint32_t*)s.bounds, s.codes[0], t.order, t.triBox); });
+  // radix sort: (codes[0], t.order) <-> (codes[1], s.order2); four passes end where they began
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8, cur = pass & 1;
+    uint32_t *kin = s.codes[cur], *kout = s.codes[cur ^ 1], *vin = cur ? s.order2 : t.order, *vout = cur ? t.order : s.order2;
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(radixHist, dim3(nb), dim3(256), 0, st, (const uint32_t*)kin, n, shift, s.hist, nb); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, st, s.hist, 256u * nb); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(radixScatter, dim3(nb), dim3(256), 0, st, (const uint32_t*)kin, (const uint32_t*)vin, n, shift, (const uint32_t*)s.hist, nb, kout, vout); });
+  }
+  t.root = n == 1 ? ~0 : -1; t.refittable = false;
+  if (n > 1) {
+    static const bool radixTree = getenv("RTGGX_BVH_RADIX_TREE") != nullptr;     // A/B switch: the Karras tree this build started with (cannot be refitted)
+    const int radius = getenv("RTGGX_PLOC_RADIUS") ? atoi(getenv("RTGGX_PLOC_RADIUS")) : RT_PLOC_RADIUS;
+    if (radixTree) {
+      t.root = 0;
+      steps.push_back([=](hipStream_t st) { hipMemsetAsync(s.arrive, 0, 4 * ((size_t)n + 1), st); });
+      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, st, (const uint32_t*)s.codes[0], (int)n, t.left, t.right, t.nodeParent, t.leafParent); });
+      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, st, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right,
+                                                               (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent, t.nodeBox, s.arrive); });
+    } else {
+      t.root = (int32_t)n - 2; t.refittable = true;      // the last node created
+      PlocArrays A;
+      A.clRef[0] = s.clRef[0]; A.clRef[1] = s.clRef[1]; A.clBox[0] = s.clBox[0]; A.clBox[1] = s.clBox[1]; A.nn = s.nn;
+      A.left = t.left; A.right = t.right; A.nodeParent = t.nodeParent; A.leafParent = t.leafParent; A.nodeBox = t.nodeBox;
+      for (int l = 0; l < RT_TREELET_LEVELS; ++l) A.cnt[l] = t.cnt[l];
+      A.roundBase = t.roundBase; A.res = t.dResult;
+      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocInit, dim3(nb), dim3(256), 0, st, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, s.clRef[0], s.clBox[0]); });
+      const uint32_t rounds = plocRoundsFor(n);
+      for (uint32_t r = 0; r < rounds; ++r) {
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocNearest, dim3(nb), dim3(256), 0, st, (const PlocState*)s.state, r, radius, A); });
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocCount, dim3(nb), dim3(256), 0, st, (const PlocState*)s.state, r, (const int32_t*)s.nn, s.blockCounts); });
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocScatter, dim3(nb), dim3(256), 0, st, s.state, r, (const uint2*)s.blockCounts, A); });
+      }
+      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocFinal, dim3(1), dim3(1024), 0, st, (const PlocState*)s.state, rounds, radius, n, A); });
+      // the refit schedule
+      const uint32_t treeletGrid = std::min<uint32_t>(std::max<uint32_t>((n + RT_TREELET_NODES / 4 - 1) / (RT_TREELET_NODES / 4), 1u), 2048u);
+      for (int l = 0; l < RT_TREELET_LEVELS; ++l) {
+        const uint32_t* prev = l ? t.cnt[l - 1] : nullptr; const uint32_t* cur = t.cnt[l];
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(treeletRootsKernel, dim3(nb), dim3(256), 0, st, (int)n - 1, l, prev, cur, (const int32_t*)t.nodeParent, t.treeletRoots, t.dResult); });
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(buildTreeletsKernel, dim3(l ? 64u : treeletGrid), dim3(256), 0, st, l, prev, (const int32_t*)t.left, (const int32_t*)t.right, (const uint32_t*)t.roundBase,
+                                                                 (const int32_t*)t.treeletRoots, (RefitTreelet*)t.dTreelets, (int4*)t.dRefitItems, t.dRefitRounds, t.dResult); });
+      }
+    }
+    const uint32_t topCap = slot == 0 ? RT_TOP_SLOT0 : RT_TOP_SLOT1;
+    const int32_t root = t.root;
+    steps.push_back([=](hipStream_t st) { hipMemsetAsync(t.topRank, 0xFF, 4 * (size_t)(n - 1), st); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(planTopKernel, dim3(1), dim3(128), 0, st, topCap, root, n - 1, (const int32_t*)t.left, (const int32_t*)t.right, t.topList, t.topRank, t.dResult); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, st, (int)n, (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent, &t.dResult->depth); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(treeCostKernel, dim3((n - 1 + 255) / 256), dim3(256), 0, st, (int)n - 1, (const float*)t.nodeBox, &t.dResult->cost); });
+  }
+  steps.push_back([=](hipStream_t st) { hipMemcpyAsync(t.hResult, t.dResult, sizeof(BuildResult), hipMemcpyDeviceToHost, st); });
+}
+
+// The tree arrays of input set `set` from a topology and that set's vertices: leaf triangles, 64-byte binary nodes (for the oracle /
+// tests), their 4-wide collapse (for the trace kernel), the table of the tree's top.  `full`: the arrays held another topology (or
+// nothing) before: unused entries of the sparse 4-wide array are cleared.
+static void emitTree(MeshDev& m, const BvhTopo& t, uint32_t set, bool full, hipStream_t s) {
+  const uint32_t n = t.numTris, nb = (n + 255) / 256;
+  if (n > 1) {
+    if (full) hipMemsetAsync(m.nodes4Buf[set], 0, sizeof(Bvh4Node) * (size_t)(n - 1), s);
+    hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right, (const float*)t.nodeBox, m.nodesBuf[set]);
+    hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right,
+                       (const int32_t*)t.nodeParent, (const float*)t.nodeBox, m.nodes4Buf[set]);
+    if (t.result.topCount) hipLaunchKernelGGL(emitTop, dim3((t.result.topCount + 63) / 64), dim3(64), 0, s, (int)t.result.topCount, (const int32_t*)t.topList, (const int32_t*)t.topRank, (const Bvh4Node*)m.nodes4Buf[set], m.topBuf[set]);
+  }
+  m.topCountBuf[set] = n > 1 ? t.result.topCount : 0u;
+}
+
+static int harvest(MeshDev& m, BvhTopo& t, uint32_t slot) {
+  t.result = *t.hResult;
+  if (t.result.error & 1u) { setError("BVH build of mesh %u: more than %u clustering rounds", slot, (unsigned)RT_MAX_ROUNDS); return -3; }
+  if (t.result.error & 2u) { setError("BVH build of mesh %u: the refit schedule would need more than %d treelet levels", slot, RT_TREELET_LEVELS); return -3; }
+  if (t.result.depth > m.depth) m.depth = t.result.depth;
+  return 0;
+}
+
+// rtggx_build_as: every launch of the build on `s`, the tree arrays of all input sets, ONE wait.
+int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
+  MeshDev& m = c->mesh[slot];
+  const uint32_t n = m.numTris;
+  m.root = -1; m.depth = 0;
+  freeBuildProducts(m);       // also the nodes / leaf triangles of every input set, and a rebuild in progress (the caller has synchronised)
+  if (n == 0) return 0;
+  // a mesh that deforms is built from its newest shape
+  const float* verts = m.deforming ? m.vertsBuf[m.latestSet] : m.verts;
+  BuildJob job; job.numTris = n; job.numVerts = m.numVerts;
+  { const int r = allocTopo(job.topo, n); if (r) return r; }
+  { const int r = allocScratch(job.s, n, m.numVerts, false); if (r) return r; }
+  planBuildSteps(c, slot, job, verts, nullptr);
+  for (auto& step : job.steps) step(s);
+  RT_HIP(hipGetLastError());
+  RT_HIP(hipStreamSynchronize(s));
+  m.topo = job.topo; job.topo = BvhTopo{};
+  freeScratch(job.s);
+  { const int r = harvest(m, m.topo, slot); if (r) return r; }
+  m.root = m.topo.root;
+  m.builtCost = m.lastCost = m.topo.result.cost; m.costInFlight = false;
+  // the tree arrays: one allocation aliased by all input sets while the mesh is static, one per set once it deforms
+  const size_t nn = n > 1 ? n - 1 : 1, topCap = slot == 0 ? RT_TOP_SLOT0 : RT_TOP_SLOT1;
+  const int sets = m.deforming ? RT_SETS : 1;
+  for (int i = 0; i < sets; ++i) {
+    RT_HIP(hipMalloc(&m.trisBuf[i], sizeof(BvhTri) * (size_t)n)); RT_HIP(hipMalloc(&m.nodesBuf[i], sizeof(BvhNode) * nn)); RT_HIP(hipMalloc(&m.nodes4Buf[i], sizeof(Bvh4Node) * nn));
+    RT_HIP(hipMalloc(&m.topBuf[i], sizeof(Bvh4Node) * topCap));
+  }
+  for (int i = sets; i < RT_SETS; ++i) { m.trisBuf[i] = m.trisBuf[0]; m.nodesBuf[i] = m.nodesBuf[0]; m.nodes4Buf[i] = m.nodes4Buf[0]; m.topBuf[i] = m.topBuf[0]; }
+  ++m.topoVersion;
+  for (int i = 0; i < sets; ++i) {
+    const float* v = m.deforming ? m.vertsBuf[i] : m.verts;
+    if (m.deforming && m.topo.refittable) { const int r = refitLbvh(c, slot, (uint32_t)i, s); if (r) return r; }      // every set's tree from that set's own vertices
+    else {
+      hipLaunchKernelGGL(emitTris, dim3((n + 255) / 256), dim3(256), 0, s, (int)n, (const uint32_t*)m.topo.order, v, (const uint32_t*)m.indices, m.trisBuf[i]);
+      emitTree(m, m.topo, (uint32_t)i, true, s);
+    }
+    m.topoVersionOfSet[i] = m.topoVersion;
+  }
+  for (int i = sets; i < RT_SETS; ++i) { m.topCountBuf[i] = m.topCountBuf[0]; m.topoVersionOfSet[i] = m.topoVersion; }
+  RT_HIP(hipGetLastError());
+  RT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- a rebuild beside the frames (meshes that deform) -------------------------------------------------------------------------------
+// A refit keeps the topology the last build chose for ANOTHER shape; when the tree's cost has drifted (capi.hip rtggx_refit_as) the mesh
+// is built anew from the vertices of input set `set` -- copied first: the set moves on --, a few launches per frame on the stream the
+// refits run on, behind the frame's refit.  When the last launch has ended (the host polls an event at the start of a frame) the new
+// topology replaces the old one: the frame's refit, a moment later on the same stream, is the first to use it.  The buffers of the two
+// topologies and the build's scratch memory are allocated once per mesh and swapped; nothing is freed, nothing waits.
+int startRebuild(rtggx_context* c, uint32_t slot, uint32_t set) {
+  MeshDev& m = c->mesh[slot];
+  if (!m.deforming || !m.topo.refittable || m.numTris < 2) return 0;
+  if (!m.job) {
+    m.job = new BuildJob();
+    m.job->numTris = m.numTris; m.job->numVerts = m.numVerts;
+    { const int r = allocTopo(m.job->topo, m.numTris); if (r) return r; }
+    { const int r = allocScratch(m.job->s, m.numTris, m.numVerts, true); if (r) return r; }
+    RT_HIP(hipEventCreateWithFlags(&m.job->done, hipEventDisableTiming));
+  }
+  BuildJob& job = *m.job;
+  if (job.active) return 0;
+  planBuildSteps(c, slot, job, nullptr, m.vertsBuf[set]);
+  job.active = true;
+  return 1;      // started
+}
+int continueRebuild(rtggx_context* c, uint32_t slot, hipStream_t s, uint32_t maxSteps, bool* swapped) {
+  MeshDev& m = c->mesh[slot];
+  *swapped = false;
+  if (!m.job || !m.job->active) return 0;
+  BuildJob& job = *m.job;
+  if (job.allIssued) {
+    if (hipEventQuery(job.done) != hipSuccess) return 0;      // still running
+    job.active = false;
+    { const int r = harvest(m, job.topo, slot); if (r) return r; }
+    std::swap(m.topo, job.topo);
+    m.root = m.topo.root; m.builtCost = m.lastCost = m.topo.result.cost; m.costInFlight = false;
+    ++m.topoVersion; ++m.rebuilds;
+    *swapped = true;
+    return 0;
+  }
+  for (uint32_t k = 0; k < maxSteps && job.next < job.steps.size(); ++k) job.steps[job.next++](s);
+  RT_HIP(hipGetLastError());
+  if (job.next == job.steps.size()) { RT_HIP(hipEventRecord(job.done, s)); job.allIssued = true; }
+  return 0;
+}
+void abandonRebuild(rtggx_context* c, uint32_t slot) {
+  MeshDev& m = c->mesh[slot];
+  if (m.job && m.job->active) { hipDeviceSynchronize(); m.job->active = false; }
+}
+
 
 static int launchTreeCost(MeshDev& m, hipStream_t s) {
   if (!m.dCost) { RT_HIP(hipMalloc(&m.dCost, 4)); RT_HIP(hipHostMalloc(&m.hCost, 4)); *m.hCost = 0.0f; RT_HIP(hipEventCreateWithFlags(&m.evCost, hipEventDisableTiming)); }
   RT_HIP(hipMemsetAsync(m.dCost, 0, 4, s));
   const int numNodes = (int)m.numTris - 1;
-  hipLaunchKernelGGL(treeCostKernel, dim3((numNodes + 255) / 256), dim3(256), 0, s, numNodes, m.nodeBox, m.dCost);
+  hipLaunchKernelGGL(treeCostKernel, dim3((numNodes + 255) / 256), dim3(256), 0, s, numNodes, (const float*)m.topo.nodeBox, m.dCost);
   return 0;
 }
 
-// New boxes for the existing tree from the vertex buffer of input set `set`, into that set's leaf triangles and nodes: the leaf
-// triangles, the node boxes treelet level by treelet level (refitTreelets), the
-// 64-byte binary nodes (for the oracle / tests) and their 4-wide collapse (for the trace kernel), every 8th time the tree's cost.
+// New boxes for the existing topology from the vertex buffer of input set `set`, into that set's leaf triangles and nodes: the fat
+// triangles, the leaf triangles + per-primitive boxes, the node boxes treelet level by treelet level (refitTreelets), the
+// 64-byte binary nodes (for the oracle / tests) and their 4-wide collapse (for the trace kernel), every 4th time the tree's cost.
 // No host round trip; everything on stream `s` (stream R, beside whatever the other streams are doing).
 int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
   MeshDev& m = c->mesh[slot];
+  const BvhTopo& t = m.topo;
   const uint32_t n = m.numTris;
   if (n == 0 || !m.trisBuf[set]) return 0;
   const uint32_t nb = (n + 255) / 256;
-  if (!m.triBox || (n > 1 && m.refitLevels.empty())) { setError("rtggx_refit_as: mesh %u has no PLOC build to refit (RTGGX_BVH_RADIX_TREE builds cannot be refitted)", slot); return -1; }
+  if (!t.triBox || (n > 1 && !t.refittable)) { setError("rtggx_refit_as: mesh %u has no PLOC build to refit (RTGGX_BVH_RADIX_TREE builds cannot be refitted)", slot); return -1; }
   { const int r = buildFatTris(c, slot, set, s); if (r) return r; }
-  hipLaunchKernelGGL(refitTris, dim3(nb), dim3(256), 0, s, (int)n, (const float*)m.vertsBuf[set], (const uint32_t*)m.indices, m.trisBuf[set], m.triBox);
+  hipLaunchKernelGGL(refitTris, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)m.vertsBuf[set], (const uint32_t*)m.indices, m.trisBuf[set], t.triBox);
   if (n > 1) {
-    for (const auto& lv : m.refitLevels)      // (first treelet, count): level after level
-      hipLaunchKernelGGL(refitTreelets, dim3(lv.second), dim3(256), 0, s, (const RefitTreelet*)m.dTreelets + lv.first, (const int4*)m.dRefitItems, (const uint32_t*)m.dRefitRounds,
-                         (const uint32_t*)m.order, (const float*)m.triBox, m.nodeBox);
-    hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right, (const float*)m.nodeBox, m.nodesBuf[set]);
-    hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)m.order, (const float*)m.triBox, (const int32_t*)m.left, (const int32_t*)m.right,
-                       (const int32_t*)m.nodeParent, (const float*)m.nodeBox, m.nodes4Buf[set]);
-    if (m.topCount) hipLaunchKernelGGL(emitTop, dim3((m.topCount + 63) / 64), dim3(64), 0, s, (int)m.topCount, (const int32_t*)m.topList, (const int32_t*)m.topRank, (const Bvh4Node*)m.nodes4Buf[set], m.topBuf[set]);
-    if (!m.costInFlight && (m.refits & 7u) == 0u) {
-      { const int r = launchTreeCost(m, s); if (r) return r; }
-      RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s));
-      RT_HIP(hipEventRecord(m.evCost, s));
-      m.costInFlight = true;
+    uint32_t first = 0;
+    for (int l = 0; l < RT_TREELET_LEVELS; ++l) {      // level after level
+      const uint32_t k = t.result.treelets[l];
+      if (k) hipLaunchKernelGGL(refitTreelets, dim3(k), dim3(256), 0, s, (const RefitTreelet*)t.dTreelets + first, (const int4*)t.dRefitItems, (const uint32_t*)t.dRefitRounds,
+                                (const uint32_t*)t.order, (const float*)t.triBox, t.nodeBox);
+      first += k;
     }
+  }
+  emitTree(m, t, set, m.topoVersionOfSet[set] != m.topoVersion, s);
+  m.topoVersionOfSet[set] = m.topoVersion;
+  if (n > 1 && !m.costInFlight && (m.refits & 3u) == 0u) {
+    { const int r = launchTreeCost(m, s); if (r) return r; }
+    RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipEventRecord(m.evCost, s));
+    m.costInFlight = true;
   }
   ++m.refits;
   RT_HIP(hipGetLastError());
-  return 0;
-}
-
-// The first `capacity` 4-wide nodes in breadth-first order (4-wide nodes = the binary nodes of even depth, rtggx_device.h): their
-// list, every node's rank in it, and the table emitTop makes of them.  Host side, at build time.
-static int planTop(MeshDev& m, uint32_t capacity, const std::vector<int32_t>& left, const std::vector<int32_t>& right, hipStream_t s) {
-  const int numNodes = (int)m.numTris - 1;
-  std::vector<int32_t> list, rank(numNodes, -1);
-  if (m.root >= 0) list.push_back(m.root);
-  for (size_t head = 0; head < list.size() && list.size() < capacity; ++head) {      // breadth first: `list` is the queue
-    const int32_t v = list[head];
-    const int32_t ch[2] = {left[v], right[v]};
-    for (int side = 0; side < 2; ++side) {
-      if (ch[side] < 0) continue;
-      const int32_t g[2] = {left[ch[side]], right[ch[side]]};
-      for (int k = 0; k < 2; ++k) if (g[k] >= 0 && list.size() < capacity) list.push_back(g[k]);
-    }
-  }
-  for (size_t k = 0; k < list.size(); ++k) rank[list[k]] = (int32_t)k;
-  m.topCount = (uint32_t)list.size();
-  if (m.topCount == 0) return 0;
-  RT_HIP(hipMalloc(&m.topList, 4 * list.size())); RT_HIP(hipMalloc(&m.topRank, 4 * (size_t)numNodes)); RT_HIP(hipMalloc(&m.topBuf[0], sizeof(Bvh4Node) * list.size()));
-  for (int i = 1; i < RT_SETS; ++i) m.topBuf[i] = m.topBuf[0];
-  m.top = m.topBuf[0];
-  RT_HIP(hipMemcpyAsync(m.topList, list.data(), 4 * list.size(), hipMemcpyHostToDevice, s)); RT_HIP(hipMemcpyAsync(m.topRank, rank.data(), 4 * (size_t)numNodes, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(emitTop, dim3((m.topCount + 63) / 64), dim3(64), 0, s, (int)m.topCount, (const int32_t*)m.topList, (const int32_t*)m.topRank, (const Bvh4Node*)m.nodes4, m.topBuf[0]);
-  RT_HIP(hipStreamSynchronize(s));      // list / rank are host vectors
-  return 0;
-}
-
-// The refit schedule of a freshly built PLOC tree (host side; the build is synchronous anyway).  left / right: the children of the
-// numNodes internal nodes as the build left them (>= 0 node, < 0 ~leaf slot); PLOC hands out node indices round by round, so a
-// child's index is smaller than its parent's and roundBase tells a node's round.
-static int planRefit(MeshDev& m, const std::vector<int32_t>& left, const std::vector<int32_t>& right, hipStream_t s) {
-  const int numNodes = (int)m.numTris - 1;
-  std::vector<int32_t> parent(numNodes, -1), roundOf(numNodes, 0);
-  for (int i = 0; i < numNodes; ++i) { if (left[i] >= 0) parent[left[i]] = i; if (right[i] >= 0) parent[right[i]] = i; }
-  for (size_t k = 0; k + 1 < m.roundBase.size(); ++k) for (uint32_t i = m.roundBase[k]; i < m.roundBase[k + 1]; ++i) roundOf[i] = (int32_t)k;
-  std::vector<uint8_t> pending(numNodes, 1);      // nodes no level has taken yet
-  std::vector<uint32_t> cnt(numNodes);
-  std::vector<int32_t> local(numNodes, -1);
-  std::vector<RefitTreelet> treelets; std::vector<int4> items; std::vector<uint32_t> rounds;
-  m.refitLevels.clear();
-  int remaining = numNodes;
-  while (remaining > 0) {
-    // pending nodes in each subtree (children come first in index order)
-    for (int i = 0; i < numNodes; ++i) {
-      cnt[i] = pending[i] ? 1u : 0u;
-      if (pending[i]) { if (left[i] >= 0) cnt[i] += cnt[left[i]]; if (right[i] >= 0) cnt[i] += cnt[right[i]]; }
-    }
-    const uint32_t firstTreelet = (uint32_t)treelets.size();
-    for (int root = 0; root < numNodes; ++root) {
-      if (!pending[root] || cnt[root] > RT_TREELET_NODES) continue;
-      if (parent[root] >= 0 && cnt[parent[root]] <= RT_TREELET_NODES) continue;      // an inner node of somebody else's treelet
-      // the pending nodes below `root`, by PLOC round (then by index: deterministic)
-      std::vector<int32_t> nodes, stack{root};
-      while (!stack.empty()) {
-        const int32_t v = stack.back(); stack.pop_back();
-        nodes.push_back(v);
-        if (left[v] >= 0 && pending[left[v]]) stack.push_back(left[v]);
-        if (right[v] >= 0 && pending[right[v]]) stack.push_back(right[v]);
-      }
-      std::sort(nodes.begin(), nodes.end(), [&](int32_t a, int32_t b) { return roundOf[a] != roundOf[b] ? roundOf[a] < roundOf[b] : a < b; });
-      RefitTreelet tl{(uint32_t)items.size(), (uint32_t)rounds.size(), 0u, 0u};
-      for (size_t k = 0; k < nodes.size(); ++k) local[nodes[k]] = (int32_t)k;
-      for (size_t k = 0; k < nodes.size(); ++k) {
-        if (k == 0 || roundOf[nodes[k]] != roundOf[nodes[k - 1]]) { rounds.push_back((uint32_t)k); ++tl.numRounds; }
-        const int32_t v = nodes[k];
-        const auto ref = [&](int32_t ch) -> int32_t {
-          if (ch < 0) return (int32_t)(0xC0000000u | (uint32_t)~ch);                        // leaf slot
-          if (pending[ch]) return local[ch];                                                // same treelet (its subtree is closed)
-          return (int32_t)(0x80000000u | (uint32_t)ch);                                     // finished by an earlier level
-        };
-        items.push_back(make_int4(v, ref(left[v]), ref(right[v]), 0));
-      }
-      rounds.push_back((uint32_t)nodes.size());
-      treelets.push_back(tl);
-      for (int32_t v : nodes) { pending[v] = 2; }      // taken by this level (still "pending" for the scan of this level's other roots)
-      remaining -= (int)nodes.size();
-    }
-    for (int i = 0; i < numNodes; ++i) if (pending[i] == 2) pending[i] = 0;
-    if (treelets.size() == firstTreelet) { setError("planRefit: no progress with %d nodes left", remaining); return -3; }
-    m.refitLevels.push_back({firstTreelet, (uint32_t)treelets.size() - firstTreelet});
-  }
-  RT_HIP(hipMalloc(&m.dTreelets, sizeof(RefitTreelet) * treelets.size()));
-  RT_HIP(hipMalloc(&m.dRefitItems, sizeof(int4) * items.size()));
-  RT_HIP(hipMalloc(&m.dRefitRounds, 4 * rounds.size()));
-  RT_HIP(hipMemcpyAsync(m.dTreelets, treelets.data(), sizeof(RefitTreelet) * treelets.size(), hipMemcpyHostToDevice, s));
-  RT_HIP(hipMemcpyAsync(m.dRefitItems, items.data(), sizeof(int4) * items.size(), hipMemcpyHostToDevice, s));
-  RT_HIP(hipMemcpyAsync(m.dRefitRounds, rounds.data(), 4 * rounds.size(), hipMemcpyHostToDevice, s));
-  RT_HIP(hipStreamSynchronize(s));      // the host vectors go out of scope
-  return 0;
-}
-
-int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
-  MeshDev& m = c->mesh[slot];
-  const uint32_t n = m.numTris;
-  m.root = -1; m.depth = 0;
-  freeBuildProducts(m);       // also the nodes / leaf triangles of every input set
-  if (n == 0) return 0;
-  RT_HIP(hipMalloc(&m.tris, sizeof(BvhTri) * (size_t)n));
-  RT_HIP(hipMalloc(&m.nodes, sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)));
-  RT_HIP(hipMalloc(&m.nodes4, sizeof(Bvh4Node) * (size_t)(n > 1 ? n - 1 : 1)));
-  RT_HIP(hipMemsetAsync(m.nodes4, 0, sizeof(Bvh4Node) * (size_t)(n > 1 ? n - 1 : 1), s));
-  for (int i = 0; i < RT_SETS; ++i) { m.nodesBuf[i] = m.nodes; m.nodes4Buf[i] = m.nodes4; m.trisBuf[i] = m.tris; }     // one allocation for all input sets until the mesh deforms
-
-  const float* mn = m.bmin; const float* mx = m.bmax;   // vertex bounds recorded by rtggx_set_mesh
-  float3 bmin = make_float3(mn[0], mn[1], mn[2]);
-  float3 invExt = make_float3(mx[0] > mn[0] ? 1.0f / (mx[0] - mn[0]) : 0.0f, mx[1] > mn[1] ? 1.0f / (mx[1] - mn[1]) : 0.0f, mx[2] > mn[2] ? 1.0f / (mx[2] - mn[2]) : 0.0f);
-
-  const uint32_t nb = (n + 255) / 256;
-  uint32_t *codes[2], *order[2], *hist; float *triBox, *nodeBox; int32_t *left, *right, *nodeParent, *leafParent; uint32_t* arrive;
-  RT_HIP(hipMalloc(&codes[0], 4 * (size_t)n)); RT_HIP(hipMalloc(&codes[1], 4 * (size_t)n));
-  RT_HIP(hipMalloc(&order[0], 4 * (size_t)n)); RT_HIP(hipMalloc(&order[1], 4 * (size_t)n));
-  RT_HIP(hipMalloc(&hist, 4 * (size_t)256 * nb));
-  RT_HIP(hipMalloc(&triBox, 4 * 6 * (size_t)n)); RT_HIP(hipMalloc(&nodeBox, 4 * 6 * (size_t)n));
-  RT_HIP(hipMalloc(&left, 4 * (size_t)n)); RT_HIP(hipMalloc(&right, 4 * (size_t)n));
-  RT_HIP(hipMalloc(&nodeParent, 4 * (size_t)n)); RT_HIP(hipMalloc(&leafParent, 4 * (size_t)n));
-  RT_HIP(hipMalloc(&arrive, 4 * ((size_t)n + 1)));            // + 1: the depthKernel result
-  RT_HIP(hipMemsetAsync(arrive, 0, 4 * ((size_t)n + 1), s));
-
-  hipLaunchKernelGGL(mortonKernel, dim3(nb), dim3(256), 0, s, m.verts, m.indices, n, bmin, invExt, codes[0], order[0], triBox);
-  int cur = 0;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = pass * 8;
-    hipLaunchKernelGGL(radixHist, dim3(nb), dim3(256), 0, s, codes[cur], n, shift, hist, nb);
-    hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, s, hist, 256u * nb);
-    hipLaunchKernelGGL(radixScatter, dim3(nb), dim3(256), 0, s, codes[cur], order[cur], n, shift, hist, nb, codes[cur ^ 1], order[cur ^ 1]);
-    cur ^= 1;
-  }
-  hipLaunchKernelGGL(emitTris, dim3(nb), dim3(256), 0, s, (int)n, order[cur], m.verts, m.indices, m.tris);
-  if (n == 1) m.root = ~0;
-  else {
-    static const bool radixTree = getenv("RTGGX_BVH_RADIX_TREE") != nullptr;     // A/B switch: the Karras tree this build started with
-    int32_t root = 0;
-    if (radixTree) {
-      hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, s, codes[cur], (int)n, left, right, nodeParent, leafParent);
-      hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, leafParent, nodeBox, arrive);
-    } else {
-      int32_t *clRef[2], *nn; float* clBox[2]; uint32_t *keepPos, *mergePos;
-      RT_HIP(hipMalloc(&clRef[0], 4 * (size_t)n)); RT_HIP(hipMalloc(&clRef[1], 4 * (size_t)n)); RT_HIP(hipMalloc(&nn, 4 * (size_t)n));
-      RT_HIP(hipMalloc(&clBox[0], 24 * (size_t)n)); RT_HIP(hipMalloc(&clBox[1], 24 * (size_t)n));
-      RT_HIP(hipMalloc(&keepPos, 4 * (size_t)n)); RT_HIP(hipMalloc(&mergePos, 4 * (size_t)n));
-      hipLaunchKernelGGL(plocInit, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, clRef[0], clBox[0]);
-      int m = (int)n, nodeBase = 0, a = 0;
-      std::vector<uint32_t> roundBase;
-      const int radius = getenv("RTGGX_PLOC_RADIUS") ? atoi(getenv("RTGGX_PLOC_RADIUS")) : RT_PLOC_RADIUS;
-      while (m > 1) {
-        const dim3 g((m + 255) / 256);
-        hipLaunchKernelGGL(plocNearest, g, dim3(256), 0, s, m, radius, clBox[a], nn);
-        hipLaunchKernelGGL(plocFlags, g, dim3(256), 0, s, m, nn, keepPos, mergePos);
-        uint32_t lastFlags[2], lastPos[2];     // totals = last exclusive prefix + last flag
-        RT_HIP(hipMemcpyAsync(&lastFlags[0], keepPos + (m - 1), 4, hipMemcpyDeviceToHost, s)); RT_HIP(hipMemcpyAsync(&lastFlags[1], mergePos + (m - 1), 4, hipMemcpyDeviceToHost, s));
-        hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, s, keepPos, (uint32_t)m);
-        hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, s, mergePos, (uint32_t)m);
-        RT_HIP(hipMemcpyAsync(&lastPos[0], keepPos + (m - 1), 4, hipMemcpyDeviceToHost, s)); RT_HIP(hipMemcpyAsync(&lastPos[1], mergePos + (m - 1), 4, hipMemcpyDeviceToHost, s));
-        hipLaunchKernelGGL(plocScatter, g, dim3(256), 0, s, m, nodeBase, nn, keepPos, mergePos, clRef[a], clBox[a], clRef[a ^ 1], clBox[a ^ 1],
-                           left, right, nodeParent, leafParent, nodeBox);
-        RT_HIP(hipStreamSynchronize(s));
-        const int kept = (int)(lastPos[0] + lastFlags[0]), merged = (int)(lastPos[1] + lastFlags[1]);
-        if (merged <= 0 || kept != m - merged) { setError("buildBvh: clustering made no progress (%d clusters, %d merges, %d kept)", m, merged, kept); return -3; }
-        roundBase.push_back((uint32_t)nodeBase);
-        nodeBase += merged; m = kept; a ^= 1;
-      }
-      roundBase.push_back((uint32_t)nodeBase);
-      c->mesh[slot].roundBase = roundBase;
-      root = (int32_t)n - 2;                      // the last node created
-      const int32_t none = -1;
-      RT_HIP(hipMemcpyAsync(nodeParent + root, &none, 4, hipMemcpyHostToDevice, s));
-      RT_HIP(hipStreamSynchronize(s));
-      hipFree(clRef[0]); hipFree(clRef[1]); hipFree(nn); hipFree(clBox[0]); hipFree(clBox[1]); hipFree(keepPos); hipFree(mergePos);
-    }
-    hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeBox, m.nodes);
-    hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, order[cur], triBox, left, right, nodeParent, nodeBox, m.nodes4);
-    hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, s, (int)n, nodeParent, leafParent, arrive + n);
-    m.root = root;
-  }
-  RT_HIP(hipGetLastError());
-  RT_HIP(hipMemcpyAsync(&m.depth, arrive + n, 4, hipMemcpyDeviceToHost, s));
-  // the topology and the per-primitive boxes stay for rtggx_refit_as (freed with the mesh or by the next build)
-  m.order = order[cur]; m.left = left; m.right = right; m.nodeParent = nodeParent; m.leafParent = leafParent; m.nodeBox = nodeBox; m.triBox = triBox;
-  if (n > 1) {
-    std::vector<int32_t> hl(n - 1), hr(n - 1);
-    RT_HIP(hipMemcpyAsync(hl.data(), left, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, s)); RT_HIP(hipMemcpyAsync(hr.data(), right, 4 * (size_t)(n - 1), hipMemcpyDeviceToHost, s));
-    RT_HIP(hipStreamSynchronize(s));
-    { const int r = planTop(m, slot == 0 ? RT_TOP_SLOT0 : RT_TOP_SLOT1, hl, hr, s); if (r) return r; }
-    if (m.roundBase.size() >= 2) {      // PLOC build: plan the refit (rtggx_refit_as) while the topology is at hand
-      const int r = planRefit(m, hl, hr, s);
-      if (r) return r;
-    }
-  }
-  if (n > 1) { const int r = launchTreeCost(m, s); if (r) return r; RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s)); }
-  RT_HIP(hipStreamSynchronize(s));
-  if (n > 1) { m.builtCost = m.lastCost = *m.hCost; m.costInFlight = false; }
-  hipFree(codes[0]); hipFree(codes[1]); hipFree(order[cur ^ 1]); hipFree(hist); hipFree(arrive);
   return 0;
 }
 

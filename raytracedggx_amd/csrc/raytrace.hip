@@ -198,6 +198,12 @@ RT_DEV f2 calcBarycentrics(const f4 p[3], f2 ndc) {   // :204-225
 // =========================================================================================================
 struct GenArgs {
   const unsigned long long* visDepth; uint32_t* depthOut;
+  // the head of the NEXT frame's visibility pass (visibility.hip): its target is cleared and its lists are emptied here, on the way
+  // (visNext == null: not).  One kernel launch per frame less, and the clear's 8 bytes per pixel ride on a kernel that is there anyway.
+  // (Tried with it and not kept: merging the queued large triangles -- rasterLarge's work -- here as well.  Same arithmetic, but in
+  // front of every wave's first dependent fetch: rayGenKernel 85 -> 169 us per launch, the 1080p frame 0.190 -> 0.243 ms, 4K 0.715 ->
+  // 0.980; with the records in LDS no different.  profiles/r03_b_visibility_merge.txt)
+  unsigned long long* visNext; uint32_t* zeroNext0; uint32_t* zeroNext1;
   uint32_t* normalOut; uint16_t* roughMetalOut; uint32_t* velocityOut; uint32_t* reflOut; uint32_t* diffOut;
   const uint16_t* roughMetalPrev;   // the previous frame's input set = what this target held before this frame
   const float4* fat0; const float4* fat1;
@@ -216,6 +222,7 @@ struct GenArgs {
 __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const FrameParams* __restrict__ fpp, GenArgs A) {
   const FrameParams& fp = *fpp;
   if (blockIdx.x == 0) A.frameRays[threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && A.visNext != nullptr) { *A.zeroNext0 = 0u; *A.zeroNext1 = 0u; }      // the next frame's large-triangle list, the next set's split list
   // 16x16 pixel tile per workgroup, 8x8 per wave: the 64 rays a wave appends are neighbours on screen
   const uint32_t tile = blockIdx.x;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -230,6 +237,7 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
     const size_t pix = (size_t)py * W + px;
     // getPrimarySurface :277-333
     const unsigned long long visWord = A.visDepth[pix];
+    if (A.visNext != nullptr) A.visNext[pix] = RT_VIS_CLEAR;
     uint32_t visibility = (uint32_t)visWord;
     A.depthOut[pix] = (uint32_t)(visWord >> 32);      // the filters read depth four bytes at a time instead of every other word of an 8-byte array
     f2 screenPos; screenPos.x = ((float)px + 0.5f) / (float)W * 2.0f - 1.0f; screenPos.y = ((float)py + 0.5f) / (float)H * 2.0f - 1.0f;
@@ -464,6 +472,11 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   if (re <= rb) return 0;
   const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
   GenArgs G;
+  // ray generation starts the next frame's visibility pass (GenArgs)
+  { const uint32_t nextFrame = c->frameCounter + 1u, nextSet = (c->setIndex + 1u) % RT_SETS;
+    static const bool clearNext = !(getenv("RTGGX_CLEAR_NEXT") && atoi(getenv("RTGGX_CLEAR_NEXT")) == 0);      // measurement: 0 = every frame clears its own target (the kernel of rounds 1 and 2)
+    G.visNext = clearNext ? c->visDepthBuf[nextFrame % RT_VIS_RING] : nullptr; G.zeroNext0 = c->largeCountBase + (nextFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
+    c->visClearedFor = G.visNext; c->visClearedRows[0] = rb; c->visClearedRows[1] = re; }
   G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
   G.fat0 = c->mesh[0].fat; G.fat1 = c->mesh[1].fat;

@@ -33,7 +33,42 @@
 #define RT_SETS 4
 #endif
 #define RT_SLOTS (RT_SETS + 1)
+// The visibility target (visDepth) exists once more than the other members of an input set: ray generation of frame f clears the
+// target of frame f + 1 on its way (raytrace.hip) -- one kernel launch and one pass over 8 bytes per pixel less per frame --, and the
+// target it clears must be one nobody reads any more: frame f + 1 - RT_VIS_RING's, whose last reader the host has waited for (evSetRead).
+#define RT_VIS_RING (RT_SETS + 1)
+#define RT_VIS_CLEAR 0x00FFFFFF00000000ull      // (D24 = 1.0) << 32 | nothing drawn
 namespace rt {
+
+// What a build tells the host: written by the build's kernels, copied to pinned memory behind its last one.
+#define RT_TREELET_LEVELS 3
+struct BuildResult {
+  uint32_t numRounds;                        // PLOC rounds (= entries of roundBase - 1)
+  uint32_t treelets[RT_TREELET_LEVELS];      // refit treelets per level (lbvh.hip "treelets")
+  uint32_t topCount;                         // entries of the LDS table of the tree's top
+  uint32_t depth;                            // deepest leaf (number of ancestors): bounds the traversal stack
+  uint32_t error;                            // bit 0: more than RT_MAX_ROUNDS rounds; bit 1: a treelet level beyond RT_TREELET_LEVELS would be needed
+  uint32_t itemCursor, roundCursor, pad;
+  float cost, pad2;                          // sum of the node-box half-areas (SAH cost up to constants)
+};
+// Everything a build derives from ONE vertex shape that refits of later shapes keep using (lbvh.hip): the binary topology (PLOC creates
+// nodes in rounds; a node's children are leaves or nodes of EARLIER rounds, and node indices are handed out round by round), the
+// per-primitive and per-node boxes of the latest refit, the refit schedule (treelets of <= 1024 nodes, one workgroup each, level by
+// level), the list of nodes at the tree's top.  All of it is produced on the device without a host round trip; the host learns a
+// handful of counts (BuildResult) when the build has ended.
+struct BvhTopo {
+  uint32_t* order = nullptr;     // leaf slot -> primitive (Morton order)
+  int32_t *left = nullptr, *right = nullptr, *nodeParent = nullptr, *leafParent = nullptr;
+  float *nodeBox = nullptr, *triBox = nullptr;
+  uint32_t* cnt[RT_TREELET_LEVELS] = {};     // per node: nodes of its subtree that treelet level l still has to place
+  uint32_t* roundBase = nullptr;             // device: first node of PLOC round k
+  void *dTreelets = nullptr, *dRefitItems = nullptr; uint32_t* dRefitRounds = nullptr; int32_t* treeletRoots = nullptr;
+  int32_t *topList = nullptr, *topRank = nullptr;
+  BuildResult* dResult = nullptr; BuildResult* hResult = nullptr;      // device record, pinned copy
+  BuildResult result{};                      // the host's copy, valid once the build has ended
+  uint32_t numTris = 0; int32_t root = -1;
+  bool refittable = false;                   // a PLOC build (the Karras radix tree of RTGGX_BVH_RADIX_TREE has no rounds)
+};
 
 struct MeshDev {
   float* verts = nullptr;        // 6 floats per vertex: the buffer of the CURRENT input set (selectSet)
@@ -50,9 +85,11 @@ struct MeshDev {
   bool deforming = false;
   float* stage[RT_SLOTS] = {};   // pinned host staging ring for the vertices handed to rtggx_refit_as
   uint32_t stageNext = 0; int pendingStage = -1;
-  // what the build leaves behind for the refit (lbvh.hip): the binary topology, per-primitive boxes, arrival counters
-  uint32_t* order = nullptr; int32_t *left = nullptr, *right = nullptr, *nodeParent = nullptr, *leafParent = nullptr;
-  float *nodeBox = nullptr, *triBox = nullptr;
+  // what a build derives from one vertex shape and a refit keeps: `topo` (BvhTopo above); `job`: a build in progress (lbvh.hip BuildJob)
+  BvhTopo topo;
+  struct BuildJob* job = nullptr;
+  bool wantRebuild = false;      // the refitted tree's cost has drifted: the next frame starts a rebuild
+  uint32_t topoVersion = 0, topoVersionOfSet[RT_SETS] = {};      // a set whose tree arrays were emitted for an older topology is emitted in full by its next refit
   float* dCost = nullptr;        // device: sum of the node-box half-areas of the current tree (SAH cost up to constants)
   float* hCost = nullptr;        // pinned: its copy, refreshed asynchronously after every refit
   hipEvent_t evCost = nullptr; bool costInFlight = false;
@@ -66,16 +103,10 @@ struct MeshDev {
   // the three above are those of the CURRENT input set: like the vertices, the boxes and leaf triangles of a deforming mesh exist
   // once per input set (frame f + 1's refit on stream R writes its set while frame f's traversal still walks the other)
   BvhNode* nodesBuf[RT_SETS] = {}; Bvh4Node* nodes4Buf[RT_SETS] = {}; BvhTri* trisBuf[RT_SETS] = {};
-  // the top of the tree once more, breadth-first, for the trace kernel's LDS (rtggx_device.h RT_TOP_*; lbvh.hip planTop / emitTop):
-  // topList[k] = node of rank k, topRank[node] = its rank or -1; the table itself per input set like the nodes
-  int32_t *topList = nullptr, *topRank = nullptr; uint32_t topCount = 0;
+  // the top of the tree once more, breadth-first, for the trace kernel's LDS (rtggx_device.h RT_TOP_*; lbvh.hip planTopKernel / emitTop):
+  // topo.topList[k] = node of rank k, topo.topRank[node] = its rank or -1; the table itself per input set like the nodes
+  uint32_t topCount = 0; uint32_t topCountBuf[RT_SETS] = {};
   Bvh4Node* top = nullptr; Bvh4Node* topBuf[RT_SETS] = {};
-  // PLOC creates nodes in rounds; a node's children are leaves or nodes of EARLIER rounds, and node indices are handed out round
-  // by round: refitting round after round needs no synchronisation inside a round (lbvh.hip: refitLbvh)
-  std::vector<uint32_t> roundBase;      // roundBase[k] = first node of round k; roundBase.back() = numTris - 1
-  // the refit schedule planned from it at build time (lbvh.hip planRefit): treelets of <= 1024 nodes, one workgroup each, level by level
-  void *dTreelets = nullptr, *dRefitItems = nullptr; uint32_t* dRefitRounds = nullptr;
-  std::vector<std::pair<uint32_t, uint32_t>> refitLevels;      // (first treelet, number of treelets) per launch
   int32_t root = -1;             // 0, or ~0 for a single-triangle mesh
   uint32_t depth = 0;            // deepest leaf (number of ancestors): bounds the traversal stack
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // vertex bounds (Morton normalisation box)
@@ -147,6 +178,7 @@ struct rtggx_context {
   bool fltRflIsFltDff = false;          // the last denoise ran without diffuse passes: FilteredOut == FilteredOut1 and only the latter was written
   bool externalStream = false;
 
+  float rebuildRatio = 1.2f; uint32_t rebuildSteps = 16;      // rtggx_set_refit_policy
   rt::MeshDev mesh[2];
   rt::EnvDev env;
   float* sh = nullptr;           // 27 floats
@@ -159,7 +191,9 @@ struct rtggx_context {
   unsigned long long* visDepth = nullptr;
   uint32_t *normal = nullptr, *velocity = nullptr, *rtRefl = nullptr, *rtDiff = nullptr, *backbuffer = nullptr;
   uint16_t* roughMetal = nullptr;
-  unsigned long long* visDepthBuf[RT_SETS] = {};
+  unsigned long long* visDepthBuf[RT_VIS_RING] = {};      // by frameCounter % RT_VIS_RING
+  // which target the last ray generation cleared for the next frame's visibility pass, and over which rows (visibility.hip)
+  unsigned long long* visClearedFor = nullptr; uint32_t visClearedRows[2] = {0, 0}; uint32_t visStandaloneClears = 0;
   uint32_t* depth32 = nullptr; uint32_t* depth32Buf[RT_SETS] = {};      // the D24 word of visDepth once more, 4 bytes per pixel, for the spatial filters (written by ray generation)
   uint32_t *normalBuf[RT_SETS] = {}, *velocityBuf[RT_SETS] = {}, *rtReflBuf[RT_SETS] = {}, *rtDiffBuf[RT_SETS] = {};
   uint16_t* roughMetalBuf[RT_SETS] = {};
@@ -167,10 +201,11 @@ struct rtggx_context {
   void *rayQueueBuf[RT_SETS] = {}, *hitQueueBuf[RT_SETS] = {};   // ray bins: written on stream B, shaded on the main stream
   uint32_t* binCountBuf[RT_SETS] = {};
   void selectSet(uint32_t i) {
-    setIndex = i; visDepth = visDepthBuf[i]; depth32 = depth32Buf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
+    setIndex = i; visDepth = visDepthBuf[frameCounter % RT_VIS_RING]; depth32 = depth32Buf[i]; normal = normalBuf[i]; velocity = velocityBuf[i]; rtRefl = rtReflBuf[i]; rtDiff = rtDiffBuf[i]; roughMetal = roughMetalBuf[i];
     rayQueue = rayQueueBuf[i]; hitQueue = hitQueueBuf[i]; binCount = binCountBuf[i];
-    splitList = splitListBuf[i]; splitCount = largeCount ? largeCount + 1 + i : nullptr;
-    for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.fat = m.fatBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.top = m.topBuf[i]; m.tris = m.trisBuf[i]; }
+    splitList = splitListBuf[i]; splitCount = largeCountBase ? largeCountBase + 2 + i : nullptr;
+    largeTris = largeTrisBuf[frameCounter & 1u]; largeCount = largeCountBase ? largeCountBase + (frameCounter & 1u) : nullptr;
+    for (auto& m : mesh) { m.verts = m.vertsBuf[i]; m.fat = m.fatBuf[i]; m.nodes = m.nodesBuf[i]; m.nodes4 = m.nodes4Buf[i]; m.top = m.topBuf[i]; m.topCount = m.topCountBuf[i]; m.tris = m.trisBuf[i]; }
     const uint32_t par = pipeline != 0 ? (frameCounter & 1u) : 0u;
     binWork = binWorkBuf[par]; rayCounter32 = rayCounterBuf + (pipeline != 0 ? (frameCounter & 3u) : 0u) * 256u;
   }
@@ -178,8 +213,11 @@ struct rtggx_context {
   uint32_t frameParity = 0;
 
   // visibility scratch
-  void* largeTris = nullptr;     // LargeTri records
-  uint32_t* largeCount = nullptr;       // [0] entries of largeTris, [1 + set] entries of splitList[set] (zeroed by that set's clearVisDepth)
+  // LargeTri records queued by rasterSmall, merged by rasterLarge; twice, by frame parity (ray generation of frame f empties the
+  // list of frame f + 1: the count it zeroes must not be the one a consumer of frame f could still read)
+  void* largeTris = nullptr; void* largeTrisBuf[2] = {};
+  uint32_t* largeCount = nullptr;       // the current frame's count (selectSet)
+  uint32_t* largeCountBase = nullptr;   // [0], [1] entries of largeTrisBuf[parity]; [2 + set] entries of splitList[set] (zeroed by the previous frame's ray generation)
   // Bins whose traversal was expensive in the previous frame are traced by 2, 4 or 8 waves (trace.hip "adaptive split"):
   uint32_t* binWork = nullptr;          // [numBinsMax] lane-steps the trace kernel spent on the bin (read and zeroed by rayGenKernel)
   uint32_t* binWorkBuf[2] = {};         // by frame parity: ray generation of frame f reads what the traversal of frame f - 2 recorded
@@ -264,7 +302,15 @@ void setError(const char* fmt, ...);
 int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s);
 int uploadScene(rtggx_context* c, hipStream_t s);
 int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);
+// Acceleration-structure builds (lbvh.hip).  A build is a fixed sequence of kernel launches on one stream, no host round trip in it:
+//   buildLbvh          all of it at once, then ONE wait (rtggx_build_as; the sample: BuildAccelerationStructures + one WaitForGpu)
+//   startRebuild       the same sequence for a mesh that deforms, from the vertices of input set `set`, into a topology of its own ...
+//   continueRebuild    ... issued a few launches per frame behind the frame's refit; when the last one has ended (an event the host
+//                      polls) the new topology replaces the old one between two frames.  Nothing waits.
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
+int startRebuild(rtggx_context* c, uint32_t slot, uint32_t set);      // 1: started, 0: not (one is in progress, or the mesh cannot be refitted), < 0: error
+int continueRebuild(rtggx_context* c, uint32_t slot, hipStream_t s, uint32_t maxSteps, bool* swapped);
+void abandonRebuild(rtggx_context* c, uint32_t slot);      // (synchronises; before the mesh's buffers are freed)
 int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s);      // boxes of the existing tree from the vertices of input set `set`, into that set's BVH arrays: no host round trip
 void freeBuildProducts(MeshDev& m);
 int buildFatTris(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s);      // mesh.fatBuf[set] from mesh.vertsBuf[set] and the indices

@@ -16,10 +16,10 @@
 // Roofline: HBM; algorithmic bytes 8 B/pixel (clear) + 8 B/covered fragment.
 #include <hip/hip_ext.h>
 #include "rtggx_context.h"
+#include "rt_raster.h"
 
 namespace rt {
 
-struct LargeTri { int32_t X[3], Y[3]; float z[3]; uint32_t word; double invA; uint32_t tl, pad; };   // 56 B; set-up done once, by rasterSmall
 
 struct RVert { long long X, Y; float z; bool ok; };
 
@@ -67,41 +67,18 @@ RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
   return (dy == 0 && dx > 0) || dy < 0;
 }
 
-// First kernel of the pass: clears the target, empties the large-triangle list and -- when the frame's constants have
-// not been uploaded yet -- copies them (912 bytes, passed by value) into their device slot for the kernels that follow.
-__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount, uint32_t* __restrict__ splitCount,
-                              FrameParams src, FrameParams* __restrict__ dst) {
+// Clears rows of a visibility target and empties the lists the pass appends to.  Since round 3 this is the EXCEPTION: ray generation
+// of frame f clears the target of frame f + 1 on its way (raytrace.hip), and this kernel runs only where that has not happened -- a
+// context's first frame, a strip whose rows changed, a caller that rendered visibility twice without tracing.
+__global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount, uint32_t* __restrict__ splitCount) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { *largeCount = 0; *splitCount = 0; }      // the large-triangle list of rasterSmall and this set's split list (rayGenKernel) start empty
-  if (blockIdx.x == 0 && dst) {
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4; i += blockDim.x) d[i] = s[i];
-  }
-  // four words (32 bytes) per thread: a quarter of the waves, each with 2 KB of stores in flight (one word per thread made this a kernel
-  // of 32 400 waves that each lived for one store)
+  // four words (32 bytes) per thread: a quarter of the waves, each with 2 KB of stores in flight
   const uint32_t i = begin + (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
-  const unsigned long long clear = 0x00FFFFFF00000000ull;
+  const unsigned long long clear = RT_VIS_CLEAR;
   if (i + 3u < end && (i & 1u) == 0u) {
     ulonglong2* p = reinterpret_cast<ulonglong2*>(vd + i);
     p[0] = make_ulonglong2(clear, clear); p[1] = make_ulonglong2(clear, clear);
   } else for (uint32_t k = 0; k < 4u; ++k) if (i + k < end) vd[i + k] = clear;
-}
-
-// Fragment test + depth for one pixel; returns the key or ~0 when not covered.
-// Snapped coordinates are below 2^30 in magnitude (rasterVertex), pixel centres below 2^23: every difference fits 32
-// bits, every product is one 32x32->64 multiply-add.
-RT_DEV unsigned long long fragmentKey(int32_t PX, int32_t PY, const int32_t X[3], const int32_t Y[3],
-                                      bool tl0, bool tl1, bool tl2, double invA, double z0, double dz1, double dz2, uint32_t word) {
-  const long long w0 = (long long)(X[2] - X[1]) * (long long)(PY - Y[1]) - (long long)(Y[2] - Y[1]) * (long long)(PX - X[1]);
-  const long long w1 = (long long)(X[0] - X[2]) * (long long)(PY - Y[2]) - (long long)(Y[0] - Y[2]) * (long long)(PX - X[2]);
-  const long long w2 = (long long)(X[1] - X[0]) * (long long)(PY - Y[0]) - (long long)(Y[1] - Y[0]) * (long long)(PX - X[0]);
-  if (w0 < 0 || w1 < 0 || w2 < 0) return ~0ull;
-  if ((w0 == 0 && !tl0) || (w1 == 0 && !tl1) || (w2 == 0 && !tl2)) return ~0ull;
-  const double l1 = (double)w1 * invA, l2 = (double)w2 * invA;
-  const double z = z0 + l1 * dz1 + l2 * dz2;
-  if (!(z >= 0.0) || !(z <= 1.0)) return ~0ull;
-  const uint32_t d24 = (uint32_t)(z * 16777215.0 + 0.5);
-  return ((unsigned long long)d24 << 32) | word;
 }
 
 // Small triangles (bounding box <= RT_SMALL_BOX pixels), balanced over the lanes of a wave.  Phase 1: one lane per
@@ -115,13 +92,19 @@ struct __attribute__((aligned(16))) TriSetup {
   int32_t px0, py0; uint32_t bwTl /* box width | top-left flags << 16 */, magic /* ceil(2^24 / box width) */;
   double invA;
 };
-__global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict__ fpp, uint32_t rowBegin, uint32_t rowEnd, const float* __restrict__ v0, const uint32_t* __restrict__ i0, uint32_t nt0,
+// The pass's first kernel also carries the frame's constants to the device: `fp` arrives by value (912 bytes of kernel argument, read
+// with scalar loads), and block 0 copies it into the constants' device slot `dst` (null: already there) for the kernels that follow.
+__global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FrameParams* __restrict__ dst, uint32_t rowBegin, uint32_t rowEnd, const float* __restrict__ v0, const uint32_t* __restrict__ i0, uint32_t nt0,
                                                    const float* __restrict__ v1, const uint32_t* __restrict__ i1, uint32_t nt1,
                                                    unsigned long long* __restrict__ vd, LargeTri* __restrict__ large,
                                                    uint32_t* __restrict__ largeCount, uint32_t largeCap) {
   __shared__ TriSetup setupMem[256];
   __shared__ uint32_t prefixMem[256];
-  const FrameParams& fp = *fpp;
+  if (blockIdx.x == 0 && dst) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&fp);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4; i += blockDim.x) d[i] = s[i];
+  }
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   TriSetup* const setup = setupMem + wave * 64; uint32_t* const prefix = prefixMem + wave * 64;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,8 +114,11 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict
     const uint32_t prim = inst ? t - nt0 : t;
     const float* verts = inst ? v1 : v0;
     const uint32_t* idx = inst ? i1 : i0;
-    const M4 wvp = cbLoad4x4(fp.po[inst].WorldViewProj);
-    const float bx = fp.po[inst].ProjBias[0], by = fp.po[inst].ProjBias[1];
+    // (selected, not indexed: the constants are a kernel argument)
+    const M4 wvp0 = cbLoad4x4(fp.po[0].WorldViewProj), wvp1 = cbLoad4x4(fp.po[1].WorldViewProj);
+    M4 wvp;
+    for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) wvp.m[r][q] = inst ? wvp1.m[r][q] : wvp0.m[r][q];
+    const float bx = inst ? fp.po[1].ProjBias[0] : fp.po[0].ProjBias[0], by = inst ? fp.po[1].ProjBias[1] : fp.po[0].ProjBias[1];
     const uint32_t word = ((inst << 24) | prim) + 1u;
     // One (sub-)triangle in clip space: project, snap, cull, box; small boxes are parked for phase 2 (at most one per
     // lane: sub-triangles of a clipped triangle always go to the tile pass), big ones queued for rasterLarge.
@@ -217,27 +203,15 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) rasterLarge(const FrameParams* __restrict__ fpp, uint32_t rowBegin, uint32_t rowEnd, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
+// The queued large triangles merged into the target: one lane per pixel of the rows, 64 x 4 pixels per workgroup.
+__global__ void __launch_bounds__(256) rasterLarge(uint32_t W, uint32_t rowBegin, uint32_t rowEnd, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
                                                    const uint32_t* __restrict__ largeCount, uint32_t largeCap) {
-  const FrameParams& fp = *fpp;
   const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63);
   const uint32_t py = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
   const uint32_t n = min(*largeCount, largeCap);
-  const int32_t tileX0 = (int32_t)(blockIdx.x * 64) * 256 + 128, tileX1 = tileX0 + 63 * 256;
-  const int32_t tileY0 = (int32_t)(rowBegin + blockIdx.y * 4) * 256 + 128, tileY1 = tileY0 + 3 * 256;
-  const int32_t PX = (int32_t)px * 256 + 128, PY = (int32_t)py * 256 + 128;
-  unsigned long long best = ~0ull;
-  for (uint32_t i = 0; i < n; ++i) {
-    const LargeTri lt = large[i];
-    const int32_t minX = min(lt.X[0], min(lt.X[1], lt.X[2])), maxX = max(lt.X[0], max(lt.X[1], lt.X[2]));
-    const int32_t minY = min(lt.Y[0], min(lt.Y[1], lt.Y[2])), maxY = max(lt.Y[0], max(lt.Y[1], lt.Y[2]));
-    if (maxX < tileX0 || minX > tileX1 || maxY < tileY0 || minY > tileY1) continue;   // uniform per workgroup
-    const double z0 = (double)lt.z[0], dz1 = (double)lt.z[1] - z0, dz2 = (double)lt.z[2] - z0;
-    const unsigned long long key = fragmentKey(PX, PY, lt.X, lt.Y, lt.tl & 1u, (lt.tl >> 1) & 1u, (lt.tl >> 2) & 1u, lt.invA, z0, dz1, dz2, lt.word);
-    best = key < best ? key : best;
-  }
-  if (px < fp.W && py < rowEnd && best != ~0ull) {
-    unsigned long long* dst = vd + (size_t)py * fp.W + px;
+  const unsigned long long best = mergeLargeTris(~0ull, px, py, blockIdx.x * 64, rowBegin + blockIdx.y * 4, blockIdx.x * 64 + 63, rowBegin + blockIdx.y * 4 + 3, large, n);
+  if (px < W && py < rowEnd && best != ~0ull) {
+    unsigned long long* dst = vd + (size_t)py * W + px;
     if (best < *dst) *dst = best;
   }
 }
@@ -256,20 +230,25 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   passRows(fp, ROWS_GBUFFER, rb, re);
   const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
-  hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 1023) / 1024), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount, c->splitCount,
-                     fp, c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot);
-  c->slotUploaded = true;
+  // the target was cleared by the previous frame's ray generation -- unless it was not (see clearVisDepth)
+  if (!(c->visClearedFor == c->visDepth && c->visClearedRows[0] <= rb && c->visClearedRows[1] >= re)) {
+    hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 1023) / 1024), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount, c->splitCount);
+    ++c->visStandaloneClears;
+  }
+  c->visClearedFor = nullptr;
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
+  FrameParams* const dst = c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot;
+  c->slotUploaded = true;
+  // (with no triangles at all the kernel still runs, for the constants)
+  const dim3 grid(nt ? (nt + 255) / 256 : 1u);
+  hipLaunchKernelGGL(rasterSmall, grid, dim3(256), 0, s, fp, dst, rb, re, (const float*)c->mesh[0].verts, (const uint32_t*)c->mesh[0].indices, c->mesh[0].numTris,
+                     (const float*)c->mesh[1].verts, (const uint32_t*)c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
   if (nt) {
-    hipLaunchKernelGGL(rasterSmall, dim3((nt + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->mesh[0].verts, c->mesh[0].indices, c->mesh[0].numTris,
-                       c->mesh[1].verts, c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
+    const dim3 lgrid((fp.W + 63) / 64, (re - rb + 3) / 4);
     if (done && c->attachEvents) {      // the event rides on the pass's last kernel (rtggx_context.h)
-      hipExtLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (re - rb + 3) / 4), dim3(256), 0, s, nullptr, done, 0, (const FrameParams*)(c->dParams + c->slot), rb, re, c->visDepth,
-                            (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity);
+      hipExtLaunchKernelGGL(rasterLarge, lgrid, dim3(256), 0, s, nullptr, done, 0, fp.W, rb, re, c->visDepth, (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity);
       done = nullptr;
-    } else
-      hipLaunchKernelGGL(rasterLarge, dim3((fp.W + 63) / 64, (re - rb + 3) / 4), dim3(256), 0, s, c->dParams + c->slot, rb, re, c->visDepth,
-                         (const LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
+    } else hipLaunchKernelGGL(rasterLarge, lgrid, dim3(256), 0, s, fp.W, rb, re, c->visDepth, (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity);
   }
   if (done) hipEventRecord(done, s);
   RT_HIP(hipGetLastError());

@@ -90,6 +90,17 @@ void RayTracedGGX::OnRender() {
   m_denoiser->Denoise(m_useSharedMem, m_asyncCompute != 0);
   m_denoiser->ToneMap();
   m_frameIndex = (uint8_t)((m_frameIndex + 1) % FrameCount);   // MoveToNextFrame :684-701
+  // Screen-shot helper (MoveToNextFrame :703-717: the sample copies the back buffer of the frame rendered after [F11] and writes
+  // "RayTracedGGX_<time stamp>.png" FrameCount frames later).  Headless runs want reproducible names: <-dump prefix or RayTracedGGX>
+  // _f<frame number, 6 digits>.png, written at once (the read-back waits for the frame).
+  if (m_screenShot) {
+    m_screenShot = 0;
+    std::string stem = m_dumpPrefix.empty() ? std::string("RayTracedGGX") : m_dumpPrefix;
+    if (stem.size() >= 4 && (stem.compare(stem.size() - 4, 4, ".png") == 0 || stem.compare(stem.size() - 4, 4, ".ppm") == 0)) stem.resize(stem.size() - 4);
+    char tail[32]; std::snprintf(tail, sizeof tail, "_f%06u.png", m_frameNumber - 1u);      // OnUpdate has counted this frame already
+    m_lastScreenShot = stem + tail;
+    if (SaveImage(m_lastScreenShot.c_str())) std::printf("wrote %s\n", m_lastScreenShot.c_str()); else m_lastScreenShot.clear();
+  }
 }
 
 void RayTracedGGX::OnDestroy() {
@@ -108,6 +119,7 @@ void RayTracedGGX::OnKeyUp(uint8_t key) {
     case 0x27: m_currentMesh = (m_currentMesh + 1) % RayTracer::NUM_MESH; break;
     case 0x26: metallic = std::min(metallic + 0.25f, 1.0f); m_rayTracer->SetMetallic(m_currentMesh, metallic); break;
     case 0x28: metallic = std::max(metallic - 0.25f, 0.0f); m_rayTracer->SetMetallic(m_currentMesh, metallic); break;
+    case 0x7A: m_screenShot = 1; break;                       // VK_F11, RayTracedGGX.cpp:388-390: the frame rendered next is saved
     case 'V': m_useSharedMem = !m_useSharedMem; break;
     case 'A': m_asyncCompute = !m_asyncCompute; m_rayTracer->SetAsyncCompute(m_asyncCompute != 0); break;   // RayTracedGGX.cpp:394-396
     default: break;
@@ -153,7 +165,7 @@ bool RayTracedGGX::LoadTrack(const std::string& fileName) {
     if (c == "key") {
       if (std::sscanf(line, "%u %*s %31s", &frame, arg) != 2) continue;
       const std::string k = arg;
-      const int code = k == "SPACE" ? ' ' : k == "LEFT" ? 0x25 : k == "UP" ? 0x26 : k == "RIGHT" ? 0x27 : k == "DOWN" ? 0x28 : k.size() == 1 ? std::toupper((unsigned char)k[0]) : std::atoi(arg);
+      const int code = k == "SPACE" ? ' ' : k == "LEFT" ? 0x25 : k == "UP" ? 0x26 : k == "RIGHT" ? 0x27 : k == "DOWN" ? 0x28 : k == "F11" ? 0x7A : k.size() == 1 ? std::toupper((unsigned char)k[0]) : std::atoi(arg);
       e.type = 0; e.a = (float)code;
     } else if (c == "down" || c == "up" || c == "move") {
       if (std::sscanf(line, "%u %*s %f %f", &frame, &a, &b) != 3) continue;

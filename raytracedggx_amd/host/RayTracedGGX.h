@@ -44,6 +44,8 @@ class RayTracedGGX {
   uint32_t GetHeight() const { return m_height; }
   uint32_t GetNumFrames() const { return m_numFrames; }
   const std::string& GetDumpPrefix() const { return m_dumpPrefix; }
+  void SetDumpPrefix(const std::string& prefix) { m_dumpPrefix = prefix; }
+  const std::string& GetLastScreenShot() const { return m_lastScreenShot; }
   // multi-GPU (host/Strips.h): -gpus N (one process per GPU), what the launcher hands a rank, the single-process mode
   int GetNumGpus() const { return m_gpus; }
   int GetRank() const { return m_rank; }
@@ -70,6 +72,8 @@ class RayTracedGGX {
   uint32_t m_currentMesh = 0;
   bool m_useSharedMem = false;
   bool m_isPaused = false;
+  uint32_t m_screenShot = 0;           // RayTracedGGX.h:123; set by [F11]
+  std::string m_lastScreenShot;        // the file the last [F11] wrote
   float m_metallics[RayTracer::NUM_MESH];
 
   // camera (RayTracedGGX.h:100-104)

@@ -56,6 +56,10 @@ std::vector<uint32_t> ProfileBounds(RayTracedGGX& app, int world, uint32_t apron
 
 // One process per GPU: the executable restarts itself `world` times with -rank r -idfile <path> (before anything touches a GPU)
 // and returns the worst exit code.
+// Restarts the executable once per rank (before anything has touched a GPU: it refuses, exit code 2, under a profiler / preload or with
+// /dev/kfd open), reaps the ranks in any order, and stops the others when one fails or none has ended for RankTimeoutSeconds
+// (RTGGX_RANK_TIMEOUT overrides).  The ranks, not the launcher, are what belongs behind `rocprofv3 --`.
+constexpr double RankTimeoutSeconds = 900.0, RankGraceSeconds = 2.0;
 int LaunchRanks(int world, int argc, char* argv[]);
 // Body of a rank (world > 1), and of the single-process mode (-strips N: N contexts on one GPU, the sends and receives of a
 // one-rank communicator paired with each other -- the exchange code exercised without N GPUs).  Return the process exit code.

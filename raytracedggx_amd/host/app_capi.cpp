@@ -49,6 +49,8 @@ void rtggx_app_set_time_step(void* h, float dt) { ((RayTracedGGX*)h)->SetFixedTi
 void* rtggx_app_context(void* h) { return ((RayTracedGGX*)h)->GetContext(); }
 void rtggx_app_size(void* h, uint32_t* w, uint32_t* ht) { *w = ((RayTracedGGX*)h)->GetWidth(); *ht = ((RayTracedGGX*)h)->GetHeight(); }
 void rtggx_app_frame_constants(void* h, void* out768) { std::memcpy(out768, &((RayTracedGGX*)h)->GetRayTracer()->GetFrameConstants(), sizeof(RtggxFrameConstants)); }
+int rtggx_app_set_dump_prefix(void* h, const char* prefix) { ((RayTracedGGX*)h)->SetDumpPrefix(prefix ? prefix : ""); return 0; }
+const char* rtggx_app_last_screen_shot(void* h) { return ((RayTracedGGX*)h)->GetLastScreenShot().c_str(); }
 int rtggx_app_save_image(void* h, const char* path) { return ((RayTracedGGX*)h)->SaveImage(path) ? 0 : -1; }
 
 int rtggx_host_write_png(const char* path, uint32_t w, uint32_t h, uint32_t comp, const uint8_t* pixels) { return WritePng(path, w, h, comp, pixels) ? 0 : -1; }

@@ -221,12 +221,12 @@ class StripRenderer:
     def strip_rows_with_apron(self):
         return max(self.b - 18, 0), min(self.e + 18, self.H)
 
-    def trace_kernel_algorithmic_bytes(self, rays_per_launch):
-        """DESIGN.md "Roofline": what one launch of traceKernel has to move if every byte moved once, by SURVEY.md 8(d)'s
-        per-ray figure -- a 64-byte ray record in and an 8-byte hit key out -- plus the acceleration structure once (the
-        4-wide nodes in use and the leaf triangles of both instances).  The yardstick stays fixed; the kernel itself has
-        read 32 bytes of a 48-byte record per ray since round 2 (csrc/rt_queue.h)."""
-        return 72 * rays_per_launch + self.bvh_bytes()
+    def trace_kernel_algorithmic_bytes(self, rays_per_launch, per_ray=40):
+        """DESIGN.md "Roofline": what one launch of traceKernel has to move if every byte moved once: per ray the 32 bytes of the
+        48-byte record the traversal reads (origin, direction, pixel, start primitive: csrc/rt_queue.h) and the 8-byte hit key it
+        merges = 40 B, plus the acceleration structure once (the 4-wide nodes in use and the leaf triangles of both instances).
+        per_ray=72 gives round 1's figure (64-byte record + 8-byte key), kept in the bench line as `algorithmic_bytes_r01`."""
+        return per_ray * rays_per_launch + self.bvh_bytes()
 
     def bvh_bytes(self):
         if not hasattr(self, "_bvh_bytes"):
@@ -237,9 +237,12 @@ class StripRenderer:
             self._bvh_bytes = n
         return self._bvh_bytes
 
-    def frame_algorithmic_bytes(self, rows, metallic_lt_1=False):
-        """146 B/pixel for the all-metal scene (178 with diffuse rays) + the scene once."""
-        return (178 if metallic_lt_1 else 146) * (rows[1] - rows[0]) * self.W + self.bvh_bytes()
+    def frame_algorithmic_bytes(self, rows, metallic_lt_1=False, survey=False):
+        """Bytes of one frame if every pass read each input and wrote each output once (SURVEY.md 8(d) per pass) + the scene once.
+        survey=True: SURVEY's sum, 146 B/pixel for the all-metal scene (178 with diffuse rays).  Default: only the passes this
+        build LAUNCHES -- on all-metal frames the two diffuse filter passes (6 + 22 B/pixel) are not launched, 118 B/pixel."""
+        per_px = 178 if metallic_lt_1 else (146 if survey else 118)
+        return per_px * (rows[1] - rows[0]) * self.W + self.bvh_bytes()
 
     def last_timings(self):
         """Per-pass milliseconds of one extra, fully instrumented frame (outside any timed region)."""

@@ -130,6 +130,27 @@ def test_headless_executable_gpus_flag_starts_one_process_per_gpu(built):
     assert r.returncode == 1 and "-gpus: 1 .. 64" in r.stderr
 
 
+def test_launcher_stops_a_hung_rank_and_refuses_under_a_profiler(built):
+    """LaunchRanks (host/Strips.cpp): a rank that fails takes the others down after a short grace period -- a peer that waits for it inside
+    RCCL would wait for ever --, and the launcher does not fork + exec at all when a profiler or preloaded GPU library is around
+    (such a process has initialised the GPU before main; replacing it is not allowed on this pool)."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "raytracedggx_amd", "RayTracedGGX")
+    args = [exe, "-gpus", "2", "-mesh", assets.path("triangle.obj"), "-env", assets.path("rnl_cross.dds"), "-width", "64", "-height", "64"]
+    t0 = time.time()
+    r = subprocess.run(args, capture_output=True, text=True, timeout=60, env=dict(os.environ, RTGGX_DEBUG_RANK_SLEEP="1:40"))      # rank 0 fails at once (no GPU), rank 1 "hangs"
+    assert r.returncode != 0 and "a rank failed" in r.stderr and time.time() - t0 < 20, r.stderr
+    t0 = time.time()
+    r = subprocess.run(args, capture_output=True, text=True, timeout=60, env=dict(os.environ, RTGGX_DEBUG_RANK_SLEEP="0:40", RTGGX_RANK_TIMEOUT="3"))     # (rank 1 fails; same path)
+    assert r.returncode != 0 and time.time() - t0 < 20, r.stderr
+    for var, val in (("HSA_TOOLS_LIB", "librocprofiler-sdk-tool.so"), ("LD_PRELOAD", "librocprofiler-sdk-does-not-exist.so")):      # (nothing is loaded: the runtime is never initialised, a missing preload is ignored by ld.so)
+        r = subprocess.run(args, capture_output=True, text=True, timeout=60, env=dict(os.environ, **{var: val}))
+        assert r.returncode == 2 and "refusing to start ranks" in r.stderr and "no HIP device" not in r.stderr, (var, r.stderr)
+
+
 def test_cpp_strip_plans_equal_the_python_ones(built):
     """host/Strips.cpp (the executable's multi-GPU host) and raytracedggx_amd/strips.py (what bench.py drives) must cut the frame
     and pair the transfers identically: exchange plans for every rank of 2..8 strips over equal and uneven boundaries, balanced
