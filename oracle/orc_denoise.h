@@ -8,6 +8,7 @@
 // bilinear fetch with clamped addresses (full fp32 weights here); typed stores convert with
 // orc_formats.h.  The H passes store a float3 into RGBA16F: alpha is written as 0 (never read).
 #pragma once
+#include <cstdlib>
 #include "orc_scene.h"
 #include "orc_formats.h"
 
@@ -41,8 +42,20 @@ static inline void load_rgba16(const std::vector<uint64_t>& b, const Ctx& c, int
 // FilterCommon.hlsli
 static inline void TM3(float* rgb) { const float l = 1.0f + ((rgb[0] * 0.25f + rgb[1] * 0.5f) + rgb[2] * 0.25f); rgb[0] /= l; rgb[1] /= l; rgb[2] /= l; }     // :14-19
 static inline void ITM3(float* rgb) { const float l = 1.0f - ((rgb[0] * 0.25f + rgb[1] * 0.5f) + rgb[2] * 0.25f); rgb[0] /= l; rgb[1] /= l; rgb[2] /= l; }    // :24-27
+// pow(x, sigma) with sigma = 512 or 32, the only exponents the filters use (SpatialFilter.hlsli:62,73): by repeated squaring -- 9 or 5
+// fp32 multiplications, part of the numeric contract like pow(x, 5) by multiplication in the shading path (DESIGN.md "Oracle").  HLSL's
+// pow is exp2(y * log2(x)) on 1-ulp hardware functions: for x next to 1 its result is uncertain by ~1e-5, libm's pow is exact to half
+// an ulp, squaring nine times carries ~256 ulps.  None is "the" reference value; what matters downstream is that the two sides of the
+// parity check agree, because the temporal pass turns a 1e-5 difference of its input into a 1e-3 difference of its output on a few bright
+// pixels (variance clamp x inverse tone map; tools/probes/parity_probe.py, profiles/r03_d_parity_1080p.txt).  RTGGX_ORACLE_LIBM_POW=1
+// selects std::pow again (measurement).
 static inline float normal_weight(const float* a, const float* b, float sigma) {   // :34-37
-  return std::pow(std::fmax((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2], 0.0f), sigma);
+  static const bool libmPow = std::getenv("RTGGX_ORACLE_LIBM_POW") != nullptr;
+  float p = std::fmax(std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])), 0.0f);      // a dp3: one multiplication, two fused multiply-adds (as the product's filter)
+  if (libmPow || (sigma != 512.0f && sigma != 32.0f)) return std::pow(p, sigma);
+  p *= p; p *= p; p *= p; p *= p; p *= p;        // ^32
+  if (sigma == 512.0f) { p *= p; p *= p; p *= p; p *= p; }
+  return p;
 }
 static inline float depth_weight(float dc, float d, float sigma) { return std::exp(-std::fabs(dc - d) * dc * sigma); }   // :39-42
 static inline float roughness_weight(float rc, float r, float smin, float smax) { return 1.0f - smoothstep(smin, smax, std::fabs(r - rc)); }   // :44-47

@@ -20,6 +20,39 @@ struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 
 static inline float3 f3(float x, float y, float z) { return {x, y, z}; }
+// (the same text as csrc/rtggx_device.h -- written down twice on purpose: the oracle includes nothing of the product)
+// exp2 / log2 of the shading path, part of the numeric contract: the HLSL intrinsics are ~1-ulp hardware functions, libm's are (almost)
+// correctly rounded, the device library's are 1-ulp again -- three different last bits.  Both sides of the parity check evaluate THIS
+// text instead: range reduction and a fixed polynomial in fp32 (IEEE add / multiply / divide only, no contraction: the same bits on the
+// host and on the device), accurate to ~1.5 ulp -- as close to the reference's hardware functions as those are to each other.
+// (round 3: with these the raw traced images are compared bit for bit; until then a word was allowed to differ by one code.)
+static inline float exp2Contract(float x) {
+  if (!(x > -126.0f)) return x != x ? x : 0.0f;      // (results below the normal range: zero -- the shading path asks for 2^(-9.28 NoV))
+  if (!(x < 128.0f)) return x != x ? x : __builtin_inff();
+  const float n = __builtin_rintf(x);
+  const float t = (x - n) * 0.693147180559945f;      // e^t, |t| <= 0.347: Taylor to t^8 (next term 2e-10)
+  float p = 1.0f / 40320.0f;
+  p = p * t + 1.0f / 5040.0f; p = p * t + 1.0f / 720.0f; p = p * t + 1.0f / 120.0f; p = p * t + 1.0f / 24.0f;
+  p = p * t + 1.0f / 6.0f; p = p * t + 0.5f; p = p * t + 1.0f; p = p * t + 1.0f;
+  union { uint32_t u; float f; } s; s.u = (uint32_t)(127 + (int)n) << 23;      // 2^n, n in [-126, 127]
+  return p * s.f;
+}
+static inline float log2Contract(float x) {
+  if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+  if (!(x < __builtin_inff())) return x;
+  union { float f; uint32_t u; } v; v.f = x;
+  int e = 0;
+  if (v.u < 0x00800000u) { v.f = x * 8388608.0f; e = -23; }      // subnormal: scaled into the normal range
+  e += (int)(v.u >> 23) - 127;
+  v.u = (v.u & 0x007FFFFFu) | 0x3F800000u;                           // mantissa in [1, 2)
+  float m = v.f;
+  if (m > 1.41421356f) { m *= 0.5f; e += 1; }                        // [sqrt(1/2), sqrt(2)): |s| <= 0.1716
+  const float s = (m - 1.0f) / (m + 1.0f), s2 = s * s;
+  float q = 1.0f / 9.0f;                                             // atanh series to s^9 (next term 3e-10)
+  q = q * s2 + 1.0f / 7.0f; q = q * s2 + 1.0f / 5.0f; q = q * s2 + 1.0f / 3.0f; q = q * s2 + 1.0f;
+  return (float)e + ((2.0f * s) * q) * 1.44269504088896f;
+}
+
 static inline float3 operator+(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static inline float3 operator-(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 static inline float3 operator*(float3 a, float3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }

@@ -137,7 +137,7 @@ static inline float3 f_schlick(float3 spec, float VoH) {   // :54-62
 static inline float3 env_brdf_approx(float3 spec, float roughness, float NoV) {   // :64-77
   const float rx = roughness * -1.0f + 1.0f, ry = roughness * -0.0275f + 0.0425f;
   const float rz = roughness * -0.572f + 1.04f, rw = roughness * 0.022f + -0.04f;
-  const float a004 = std::fmin(rx * rx, std::exp2(-9.28f * NoV)) * rx + ry;
+  const float a004 = std::fmin(rx * rx, exp2Contract(-9.28f * NoV)) * rx + ry;
   const float ABx = -1.04f * a004 + rz;
   float ABy = 1.04f * a004 + rw;
   ABy *= saturate(50.0f * spec.y);
@@ -158,7 +158,7 @@ static inline SampleParam get_sample_param(uint32_t px, uint32_t py, uint32_t W,
   return {s, (float)s / 256.0f, (float)(rng(s) & 0xffffu) / 65536.0f};
 }
 static inline float calc_mip_from_roughness(float rgh, float mipCount) {   // :416-422
-  const float level = 3.0f - 1.15f * std::log2(rgh);
+  const float level = 3.0f - 1.15f * log2Contract(rgh);
   return mipCount - 1.0f - level;
 }
 static inline float3 local_to_world(float3 n, float3 l) {   // computeLocalToWorld + combine :129-147

@@ -87,6 +87,23 @@ static void flushToneMap(rtggx_context* c) {
   orderMainBehindTones(c);
   launchPreparedToneMap(c, c->tonePrepared, c->streamMain, nullptr);
 }
+// Would rtggx_tone_map put this frame's tone map aside (see there)?  Everything but "the denoiser ran this frame".
+static bool toneAsideEligible(const rtggx_context* c, const FrameParams& fp) {
+  static const bool toneAside = !(getenv("RTGGX_TONEMAP_ASIDE") && atoi(getenv("RTGGX_TONEMAP_ASIDE")) == 0);
+  return toneAside && !c->callerOrdersOnMain && c->toneAsideAllowed && c->pipeline != 0 && c->asyncCompute && c->attachEvents && c->streamMain == c->ownMain && c->streamRefit != nullptr && !c->timing
+         && !(c->mesh[0].deforming || c->mesh[1].deforming) && !c->lastTraceSmall && fp.rowBegin == 0u && fp.rowEnd == fp.H
+         && (uint64_t)fp.W * fp.H <= RT_TONE_ASIDE_PIXELS;
+}
+// The frames-in-flight fence (evSetRead[set]: the last reader of an input set has ended) rides on a kernel's completion signal, and a
+// kernel that carries an event leaves its queue idle for ~5 us behind it (profiles/r03_c_strip_chain.txt).  So it rides on the LAST
+// kernel the main stream gets for the frame: the tone map when it follows on the main stream (strips, small frames), else the temporal
+// pass, the shading kernel only when an aside tone map waits for it.  A frame that ends earlier -- the caller traces without
+// denoising -- gets the event recorded explicitly by the next frame (settleSetRead).
+static void settleSetRead(rtggx_context* c) {
+  if (c->setReadDeferred < 0) return;
+  hipEventRecord(c->evSetRead[c->setReadDeferred], c->streamMain);
+  c->setReadRecorded[c->setReadDeferred] = true; c->setReadDeferred = -1;
+}
 static hipError_t syncStreams(rtggx_context* c) {
   flushToneMap(c);      // whoever waits for the streams wants the back buffer complete
   hipError_t e = c->ownVis ? hipStreamSynchronize(c->ownVis) : hipSuccess;
@@ -583,6 +600,7 @@ int rtggx_render_visibility(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
   if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamAS); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
+  settleSetRead(c);      // (the previous frame ended without the kernel that would have carried its set's event)
   ++c->frameCounter;
   c->denoiseIssued = false;
   c->selectSet((c->setIndex + 1u) % RT_SETS);
@@ -664,8 +682,9 @@ int rtggx_ray_trace(rtggx_context* c) {
   RT_HIP(hipStreamWaitEvent(c->streamMain, evDone, 0));
   // the main stream has now been given work that reads the current input set: that set may not be overwritten (three frames
   // from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
-  if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain, c->evSetRead[c->setIndex]);
-  c->setReadRecorded[c->setIndex] = true;
+  { const bool carry = c->tonePending || !c->attachEvents;      // an aside tone map (below) waits for this kernel
+    if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr);
+    if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex; }
   if (c->tonePending) {      // the previous frame's tone map: beside this frame's filters (rtggx_tone_map)
     if (c->attachEvents && c->streamRefit != nullptr && !(c->mesh[0].deforming || c->mesh[1].deforming) && !alternate && c->streamMain == c->ownMain) {
       c->tonePending = false;
@@ -687,8 +706,10 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
     if (c->tonePending && c->toneParity == p) flushToneMap(c);
     if (c->toneRecorded[p]) { RT_HIP(hipStreamWaitEvent(c->streamMain, c->evTone[p], 0)); c->toneRecorded[p] = false; } }
   c->denoiseIssued = true;
-  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, c->evSetRead[c->setIndex]);
-  c->setReadRecorded[c->setIndex] = true;
+  // the temporal pass is the last reader of the set; its event rides on the tone map instead when that follows on this stream (settleSetRead)
+  const bool carry = !c->attachEvents || toneAsideEligible(c, c->slots[c->slot]);
+  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr);
+  if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex;
   return r;
 }
 
@@ -707,14 +728,19 @@ int rtggx_tone_map(rtggx_context* c) {
   // or 0.196 ms -- two stable states, a run falls into one --, with diffuse rays 0.304 -> 0.296; dragon 0.222 -> 0.225, dragon with
   // diffuse rays 0.357 -> 0.387 and bunny 4K 0.696 -> 0.702 if it were used there: profiles/r02_c_ab_pipeline.txt block 9).
   flushToneMap(c);
-  static const bool toneAside = !(getenv("RTGGX_TONEMAP_ASIDE") && atoi(getenv("RTGGX_TONEMAP_ASIDE")) == 0);
   const FrameParams& fp = c->slots[c->slot];
-  const bool aside = toneAside && !c->callerOrdersOnMain && c->toneAsideAllowed && c->pipeline != 0 && c->asyncCompute && c->attachEvents && c->streamMain == c->ownMain && c->streamRefit != nullptr && !c->timing
-                     && !(c->mesh[0].deforming || c->mesh[1].deforming) && !c->lastTraceSmall && fp.rowBegin == 0u && fp.rowEnd == fp.H && c->denoiseIssued
-                     && (uint64_t)fp.W * fp.H <= RT_TONE_ASIDE_PIXELS;
+  const bool aside = toneAsideEligible(c, fp) && c->denoiseIssued && c->setReadDeferred < 0;
   if (aside && prepareToneMap(c, fp, &c->tonePrepared)) { c->tonePending = true; c->toneParity = c->frameParity & 1u; ++c->toneAsideCount; return 0; }
   orderMainBehindTones(c);
-  const int r = launchToneMap(c, fp, c->streamMain);
+  // the frame's last kernel on this stream: it carries the set's event if the kernels before it left that to it
+  PreparedToneMap p;
+  int r = 0;
+  if (prepareToneMap(c, fp, &p)) {
+    const bool carry = c->setReadDeferred >= 0 && c->attachEvents;
+    r = launchPreparedToneMap(c, p, c->streamMain, carry ? c->evSetRead[c->setReadDeferred] : nullptr);
+    if (carry) { c->setReadRecorded[c->setReadDeferred] = true; c->setReadDeferred = -1; }
+  }
+  settleSetRead(c);
   if (c->timing) { hipEventRecord(c->tev[10], c->streamMain); c->timingsPending = true; }
   return r;
 }

@@ -78,7 +78,11 @@ struct Centre { float nx, ny, nz, depth, rough, gaussK /* -0.5 log2(e) / sigma^2
 template <bool DIFFUSE>
 RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, float depth, float rough) {
 #pragma clang fp contract(fast)
-  float p = fmaxf((c.nx * nx + c.ny * ny) + c.nz * nz, 0.0f);
+  // N . Nc as one multiplication and two fused multiply-adds (what a dp3 is on the reference's hardware), written out so that the oracle
+  // can evaluate the same three operations: the 512th power multiplies an ulp of this dot product by 512, and the temporal pass
+  // multiplies what is left of it again (variance clamp, inverse tone map: profiles/r03_d_parity_1080p.txt).  The power itself --
+  // nine squarings -- is the numeric contract's on both sides.
+  float p = fmaxf(__builtin_fmaf(c.nz, nz, __builtin_fmaf(c.ny, ny, c.nx * nx)), 0.0f);
   p *= p; p *= p; p *= p; p *= p; p *= p;                 // ^32
   const float dd = fabsf(c.depth - depth) * c.depthK;
   if (DIFFUSE) return p * __builtin_amdgcn_exp2f(-dd);

@@ -32,14 +32,18 @@ RT_DEV uint32_t expandBits10(uint32_t v) {
 // Vertex bounds (the Morton normalisation box) on the device: floats ordered as unsigned integers, one atomic per wave and bound.
 RT_DEV uint32_t orderedBits(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 RT_DEV float fromOrderedBits(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
-__global__ void boundsKernel(const float* __restrict__ verts, uint32_t nv, uint32_t* __restrict__ bounds /* min[3] max[3], ordered bits */) {
+__global__ void __launch_bounds__(256) boundsKernel(const float* __restrict__ verts, uint32_t nv, uint32_t* __restrict__ bounds /* min[3] max[3], ordered bits */) {
+  __shared__ float red[4][6];
   float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
   for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += gridDim.x * blockDim.x)
     for (int k = 0; k < 3; ++k) { const float x = verts[6 * (size_t)v + k]; mn[k] = fminf(mn[k], x); mx[k] = fmaxf(mx[k], x); }
   for (int k = 0; k < 3; ++k) {
     for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_down(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_down(mx[k], o)); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&bounds[k], orderedBits(mn[k])); atomicMax(&bounds[3 + k], orderedBits(mx[k])); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][k] = mn[k]; red[threadIdx.x >> 6][3 + k] = mx[k]; }
   }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], orderedBits(fminf(fminf(red[0][threadIdx.x], red[1][threadIdx.x]), fminf(red[2][threadIdx.x], red[3][threadIdx.x]))));
+  else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], orderedBits(fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]))));
 }
 __global__ void mortonKernel(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t n,
                              const uint32_t* __restrict__ bounds, uint32_t* __restrict__ codes, uint32_t* __restrict__ order,
@@ -77,26 +81,42 @@ __global__ void __launch_bounds__(256) radixHist(const uint32_t* __restrict__ ke
   __syncthreads();
   hist[threadIdx.x * numBlocks + blockIdx.x] = h[threadIdx.x];
 }
-// exclusive scan of `count` values by one workgroup
-__global__ void __launch_bounds__(1024) scanExclusive(uint32_t* __restrict__ data, uint32_t count) {
-  __shared__ uint32_t partial[1024];
-  const uint32_t per = (count + 1023) / 1024;
-  const uint32_t b = threadIdx.x * per, e = min(b + per, count);
-  uint32_t s = 0;
-  for (uint32_t i = b; i < e; ++i) s += data[i];
-  // exclusive scan of the 1024 partial sums: inside each wave with shuffles, then over the 16 wave totals
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t inc = s;
-  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += v; }
-  if (lane == 63u) partial[wave] = inc;
+// Exclusive scan of `count` values in two steps (a single workgroup took 106 us per pass for the bunny's 70 000 histogram entries,
+// a third of the whole build): scanChunks -- one workgroup per 1024 values: the exclusive scan inside the chunk and the chunk's total --,
+// scanTotals -- one workgroup: the exclusive scan of the totals.  A consumer adds chunkSums[index >> 10] to the value it reads.
+__global__ void __launch_bounds__(1024) scanChunks(uint32_t* __restrict__ data, uint32_t count, uint32_t* __restrict__ chunkSums) {
+  __shared__ uint32_t waveTotal[16];
+  const uint32_t i = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t v = i < count ? data[i] : 0u;
+  uint32_t inc = v;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += u; }
+  if (lane == 63u) waveTotal[wave] = inc;
   __syncthreads();
   uint32_t base = 0;
-  for (uint32_t w = 0; w < wave; ++w) base += partial[w];
-  uint32_t run = base + inc - s;
-  for (uint32_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
+  for (uint32_t w = 0; w < wave; ++w) base += waveTotal[w];
+  if (i < count) data[i] = base + inc - v;
+  if (threadIdx.x == 1023u) chunkSums[blockIdx.x] = base + inc;
+}
+__global__ void __launch_bounds__(1024) scanTotals(uint32_t* __restrict__ sums, uint32_t n) {
+  __shared__ uint32_t waveTotal[16];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (uint32_t c0 = 0; c0 < n; c0 += 1024u) {
+    const uint32_t i = c0 + threadIdx.x;
+    const uint32_t v = i < n ? sums[i] : 0u;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += u; }
+    if (lane == 63u) waveTotal[wave] = inc;
+    __syncthreads();
+    uint32_t base = carry, total = 0;
+    for (uint32_t w = 0; w < 16u; ++w) { if (w < wave) base += waveTotal[w]; total += waveTotal[w]; }
+    if (i < n) sums[i] = base + inc - v;
+    carry += total;
+    __syncthreads();
+  }
 }
 __global__ void __launch_bounds__(256) radixScatter(const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t n, int shift,
-                                                    const uint32_t* __restrict__ hist, uint32_t numBlocks,
+                                                    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunkSums, uint32_t numBlocks,
                                                     uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut) {
   __shared__ uint32_t waveCount[4][256];
   for (int w = 0; w < 4; ++w) waveCount[w][threadIdx.x] = 0;
@@ -115,7 +135,8 @@ __global__ void __launch_bounds__(256) radixScatter(const uint32_t* __restrict__
   if (active && rankInWave == 0) waveCount[wave][digit] = (uint32_t)__popcll(peers);
   __syncthreads();
   if (active) {
-    uint32_t off = hist[digit * numBlocks + blockIdx.x] + rankInWave;
+    const uint32_t h = digit * numBlocks + blockIdx.x;
+    uint32_t off = hist[h] + chunkSums[h >> 10] + rankInWave;
     for (uint32_t w = 0; w < wave; ++w) off += waveCount[w][digit];
     keysOut[off] = key; valsOut[off] = valsIn[i];
   }
@@ -183,7 +204,7 @@ __global__ void fitKernel(int n, const uint32_t* __restrict__ order, const float
 // Everything is deterministic: ties go to the lower position, node indices come from prefix sums.
 //
 // Device-driven (round 3).  How many clusters a round leaves is known on the device only, so nothing on the host depends on it:
-// the host issues a FIXED number of rounds sized from the triangle count (each round: plocNearest, plocCount, plocScatter, all with
+// the host issues a FIXED number of rounds sized from the triangle count (each round: plocNearest, plocScatter, both with
 // the grid of the first round -- workgroups beyond the clusters left leave at once), then plocFinal, ONE workgroup that runs rounds
 // until a single cluster is left, whatever it is handed (normally <= 2048 clusters; if the fixed rounds merged less than expected it
 // simply has more to do).  The state between rounds -- clusters left, next node index, rounds so far -- lives in a two-entry ring in
@@ -227,11 +248,59 @@ RT_DEV int plocNearestOf(int i, int m, int radius, const float* __restrict__ clB
   }
   return bj;
 }
-__global__ void __launch_bounds__(256) plocNearest(const PlocState* __restrict__ state, uint32_t r, int radius, PlocArrays A) {
+// A round's first kernel: nearest neighbours, the keep / merge flags they imply, and the workgroup's counts of both.  A workgroup
+// owns 256 positions and stages the boxes of those and of 2 x radius positions to either side in LDS: the flags of position i need the
+// nearest neighbour of i's nearest neighbour (within the radius of i), whose own search reaches another radius further.  (Round 3
+// began with two kernels -- nearest, then flags + counts --: with ~14 rounds to issue, a launch less per round is 100 us of the build.)
+#define RT_PLOC_APRON (2 * RT_PLOC_RADIUS)
+__global__ void __launch_bounds__(256) plocNearest(const PlocState* __restrict__ state, uint32_t r, int radius, PlocArrays A, uint2* __restrict__ blockCounts) {
+  __shared__ float box[6][256 + 2 * RT_PLOC_APRON];
+  __shared__ int32_t nnS[256 + 2 * RT_PLOC_RADIUS];
+  __shared__ uint32_t wk[4], wm[4];
   const int m = (int)state[r & 1u].m;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (m <= 1 || i >= m) return;
-  A.nn[i] = plocNearestOf(i, m, radius, A.clBox[r & 1u]);
+  if (m <= 1 || (int)(blockIdx.x * 256) >= m) return;
+  if (radius > RT_PLOC_RADIUS) radius = RT_PLOC_RADIUS;
+  const float* __restrict__ clBox = A.clBox[r & 1u];
+  const int b0 = (int)(blockIdx.x * 256), lo = b0 - RT_PLOC_APRON;      // LDS entry e holds position lo + e
+  for (int e = threadIdx.x; e < 256 + 2 * RT_PLOC_APRON; e += 256) {
+    const int pos = lo + e;
+    if (pos >= 0 && pos < m) for (int k = 0; k < 6; ++k) box[k][e] = clBox[6 * (size_t)pos + k];
+  }
+  __syncthreads();
+  // nearest neighbour of positions [b0 - radius, b0 + 256 + radius): smallest merged box, ties to the lower position
+  for (int q = threadIdx.x; q < 256 + 2 * RT_PLOC_RADIUS; q += 256) {
+    const int i = b0 - RT_PLOC_RADIUS + q;
+    int bj = -1;
+    if (i >= 0 && i < m) {
+      const int ei = i - lo;
+      float mine[6];
+      for (int k = 0; k < 6; ++k) mine[k] = box[k][ei];
+      float best = __builtin_inff();
+      const int jl = max(i - radius, 0), jh = min(i + radius, m - 1);
+      for (int j = jl; j <= jh; ++j) {
+        if (j == i) continue;
+        const int ej = j - lo;
+        const float ex = fmaxf(mine[3], box[3][ej]) - fminf(mine[0], box[0][ej]), ey = fmaxf(mine[4], box[4][ej]) - fminf(mine[1], box[1][ej]), ez = fmaxf(mine[5], box[5][ej]) - fminf(mine[2], box[2][ej]);
+        const float d = (ex * ey + ey * ez) + ez * ex;
+        if (d < best) { best = d; bj = j; }
+      }
+    }
+    nnS[q] = bj;
+  }
+  __syncthreads();
+  const int i = b0 + (int)threadIdx.x;
+  uint32_t keep = 0u, merge = 0u;
+  if (i < m) {
+    const int j = nnS[i - b0 + RT_PLOC_RADIUS];
+    A.nn[i] = j;
+    const bool mutual = j >= 0 && nnS[j - b0 + RT_PLOC_RADIUS] == i;
+    merge = mutual && i < j ? 1u : 0u;
+    keep = mutual && i > j ? 0u : 1u;
+  }
+  const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u);
+  if ((threadIdx.x & 63u) == 0u) { wk[threadIdx.x >> 6] = (uint32_t)__popcll(bk); wm[threadIdx.x >> 6] = (uint32_t)__popcll(bm); }
+  __syncthreads();
+  if (threadIdx.x == 0) blockCounts[blockIdx.x] = make_uint2(wk[0] + wk[1] + wk[2] + wk[3], wm[0] + wm[1] + wm[2] + wm[3]);
 }
 // keep / merge flags of position i: mutual nearest neighbours merge, the lower position carries the new node, the higher one disappears
 RT_DEV void plocFlags(int i, int m, const int32_t* __restrict__ nn, int& j, bool& mutual, uint32_t& keep, uint32_t& merge) {
@@ -241,17 +310,6 @@ RT_DEV void plocFlags(int i, int m, const int32_t* __restrict__ nn, int& j, bool
   mutual = j >= 0 && nn[j] == i;
   merge = mutual && i < j ? 1u : 0u;
   keep = mutual && i > j ? 0u : 1u;
-}
-__global__ void __launch_bounds__(256) plocCount(const PlocState* __restrict__ state, uint32_t r, const int32_t* __restrict__ nn, uint2* __restrict__ blockCounts) {
-  const int m = (int)state[r & 1u].m;
-  if (m <= 1 || (int)(blockIdx.x * 256) >= m) return;
-  int j; bool mutual; uint32_t keep, merge;
-  plocFlags(blockIdx.x * 256 + threadIdx.x, m, nn, j, mutual, keep, merge);
-  __shared__ uint32_t wk[4], wm[4];
-  const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u);
-  if ((threadIdx.x & 63u) == 0u) { wk[threadIdx.x >> 6] = (uint32_t)__popcll(bk); wm[threadIdx.x >> 6] = (uint32_t)__popcll(bm); }
-  __syncthreads();
-  if (threadIdx.x == 0) blockCounts[blockIdx.x] = make_uint2(wk[0] + wk[1] + wk[2] + wk[3], wm[0] + wm[1] + wm[2] + wm[3]);
 }
 // Position i survives at position p of the next round's list: as itself, or merged with j into node `node`.  A new node also gets, per
 // treelet level, the number of nodes of its subtree that level still has to place (its children are older: their counts are final).
@@ -309,13 +367,22 @@ __global__ void __launch_bounds__(256) plocScatter(PlocState* __restrict__ state
 }
 // One workgroup finishes the clustering: rounds until one cluster is left (each merges at least one pair: it ends), then the root's
 // parent, the last roundBase entry and the round count.  `r`: the rounds issued before it (it reads state entry r & 1).
+// While more than RT_PLOC_LDS clusters are left the rounds run as above, on the lists in global memory; from then on the clusters --
+// reference, box, subtree counts -- live in LDS: the tail of the clustering is ~40 rounds that merge a handful of pairs each, and
+// from global memory a round of ONE workgroup is a chain of L2 round trips (9.5 us per round, 360 us for the bunny: a quarter of its
+// build; in LDS 1 us).  A round compacts the list in place: every thread first reads what it needs into registers, then writes.
+#define RT_PLOC_LDS 2048
+struct PlocLds {
+  int32_t ref[RT_PLOC_LDS]; float box[6][RT_PLOC_LDS]; uint32_t cnt[RT_TREELET_LEVELS][RT_PLOC_LDS]; int32_t nn[RT_PLOC_LDS];
+  uint32_t wk[16], wm[16];
+};
 __global__ void __launch_bounds__(1024) plocFinal(const PlocState* __restrict__ state, uint32_t r, int radius, uint32_t n, PlocArrays A) {
-  __shared__ uint32_t wk[16], wm[16];
+  __shared__ PlocLds L;
   const PlocState st = state[r & 1u];
   uint32_t m = st.m, nodeBase = st.nodeBase, rounds = st.rounds, p = r & 1u;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
-  while (m > 1u) {
+  while (m > RT_PLOC_LDS) {      // (only when the rounds before merged less than expected)
     const int32_t* clRef = A.clRef[p]; const float* clBox = A.clBox[p];
     for (uint32_t i = threadIdx.x; i < m; i += 1024u) A.nn[i] = plocNearestOf((int)i, (int)m, radius, clBox);
     __syncthreads();
@@ -325,16 +392,92 @@ __global__ void __launch_bounds__(1024) plocFinal(const PlocState* __restrict__ 
       int j; bool mutual; uint32_t keep, merge;
       plocFlags(i, (int)m, A.nn, j, mutual, keep, merge);
       const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u);
-      if (lane == 0u) { wk[wave] = (uint32_t)__popcll(bk); wm[wave] = (uint32_t)__popcll(bm); }
+      if (lane == 0u) { L.wk[wave] = (uint32_t)__popcll(bk); L.wm[wave] = (uint32_t)__popcll(bm); }
       __syncthreads();
       uint32_t rk = (uint32_t)__popcll(bk & below), rm = (uint32_t)__popcll(bm & below), totK = 0, totM = 0;
-      for (uint32_t w = 0; w < 16u; ++w) { if (w < wave) { rk += wk[w]; rm += wm[w]; } totK += wk[w]; totM += wm[w]; }
+      for (uint32_t w = 0; w < 16u; ++w) { if (w < wave) { rk += L.wk[w]; rm += L.wm[w]; } totK += L.wk[w]; totM += L.wm[w]; }
       if (keep) plocEmit(i, j, mutual, keptBase + rk, (int)(nodeBase + mergedBase + rm), clRef, clBox, A.clRef[p ^ 1u], A.clBox[p ^ 1u], A);
       keptBase += totK; mergedBase += totM;
       __syncthreads();
     }
     if (threadIdx.x == 0) { if (rounds < RT_MAX_ROUNDS) A.roundBase[rounds] = nodeBase; else atomicOr(&A.res->error, 1u); }
     ++rounds; nodeBase += mergedBase; m = keptBase; p ^= 1u;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { A.res->finalEntry = st.m; A.res->finalLds = m; }      // (statistics: clusters handed over, clusters at the start of the LDS rounds)
+  // the clusters into LDS
+  for (uint32_t i = threadIdx.x; i < m; i += 1024u) {
+    const int32_t ref = A.clRef[p][i];
+    L.ref[i] = ref;
+    for (int k = 0; k < 6; ++k) L.box[k][i] = A.clBox[p][6 * (size_t)i + k];
+    for (int l = 0; l < RT_TREELET_LEVELS; ++l) L.cnt[l][i] = ref >= 0 ? A.cnt[l][ref] : 0u;
+  }
+  __syncthreads();
+  while (m > 1u) {
+    for (uint32_t i = threadIdx.x; i < m; i += 1024u) {      // nearest neighbour within the radius, smallest merged box, ties to the lower position
+      float mine[6];
+      for (int k = 0; k < 6; ++k) mine[k] = L.box[k][i];
+      float best = __builtin_inff(); int bj = -1;
+      const int lo = max((int)i - radius, 0), hi = min((int)i + radius, (int)m - 1);
+      for (int j = lo; j <= hi; ++j) {
+        if (j == (int)i) continue;
+        const float ex = fmaxf(mine[3], L.box[3][j]) - fminf(mine[0], L.box[0][j]), ey = fmaxf(mine[4], L.box[4][j]) - fminf(mine[1], L.box[1][j]), ez = fmaxf(mine[5], L.box[5][j]) - fminf(mine[2], L.box[2][j]);
+        const float d = (ex * ey + ey * ez) + ez * ex;
+        if (d < best) { best = d; bj = j; }
+      }
+      L.nn[i] = bj;
+    }
+    __syncthreads();
+    // flags, ranks and everything a surviving position needs, into registers (two positions per thread) ...
+    struct Out { bool keep, mutual; uint32_t pos; int32_t node, l, r; float box[6]; uint32_t cnt[RT_TREELET_LEVELS]; } out[RT_PLOC_LDS / 1024];
+    uint32_t keptBase = 0, mergedBase = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < RT_PLOC_LDS / 1024; ++c) {      // (unrolled: `out` must stay in registers)
+      if (c * 1024u >= m) { out[c].keep = false; continue; }   // uniform
+      const int i = (int)(c * 1024u + threadIdx.x);
+      int j; bool mutual; uint32_t keep, merge;
+      plocFlags(i, (int)m, L.nn, j, mutual, keep, merge);
+      const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u);
+      if (lane == 0u) { L.wk[wave] = (uint32_t)__popcll(bk); L.wm[wave] = (uint32_t)__popcll(bm); }
+      __syncthreads();
+      uint32_t rk = (uint32_t)__popcll(bk & below), rm = (uint32_t)__popcll(bm & below), totK = 0, totM = 0;
+      for (uint32_t w = 0; w < 16u; ++w) { if (w < wave) { rk += L.wk[w]; rm += L.wm[w]; } totK += L.wk[w]; totM += L.wm[w]; }
+      Out& o = out[c];
+      o.keep = keep != 0u; o.mutual = mutual;
+      if (o.keep) {
+        o.pos = keptBase + rk; o.node = (int32_t)(nodeBase + mergedBase + rm);
+        o.l = L.ref[i];
+        if (mutual) {
+          o.r = L.ref[j];
+          for (int k = 0; k < 3; ++k) { o.box[k] = fminf(L.box[k][i], L.box[k][j]); o.box[3 + k] = fmaxf(L.box[3 + k][i], L.box[3 + k][j]); }
+          uint32_t belowCnt = 0xFFFFFFFFu;
+          for (int l = 0; l < RT_TREELET_LEVELS; ++l) { const uint32_t cc = belowCnt > RT_TREELET_NODES ? 1u + L.cnt[l][i] + L.cnt[l][j] : 0u; o.cnt[l] = cc; belowCnt = cc; }
+        } else {
+          for (int k = 0; k < 6; ++k) o.box[k] = L.box[k][i];
+          for (int l = 0; l < RT_TREELET_LEVELS; ++l) o.cnt[l] = L.cnt[l][i];
+        }
+      }
+      keptBase += totK; mergedBase += totM;
+      __syncthreads();
+    }
+    // ... then the compacted list in place, and the new nodes
+#pragma unroll
+    for (uint32_t c = 0; c < RT_PLOC_LDS / 1024; ++c) {
+      const Out& o = out[c];
+      if (!o.keep) continue;
+      L.ref[o.pos] = o.mutual ? o.node : o.l;
+      for (int k = 0; k < 6; ++k) L.box[k][o.pos] = o.box[k];
+      for (int l = 0; l < RT_TREELET_LEVELS; ++l) L.cnt[l][o.pos] = o.cnt[l];
+      if (o.mutual) {
+        A.left[o.node] = o.l; A.right[o.node] = o.r;
+        if (o.l < 0) A.leafParent[~o.l] = o.node; else A.nodeParent[o.l] = o.node;
+        if (o.r < 0) A.leafParent[~o.r] = o.node; else A.nodeParent[o.r] = o.node;
+        for (int k = 0; k < 6; ++k) A.nodeBox[6 * (size_t)o.node + k] = o.box[k];
+        for (int l = 0; l < RT_TREELET_LEVELS; ++l) A.cnt[l][o.node] = o.cnt[l];
+      }
+    }
+    if (threadIdx.x == 0) { if (rounds < RT_MAX_ROUNDS) A.roundBase[rounds] = nodeBase; else atomicOr(&A.res->error, 1u); }
+    ++rounds; nodeBase += mergedBase; m = keptBase;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -350,7 +493,10 @@ __global__ void depthKernel(int n, const int32_t* __restrict__ nodeParent, const
   uint32_t d = 0;
   if (leaf < n) for (int cur = leafParent[leaf]; cur >= 0; cur = nodeParent[cur]) ++d;
   for (int o = 32; o > 0; o >>= 1) d = max(d, (uint32_t)__shfl_down((int)d, o));
-  if ((threadIdx.x & 63) == 0 && d) atomicMax(maxDepth, d);
+  __shared__ uint32_t red[16];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t w = 1; w < (blockDim.x + 63u) / 64u; ++w) d = max(d, red[w]); if (d) atomicMax(maxDepth, d); }
 }
 
 __global__ void emitNodes(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
@@ -481,80 +627,48 @@ __global__ void treeletRootsKernel(int numNodes, int level, const uint32_t* __re
   if (p >= 0 && cntCur[p] <= RT_TREELET_NODES) return;           // an inner node of somebody else's treelet
   roots[treeletBase(res, level) + atomicAdd(&res->treelets[level], 1u)] = i;
 }
+// The treelet below each root of `level`: its pending nodes breadth first, stored in REVERSE -- children before parents --, one round
+// per level of the walk (deepest first).  (The first version sorted the nodes by index = by PLOC round: a bitonic sort and two binary
+// searches per item; the levels of the walk order the nodes just as well.)
 __global__ void __launch_bounds__(256) buildTreeletsKernel(int level, const uint32_t* __restrict__ cntPrev, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
-                                                           const uint32_t* __restrict__ roundBase, const int32_t* __restrict__ roots,
+                                                           const int32_t* __restrict__ roots,
                                                            RefitTreelet* __restrict__ treelets, int4* __restrict__ items, uint32_t* __restrict__ rounds, BuildResult* res) {
-  __shared__ int32_t list[RT_TREELET_NODES];
-  __shared__ uint32_t sCount, sHead, sItemBegin, sRoundBegin, waveSum[4];
-  const uint32_t base = treeletBase(res, level), K = res->treelets[level], numRounds = res->numRounds;
+  __shared__ int32_t list[RT_TREELET_NODES], refL[RT_TREELET_NODES], refR[RT_TREELET_NODES];
+  __shared__ uint32_t levelStart[RT_TREELET_NODES + 1];
+  __shared__ uint32_t sCount, sHead, sLevels, sItemBegin, sRoundBegin;
+  const uint32_t base = treeletBase(res, level), K = res->treelets[level];
   const auto pending = [&](int32_t x) { return level == 0 || cntPrev[x] > RT_TREELET_NODES; };
   for (uint32_t k = blockIdx.x; k < K; k += gridDim.x) {
-    // the pending nodes below the root, breadth first
-    if (threadIdx.x == 0) { list[0] = roots[base + k]; sCount = 1u; sHead = 0u; }
+    if (threadIdx.x == 0) { list[0] = roots[base + k]; sCount = 1u; sHead = 0u; sLevels = 0u; }
     __syncthreads();
     for (;;) {
-      const uint32_t head = sHead, count = sCount;
+      const uint32_t head = sHead, count = min(sCount, (uint32_t)RT_TREELET_NODES);
       if (head >= count) break;
       __syncthreads();      // everybody has read head / count
+      if (threadIdx.x == 0) levelStart[sLevels++] = head;
       for (uint32_t idx = head + threadIdx.x; idx < count; idx += 256u) {
         const int32_t v = list[idx];
-        const int32_t L = left[v], R = right[v];
-        if (L >= 0 && pending(L)) { const uint32_t q = atomicAdd(&sCount, 1u); if (q < RT_TREELET_NODES) list[q] = L; }
-        if (R >= 0 && pending(R)) { const uint32_t q = atomicAdd(&sCount, 1u); if (q < RT_TREELET_NODES) list[q] = R; }
+        const int32_t lc = left[v], rc = right[v];
+        // a child reference: < 0 as it will be stored (leaf / node of a lower level); >= 0 the child's position in the walk (turned round below)
+        int32_t a = lc < 0 ? (int32_t)(0xC0000000u | (uint32_t)~lc) : (int32_t)(0x80000000u | (uint32_t)lc);
+        int32_t b = rc < 0 ? (int32_t)(0xC0000000u | (uint32_t)~rc) : (int32_t)(0x80000000u | (uint32_t)rc);
+        if (lc >= 0 && pending(lc)) { const uint32_t q = atomicAdd(&sCount, 1u); if (q < RT_TREELET_NODES) { list[q] = lc; a = (int32_t)q; } }
+        if (rc >= 0 && pending(rc)) { const uint32_t q = atomicAdd(&sCount, 1u); if (q < RT_TREELET_NODES) { list[q] = rc; b = (int32_t)q; } }
+        refL[idx] = a; refR[idx] = b;
       }
       __syncthreads();
       if (threadIdx.x == 0) sHead = count;
       __syncthreads();
     }
-    const uint32_t count = min(sCount, (uint32_t)RT_TREELET_NODES);
-    // by node index = by PLOC round (indices are handed out round by round): bitonic sort of the padded list
-    for (uint32_t idx = count + threadIdx.x; idx < RT_TREELET_NODES; idx += 256u) list[idx] = 0x7FFFFFFF;
+    const uint32_t count = min(sCount, (uint32_t)RT_TREELET_NODES), levels = sLevels;
+    if (threadIdx.x == 0) { levelStart[levels] = count; sItemBegin = atomicAdd(&res->itemCursor, count); sRoundBegin = atomicAdd(&res->roundCursor, levels + 1u); }
     __syncthreads();
-    for (uint32_t kk = 2u; kk <= RT_TREELET_NODES; kk <<= 1)
-      for (uint32_t jj = kk >> 1; jj > 0u; jj >>= 1) {
-        for (uint32_t idx = threadIdx.x; idx < RT_TREELET_NODES; idx += 256u) {
-          const uint32_t ixj = idx ^ jj;
-          if (ixj > idx) {
-            const int32_t a = list[idx], b = list[ixj];
-            const bool asc = (idx & kk) == 0u;
-            if ((a > b) == asc) { list[idx] = b; list[ixj] = a; }
-          }
-        }
-        __syncthreads();
-      }
-    if (threadIdx.x == 0) sItemBegin = atomicAdd(&res->itemCursor, count);
-    __syncthreads();
-    const auto position = [&](int32_t node) { uint32_t lo = 0, hi = count; while (lo + 1u < hi) { const uint32_t mid = (lo + hi) >> 1; if (list[mid] <= node) lo = mid; else hi = mid; } return (int32_t)lo; };
-    const auto ref = [&](int32_t ch) -> int32_t {
-      if (ch < 0) return (int32_t)(0xC0000000u | (uint32_t)~ch);
-      if (pending(ch)) return position(ch);
-      return (int32_t)(0x80000000u | (uint32_t)ch);
-    };
-    const auto roundOf = [&](int32_t node) { uint32_t lo = 0, hi = numRounds; while (lo + 1u < hi) { const uint32_t mid = (lo + hi) >> 1; if (roundBase[mid] <= (uint32_t)node) lo = mid; else hi = mid; } return lo; };
-    // items, and the positions at which a new round starts: four consecutive positions per thread, prefix sum over the workgroup
-    uint32_t flags[4], mine = 0;
-    for (uint32_t q = 0; q < 4u; ++q) {
-      const uint32_t idx = threadIdx.x * 4u + q;
-      flags[q] = 0u;
-      if (idx < count) {
-        const int32_t v = list[idx];
-        items[sItemBegin + idx] = make_int4(v, ref(left[v]), ref(right[v]), 0);
-        flags[q] = idx == 0u || roundOf(v) != roundOf(list[idx - 1u]) ? 1u : 0u;
-        mine += flags[q];
-      }
+    for (uint32_t idx = threadIdx.x; idx < count; idx += 256u) {
+      const int32_t a = refL[idx], b = refR[idx];
+      items[sItemBegin + (count - 1u - idx)] = make_int4(list[idx], a >= 0 ? (int32_t)(count - 1u) - a : a, b >= 0 ? (int32_t)(count - 1u) - b : b, 0);
     }
-    uint32_t inc = mine;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += v; }
-    if (lane == 63u) waveSum[wave] = inc;
-    __syncthreads();
-    uint32_t pos = inc - mine;
-    for (uint32_t w = 0; w < wave; ++w) pos += waveSum[w];
-    const uint32_t total = waveSum[0] + waveSum[1] + waveSum[2] + waveSum[3];
-    if (threadIdx.x == 0) sRoundBegin = atomicAdd(&res->roundCursor, total + 1u);
-    __syncthreads();
-    for (uint32_t q = 0; q < 4u; ++q) if (flags[q]) rounds[sRoundBegin + pos++] = threadIdx.x * 4u + q;
-    if (threadIdx.x == 0) { rounds[sRoundBegin + total] = count; RefitTreelet tl; tl.itemBegin = sItemBegin; tl.roundBegin = sRoundBegin; tl.numRounds = total; tl.pad = 0u; treelets[base + k] = tl; }
+    for (uint32_t rr = threadIdx.x; rr <= levels; rr += 256u) rounds[sRoundBegin + rr] = count - levelStart[levels - rr];      // round rr = level (levels - 1 - rr)
+    if (threadIdx.x == 0) { RefitTreelet tl; tl.itemBegin = sItemBegin; tl.roundBegin = sRoundBegin; tl.numRounds = levels; tl.pad = 0u; treelets[base + k] = tl; }
     __syncthreads();
   }
 }
@@ -579,16 +693,18 @@ __global__ void refitTris(int n, const uint32_t* __restrict__ order, const float
 }
 // Sum of the half-areas of all node boxes: the tree's SAH cost up to constants.  A refit keeps the topology the build chose for
 // the OLD shape; when this sum has grown by RT_REFIT_REBUILD_RATIO the host rebuilds (capi.hip).
-__global__ void treeCostKernel(int numNodes, const float* __restrict__ nodeBox, float* __restrict__ cost) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) treeCostKernel(int numNodes, const float* __restrict__ nodeBox, float* __restrict__ cost) {
+  __shared__ float red[4];
   float a = 0.0f;
-  if (i < numNodes) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < numNodes; i += gridDim.x * 256) {      // (few workgroups: the atomics on one word are what this kernel costs)
     const float* b = nodeBox + 6 * (size_t)i;
     const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
-    a = (ex * ey + ey * ez) + ez * ex;
+    a += (ex * ey + ey * ez) + ez * ex;
   }
   for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
-  if ((threadIdx.x & 63) == 0 && a != 0.0f) atomicAdd(cost, a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) { const float t = (red[0] + red[1]) + (red[2] + red[3]); if (t != 0.0f) atomicAdd(cost, t); }
 }
 
 // One workgroup refits one treelet (see "the refit schedule" above): round by round, the treelet's boxes in LDS.
@@ -652,7 +768,7 @@ static void freeTopo(BvhTopo& t) {
 
 // ---- a build as a list of launches ------------------------------------------------------------------------------------------------
 struct BuildScratch {
-  uint32_t *codes[2] = {}, *order2 = nullptr, *hist = nullptr, *bounds = nullptr, *arrive = nullptr;
+  uint32_t *codes[2] = {}, *order2 = nullptr, *hist = nullptr, *chunkSums = nullptr, *bounds = nullptr, *arrive = nullptr;
   int32_t *clRef[2] = {}, *nn = nullptr; float* clBox[2] = {}; uint2* blockCounts = nullptr; PlocState* state = nullptr;
   float* vertsSnapshot = nullptr;      // a rebuild beside the frames works on a copy of the vertices it started from
 };
@@ -666,7 +782,7 @@ struct BuildJob {
   uint32_t numTris = 0, numVerts = 0;
 };
 static void freeScratch(BuildScratch& s) {
-  hipFree(s.codes[0]); hipFree(s.codes[1]); hipFree(s.order2); hipFree(s.hist); hipFree(s.bounds); hipFree(s.arrive);
+  hipFree(s.codes[0]); hipFree(s.codes[1]); hipFree(s.order2); hipFree(s.hist); hipFree(s.chunkSums); hipFree(s.bounds); hipFree(s.arrive);
   hipFree(s.clRef[0]); hipFree(s.clRef[1]); hipFree(s.nn); hipFree(s.clBox[0]); hipFree(s.clBox[1]); hipFree(s.blockCounts); hipFree(s.state); hipFree(s.vertsSnapshot);
   s = BuildScratch{};
 }
@@ -695,19 +811,20 @@ static int allocTopo(BvhTopo& t, uint32_t n) {
 static int allocScratch(BuildScratch& s, uint32_t n, uint32_t nv, bool snapshot) {
   const size_t nn = n > 1 ? n : 2, nb = (n + 255) / 256;
   RT_HIP(hipMalloc(&s.codes[0], 4 * nn)); RT_HIP(hipMalloc(&s.codes[1], 4 * nn)); RT_HIP(hipMalloc(&s.order2, 4 * nn));
-  RT_HIP(hipMalloc(&s.hist, 4 * 256 * nb)); RT_HIP(hipMalloc(&s.bounds, 4 * 8)); RT_HIP(hipMalloc(&s.arrive, 4 * (nn + 1)));
+  RT_HIP(hipMalloc(&s.hist, 4 * 256 * nb)); RT_HIP(hipMalloc(&s.chunkSums, 4 * ((256 * nb + 1023) / 1024 + 1))); RT_HIP(hipMalloc(&s.bounds, 4 * 8)); RT_HIP(hipMalloc(&s.arrive, 4 * (nn + 1)));
   RT_HIP(hipMalloc(&s.clRef[0], 4 * nn)); RT_HIP(hipMalloc(&s.clRef[1], 4 * nn)); RT_HIP(hipMalloc(&s.nn, 4 * nn));
   RT_HIP(hipMalloc(&s.clBox[0], 24 * nn)); RT_HIP(hipMalloc(&s.clBox[1], 24 * nn));
   RT_HIP(hipMalloc(&s.blockCounts, sizeof(uint2) * nb)); RT_HIP(hipMalloc(&s.state, 2 * sizeof(PlocState)));
   if (snapshot) RT_HIP(hipMalloc(&s.vertsSnapshot, sizeof(float) * 6 * (size_t)nv));
   return 0;
 }
-// How many multi-workgroup rounds the host issues: until ~2048 clusters are expected to be left, at the ~0.62 a round keeps on the bunny
-// and the dragon, plus two (a round that keeps more only leaves plocFinal more to do).
+// How many multi-workgroup rounds the host issues: until RT_PLOC_LDS clusters are expected to be left, at the ~0.77 of its clusters a
+// round keeps (bunny: 69 666 -> 6 252 in nine rounds, dragon: 100 000 -> 14 319 in ten; RTGGX_BUILD_LOG), plus one.  A round that keeps
+// more only leaves plocFinal more to do: it starts on the lists in global memory.
 static uint32_t plocRoundsFor(uint32_t n) {
   uint32_t rounds = 0; double m = (double)n;
-  while (m > 2048.0) { m *= 0.66; ++rounds; }
-  return rounds ? rounds + 2u : 0u;
+  while (m > (double)RT_PLOC_LDS) { m *= 0.77; ++rounds; }
+  return rounds ? rounds + 1u : 0u;
 }
 
 // The launches of one build of mesh `slot` from `verts` (device; the job's snapshot when `snapshotFrom` is given), into job.topo.
@@ -720,15 +837,17 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
   const uint32_t* indices = m.indices;
   if (snapshotFrom) { steps.push_back([=](hipStream_t st) { hipMemcpyAsync(s.vertsSnapshot, snapshotFrom, sizeof(float) * 6 * (size_t)nv, hipMemcpyDeviceToDevice, st); }); verts = s.vertsSnapshot; }
   steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(buildBegin, dim3(1), dim3(64), 0, st, n, s.state, t.dResult, s.bounds); });
-  steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(boundsKernel, dim3(std::min<uint32_t>((nv + 255) / 256, 512u)), dim3(256), 0, st, verts, nv, s.bounds); });
+  steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(boundsKernel, dim3(std::min<uint32_t>((nv + 255) / 256, 64u)), dim3(256), 0, st, verts, nv, s.bounds); });
   steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(mortonKernel, dim3(nb), dim3(256), 0, st, verts, indices, n, (const uint32_t*)s.bounds, s.codes[0], t.order, t.triBox); });
   // radix sort: (codes[0], t.order) <-> (codes[1], s.order2); four passes end where they began
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = pass * 8, cur = pass & 1;
     uint32_t *kin = s.codes[cur], *kout = s.codes[cur ^ 1], *vin = cur ? s.order2 : t.order, *vout = cur ? t.order : s.order2;
     steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(radixHist, dim3(nb), dim3(256), 0, st, (const uint32_t*)kin, n, shift, s.hist, nb); });
-    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(scanExclusive, dim3(1), dim3(1024), 0, st, s.hist, 256u * nb); });
-    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(radixScatter, dim3(nb), dim3(256), 0, st, (const uint32_t*)kin, (const uint32_t*)vin, n, shift, (const uint32_t*)s.hist, nb, kout, vout); });
+    const uint32_t chunks = (256u * nb + 1023u) / 1024u;
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(scanChunks, dim3(chunks), dim3(1024), 0, st, s.hist, 256u * nb, s.chunkSums); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(scanTotals, dim3(1), dim3(1024), 0, st, s.chunkSums, chunks); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(radixScatter, dim3(nb), dim3(256), 0, st, (const uint32_t*)kin, (const uint32_t*)vin, n, shift, (const uint32_t*)s.hist, (const uint32_t*)s.chunkSums, nb, kout, vout); });
   }
   t.root = n == 1 ? ~0 : -1; t.refittable = false;
   if (n > 1) {
@@ -750,8 +869,7 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
       steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocInit, dim3(nb), dim3(256), 0, st, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, s.clRef[0], s.clBox[0]); });
       const uint32_t rounds = plocRoundsFor(n);
       for (uint32_t r = 0; r < rounds; ++r) {
-        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocNearest, dim3(nb), dim3(256), 0, st, (const PlocState*)s.state, r, radius, A); });
-        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocCount, dim3(nb), dim3(256), 0, st, (const PlocState*)s.state, r, (const int32_t*)s.nn, s.blockCounts); });
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocNearest, dim3(nb), dim3(256), 0, st, (const PlocState*)s.state, r, radius, A, s.blockCounts); });
         steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocScatter, dim3(nb), dim3(256), 0, st, s.state, r, (const uint2*)s.blockCounts, A); });
       }
       steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocFinal, dim3(1), dim3(1024), 0, st, (const PlocState*)s.state, rounds, radius, n, A); });
@@ -760,7 +878,7 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
       for (int l = 0; l < RT_TREELET_LEVELS; ++l) {
         const uint32_t* prev = l ? t.cnt[l - 1] : nullptr; const uint32_t* cur = t.cnt[l];
         steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(treeletRootsKernel, dim3(nb), dim3(256), 0, st, (int)n - 1, l, prev, cur, (const int32_t*)t.nodeParent, t.treeletRoots, t.dResult); });
-        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(buildTreeletsKernel, dim3(l ? 64u : treeletGrid), dim3(256), 0, st, l, prev, (const int32_t*)t.left, (const int32_t*)t.right, (const uint32_t*)t.roundBase,
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(buildTreeletsKernel, dim3(l ? 64u : treeletGrid), dim3(256), 0, st, l, prev, (const int32_t*)t.left, (const int32_t*)t.right,
                                                                  (const int32_t*)t.treeletRoots, (RefitTreelet*)t.dTreelets, (int4*)t.dRefitItems, t.dRefitRounds, t.dResult); });
       }
     }
@@ -769,7 +887,7 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
     steps.push_back([=](hipStream_t st) { hipMemsetAsync(t.topRank, 0xFF, 4 * (size_t)(n - 1), st); });
     steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(planTopKernel, dim3(1), dim3(128), 0, st, topCap, root, n - 1, (const int32_t*)t.left, (const int32_t*)t.right, t.topList, t.topRank, t.dResult); });
     steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, st, (int)n, (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent, &t.dResult->depth); });
-    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(treeCostKernel, dim3((n - 1 + 255) / 256), dim3(256), 0, st, (int)n - 1, (const float*)t.nodeBox, &t.dResult->cost); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(treeCostKernel, dim3(std::min<uint32_t>((n - 1 + 255) / 256, 48u)), dim3(256), 0, st, (int)n - 1, (const float*)t.nodeBox, &t.dResult->cost); });
   }
   steps.push_back([=](hipStream_t st) { hipMemcpyAsync(t.hResult, t.dResult, sizeof(BuildResult), hipMemcpyDeviceToHost, st); });
 }
@@ -794,6 +912,9 @@ static int harvest(MeshDev& m, BvhTopo& t, uint32_t slot) {
   if (t.result.error & 1u) { setError("BVH build of mesh %u: more than %u clustering rounds", slot, (unsigned)RT_MAX_ROUNDS); return -3; }
   if (t.result.error & 2u) { setError("BVH build of mesh %u: the refit schedule would need more than %d treelet levels", slot, RT_TREELET_LEVELS); return -3; }
   if (t.result.depth > m.depth) m.depth = t.result.depth;
+  static const bool log = getenv("RTGGX_BUILD_LOG") != nullptr;
+  if (log) fprintf(stderr, "[rtggx] build of mesh %u: %u triangles, %u rounds (%u clusters handed to the last workgroup, %u at the start of its LDS rounds), treelets %u / %u / %u, table %u, depth %u, cost %.1f\n",
+                   slot, t.numTris, t.result.numRounds, t.result.finalEntry, t.result.finalLds, t.result.treelets[0], t.result.treelets[1], t.result.treelets[2], t.result.topCount, t.result.depth, t.result.cost);
   return 0;
 }
 
@@ -894,7 +1015,7 @@ static int launchTreeCost(MeshDev& m, hipStream_t s) {
   if (!m.dCost) { RT_HIP(hipMalloc(&m.dCost, 4)); RT_HIP(hipHostMalloc(&m.hCost, 4)); *m.hCost = 0.0f; RT_HIP(hipEventCreateWithFlags(&m.evCost, hipEventDisableTiming)); }
   RT_HIP(hipMemsetAsync(m.dCost, 0, 4, s));
   const int numNodes = (int)m.numTris - 1;
-  hipLaunchKernelGGL(treeCostKernel, dim3((numNodes + 255) / 256), dim3(256), 0, s, numNodes, (const float*)m.topo.nodeBox, m.dCost);
+  hipLaunchKernelGGL(treeCostKernel, dim3(std::min((numNodes + 255) / 256, 48)), dim3(256), 0, s, numNodes, (const float*)m.topo.nodeBox, m.dCost);
   return 0;
 }
 

@@ -133,7 +133,7 @@ RT_DEV f3 fSchlick(f3 spec, float VoH) {   // :54-62, pow(x,5) by multiplication
 RT_DEV f3 envBRDFApprox(f3 spec, float roughness, float NoV) {   // :64-77
   const float rx = roughness * -1.0f + 1.0f, ry = roughness * -0.0275f + 0.0425f;
   const float rz = roughness * -0.572f + 1.04f, rw = roughness * 0.022f + -0.04f;
-  const float a004 = fminf(rx * rx, exp2f(-9.28f * NoV)) * rx + ry;
+  const float a004 = fminf(rx * rx, exp2Contract(-9.28f * NoV)) * rx + ry;
   const float ABx = -1.04f * a004 + rz;
   float ABy = 1.04f * a004 + rw;
   ABy *= saturatef(50.0f * spec.y);
@@ -148,7 +148,7 @@ RT_DEV uint32_t rng(uint32_t seed) {   // :379-387
   return seed;
 }
 RT_DEV float calcMipFromRoughness(float rgh, float mipCount) {   // :416-422
-  const float level = 3.0f - 1.15f * log2f(rgh);
+  const float level = 3.0f - 1.15f * log2Contract(rgh);
   return mipCount - 1.0f - level;
 }
 RT_DEV f3 localToWorld(f3 n, f3 l) {   // :129-147

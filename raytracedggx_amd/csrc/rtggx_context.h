@@ -48,7 +48,8 @@ struct BuildResult {
   uint32_t topCount;                         // entries of the LDS table of the tree's top
   uint32_t depth;                            // deepest leaf (number of ancestors): bounds the traversal stack
   uint32_t error;                            // bit 0: more than RT_MAX_ROUNDS rounds; bit 1: a treelet level beyond RT_TREELET_LEVELS would be needed
-  uint32_t itemCursor, roundCursor, pad;
+  uint32_t itemCursor, roundCursor;
+  uint32_t finalEntry, finalLds;             // statistics of plocFinal: clusters handed to it, clusters when its LDS rounds began
   float cost, pad2;                          // sum of the node-box half-areas (SAH cost up to constants)
 };
 // Everything a build derives from ONE vertex shape that refits of later shapes keep using (lbvh.hip): the binary topology (PLOC creates
@@ -172,6 +173,7 @@ struct rtggx_context {
   hipEvent_t evRefit = nullptr;   // vertices of the current set uploaded and the tree refitted (stream B -> stream C)
   hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
   bool setReadRecorded[RT_SETS] = {};
+  int setReadDeferred = -1;      // the set whose event is still to ride on a later kernel of this frame (capi.hip settleSetRead)
   // a tone map that waits to be launched beside the NEXT frame's filters (capi.hip rtggx_tone_map), and the events of those launched that way
   bool tonePending = false, denoiseIssued = false, callerOrdersOnMain = false, toneAsideAllowed = true; rt::PreparedToneMap tonePrepared; uint32_t toneParity = 0;
   hipEvent_t evTone[2] = {}; bool toneRecorded[2] = {}; uint32_t toneAsideCount = 0, toneBesideCount = 0;

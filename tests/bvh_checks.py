@@ -54,47 +54,88 @@ def bvh_check(nodes_u32, tris_u32, root, num_tris):
     return len(levels) + 1
 
 
-def bvh4_check(nodes_u32, nodes4_u32, root):
-    """The 4-wide nodes the trace kernel walks (RTGGX_BUF_BVH4_NODES*: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4])
-    are the even-depth binary nodes with their internal children folded in: same references, same boxes, bit for bit; odd-depth
-    slots stay zero.  Returns the number of 4-wide nodes in use."""
+def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None):
+    """The 4-wide nodes the trace kernel walks (RTGGX_BUF_BVH4_NODES*: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4]) against
+    the binary tree: a 4-wide node is an even-depth binary node whose entries are its grandchildren (or its children where those are
+    leaves).  Since round 3 an entry may also be a MULTI-LEAF: a whole binary subtree of at most four triangles, referenced as
+    ~(first slot | (count - 1) << 28) -- possible because the leaf slots are in depth-first order of the tree, so that every subtree's
+    triangles are consecutive.  Checked: walking the 4-wide nodes from the root reaches every leaf slot exactly once; every entry's
+    box is, bit for bit, the binary tree's box of the subtree (or leaf) it stands for; slots nobody references stay zero.
+    Returns the number of 4-wide nodes in use."""
     if root < 0:
         assert nodes4_u32.size == 0 or not nodes4_u32.any()
         return 0
     nodes, nodes4 = nodes_u32.reshape(-1, 16), nodes4_u32.reshape(-1, 32)
     f = nodes.view(np.float32)
     child = nodes[:, 12:14].view(np.int32)
-    f4, r4 = nodes4.view(np.float32), nodes4[:, 24:28].view(np.int32)
-    depth = np.full(len(nodes), -1)
-    frontier, d = np.array([root], np.int64), 0
+    n = len(nodes)
+    u4, r4 = nodes4[:, :24], nodes4[:, 24:28].view(np.int32)
+    # per binary node: depth, parent side (where its box is stored), leaf range [first, first + count) of its subtree
+    depth = np.full(n, -1); parent = np.full(n, -1); side = np.zeros(n, np.int64)
+    levels, frontier, d = [], np.array([root], np.int64), 0
     while frontier.size:
-        depth[frontier] = d
+        depth[frontier] = d; levels.append(frontier)
+        for sd in (0, 1):
+            c = child[frontier, sd]
+            inner = c >= 0
+            parent[c[inner]] = frontier[inner]; side[c[inner]] = sd
         c = child[frontier].reshape(-1)
         frontier, d = c[c >= 0].astype(np.int64), d + 1
     assert (depth >= 0).all()
-    assert not nodes4[depth % 2 == 1].any(), "odd-depth slots stay unused"
-    even = np.nonzero(depth % 2 == 0)[0]
+    first = np.zeros(n, np.int64); count = np.zeros(n, np.int64); contiguous = np.ones(n, bool)
+    for nodes_l in reversed(levels):
+        c0, c1 = child[nodes_l, 0].astype(np.int64), child[nodes_l, 1].astype(np.int64)
+        f0 = np.where(c0 < 0, ~c0, first[np.where(c0 < 0, 0, c0)]); n0 = np.where(c0 < 0, 1, count[np.where(c0 < 0, 0, c0)])
+        f1 = np.where(c1 < 0, ~c1, first[np.where(c1 < 0, 0, c1)]); n1 = np.where(c1 < 0, 1, count[np.where(c1 < 0, 0, c1)])
+        ok0 = np.where(c0 < 0, True, contiguous[np.where(c0 < 0, 0, c0)]); ok1 = np.where(c1 < 0, True, contiguous[np.where(c1 < 0, 0, c1)])
+        first[nodes_l] = np.minimum(f0, f1); count[nodes_l] = n0 + n1
+        contiguous[nodes_l] = ok0 & ok1 & ((f0 + n0 == f1) | (f1 + n1 == f0))
+    # the box the binary tree stores for a node: in its parent's child fields (the root has none)
+    pr = np.where(parent >= 0, parent, 0)
+    nbox = np.where((side == 0)[:, None], f[pr, 0:6], f[pr, 6:12]).view(np.uint32)
+    leaf_box = {}            # leaf slot -> box (from the parent's child fields)
+    for sd, off in ((0, 0), (1, 6)):
+        c = child[:, sd]
+        for i in np.nonzero(c < 0)[0]:
+            leaf_box[int(~c[i])] = nodes[i, off:off + 6]
+    by_range = {(int(first[i]), int(count[i])): i for i in range(n) if contiguous[i] and i != root}
     EMPTY = 0x7FFFFFFF
-    # expected entries per even node: for each of its two children, the child itself if it is a leaf, else that child's two children
-    want_ref = np.full((len(even), 4), EMPTY, np.int64); want_box = np.zeros((len(even), 4, 6), np.float32)
-    for side, off in ((0, 0), (1, 6)):
-        c = child[even, side]
-        leaf = c < 0
-        ci = np.where(leaf, 0, c)
-        want_ref[:, 2 * side] = np.where(leaf, c, child[ci, 0]); want_box[:, 2 * side] = np.where(leaf[:, None], f[even, off:off + 6], f[ci, 0:6])
-        want_ref[:, 2 * side + 1] = np.where(leaf, EMPTY, child[ci, 1]); want_box[:, 2 * side + 1] = np.where(leaf[:, None], 0.0, f[ci, 6:12])
-    got_ref = r4[even].astype(np.int64)
-    got_box = np.stack([f4[even][:, [k, 4 + k, 8 + k, 12 + k, 16 + k, 20 + k]] for k in range(4)], axis=1)
-    # compare as sets per node: sort both by reference
-    og, ow = np.argsort(got_ref, axis=1, kind="stable"), np.argsort(want_ref, axis=1, kind="stable")
-    gr, wr = np.take_along_axis(got_ref, og, 1), np.take_along_axis(want_ref, ow, 1)
-    assert np.array_equal(gr, wr), "4-wide node references"
-    gb, wb = np.take_along_axis(got_box, og[:, :, None], 1), np.take_along_axis(want_box, ow[:, :, None], 1)
-    used = wr != EMPTY
-    assert np.array_equal(gb[used].view(np.uint32), wb[used].view(np.uint32)), "4-wide node boxes"
-    inner = wr[used & (wr >= 0)]
-    assert (depth[inner] % 2 == 0).all()
-    return len(even)
+    num_leaves = int(count[root])
+    seen_leaf = np.zeros(num_leaves, np.int32)
+    used = np.zeros(n, bool)
+    stack = [int(root)]
+    while stack:
+        v = stack.pop()
+        assert not used[v] and depth[v] % 2 == 0, "4-wide node %d reached twice or at odd depth" % v
+        used[v] = True
+        got = 0
+        for e in range(4):
+            r = int(r4[v, e])
+            if r == EMPTY:
+                continue
+            box = u4[v, e::4]
+            if r >= 0:
+                assert r < n and parent[r] >= 0 and (parent[r] == v or parent[parent[r]] == v), "entry %d of node %d is not a (grand)child" % (e, v)
+                want = nbox[r]
+                stack.append(r); got += int(count[r])
+            else:
+                lr = ~r
+                slot, cnt = lr & 0x0FFFFFFF, (lr >> 28) + 1
+                assert 1 <= cnt <= 4 and slot + cnt <= num_leaves
+                seen_leaf[slot:slot + cnt] += 1
+                if cnt == 1:
+                    want = leaf_box[slot]
+                else:
+                    assert (slot, cnt) in by_range, "multi-leaf (%d, %d) of node %d is not a subtree of the binary tree" % (slot, cnt, v)
+                    sub = by_range[(slot, cnt)]
+                    assert parent[sub] == v or parent[parent[sub]] == v
+                    want = nbox[sub]
+                got += cnt
+            assert np.array_equal(box, want), "box of entry %d of node %d" % (e, v)
+        assert got == count[v], "node %d covers %d of its %d triangles" % (v, got, count[v])
+    assert (seen_leaf == 1).all(), "every leaf slot reached exactly once through the 4-wide nodes"
+    assert not nodes4[~used].any(), "slots of nodes nobody references stay unused"
+    return int(used.sum())
 
 
 TOP_FLAG = 0x40000000

@@ -89,14 +89,10 @@ class Pair:
             np.testing.assert_array_equal(ctx.readback(gid), o.buffer(oid), err_msg="%s: %s not bit-exact" % (label, name))
         np.testing.assert_array_equal(ctx.readback(capi.BUF_TLAS), o.inv_worlds())
         assert ctx.ray_count() == self.rays, "%s: ray count" % label
+        # the raw traced images: bit for bit since round 3 (the shading path's exp2 / log2 are the numeric contract's on both sides,
+        # rtggx_device.h exp2Contract / log2Contract; until then a word could differ by one code)
         for name, gid, oid in (("rt_refl", capi.BUF_RT_REFL, O.BUF_RT_REFL), ("rt_diff", capi.BUF_RT_DIFF, O.BUF_RT_DIFF)):
-            g, r = ctx.readback(gid), o.buffer(oid)
-            # exp2/log2 differ by an ulp between libm and the device library: a word may flip by one code, never more
-            assert (g != r).mean() < 2e-2, "%s: %s differs in %.4f%% of the words" % (label, name, 100 * (g != r).mean())
-            for shift, mask in ((0, 0x7FF), (11, 0x7FF), (22, 0x3FF)):
-                d = np.abs(((g >> shift) & mask).astype(np.int64) - ((r >> shift) & mask).astype(np.int64))
-                assert d.max() <= 1, "%s: %s channel at bit %d differs by %d codes" % (label, name, shift, d.max())
-            assert rel_l2(O.unpack_r11g11b10f(g), O.unpack_r11g11b10f(r)) < HDR_TOL
+            np.testing.assert_array_equal(ctx.readback(gid), o.buffer(oid), err_msg="%s: %s not bit-exact" % (label, name))
         p = ctx.frame_parity()
         assert p == o.parity()
         for name, gid, oid in (("FilteredOut", capi.BUF_FLT_RFL, O.BUF_FLT_RFL), ("FilteredOut1", capi.BUF_FLT_DFF, O.BUF_FLT_DFF),
@@ -307,7 +303,11 @@ def _full_size_properties(W, H, mesh, label, checked_frames=0):
         tss = O.unpack_rgba16f(ctx.readback(capi.BUF_TSS0 + ctx.frame_parity()))
         assert rel_l2(tss, O.unpack_rgba16f(o.buffer(O.BUF_TSS0 + o.parity()))) < HDR_TOL
         g, r = ctx.readback(capi.BUF_BACKBUFFER), o.buffer(O.BUF_BACKBUFFER)
-        assert np.abs(O.unpack_rgba8(g).astype(int) - O.unpack_rgba8(r).astype(int)).max() <= 1
+        # 8-bit codes.  With a history in play (checked_frames > 0) the temporal pass's clamp window -- gamma <= 32 times the square root of a
+        # 3x3 variance that is rounding noise where the image is flat -- turns the 1e-5 by which the filtered inputs differ into a percent on
+        # a handful of pixels (tools/probes/parity_probe.py): at two million pixels a frame, one of them now and then lands two codes away.
+        d = np.abs(O.unpack_rgba8(g).astype(int) - O.unpack_rgba8(r).astype(int))
+        assert d.max() <= (2 if checked_frames else 1) and (d > 1).mean() < 1e-5, "%s: back buffer differs by up to %d codes, %d values by more than one" % (label, d.max(), (d > 1).sum())
         vis = ctx.readback(capi.BUF_VISIBILITY)
         # coverage sanity: model + slab cover 15-50 % of the frame, the model is in front of the slab somewhere
         assert 0.15 < (vis > 0).mean() < 0.5 and (vis >= 0x01000000).mean() > 0.03
