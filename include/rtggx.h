@@ -162,6 +162,11 @@ int  rtggx_set_mesh(rtggx_context* ctx, uint32_t slot, const float* verts, uint3
 int  rtggx_set_env(rtggx_context* ctx, int format, uint32_t size, uint32_t mips, const void* data, size_t bytes);
 int  rtggx_set_material(rtggx_context* ctx, uint32_t mesh, const float base_color[4], float roughness, float metallic);
 int  rtggx_set_metallic(rtggx_context* ctx, uint32_t mesh, float metallic);
+/* Sampler of the reflection lobe.  0 (default): the reference's -- the GGX normal distribution itself, computeLocalDirectionGGX /
+ * computeReflection (RayTracing.hlsl:92-101, 129-147, 424-484), weight NoL F Vis 4 VoH / NoH -- the parity path.  1: the distribution
+ * of VISIBLE normals (Heitz 2018), weight F G1(L): no sample is wasted below the horizon of the view direction, less variance at
+ * grazing angles for the same one sample per pixel.  Takes effect with the next rtggx_update_frame. */
+int  rtggx_set_sampler(rtggx_context* ctx, int vndf);
 
 /* Build of both bottom-level structures (RayTracer::buildAccelerationStructures / BuildAccelerationStructures, RayTracer.cpp:676-716,
  * 158-233; the sample records the builds on the GPU timeline and waits once, RayTracedGGX.cpp:236): every step of the build --
@@ -199,6 +204,11 @@ int  rtggx_render_visibility(rtggx_context* ctx);
 int  rtggx_ray_trace(rtggx_context* ctx);
 int  rtggx_denoise(rtggx_context* ctx, int use_shared_mem);
 int  rtggx_tone_map(rtggx_context* ctx);
+
+/* Diagnostic: triangles a leaf of the 4-wide trees may hold in builds from now on (1, 2, 3 or 4; default 1, or RTGGX_LEAF_TRIS).  Whole
+ * subtrees of up to that many triangles become one entry of their (grand)parent node -- fewer node visits per ray, more triangle
+ * tests per leaf visit (measured: profiles/r03_e_multi_leaf.txt).  Results do not depend on it. */
+int  rtggx_debug_leaf_tris(rtggx_context* ctx, uint32_t leaf_tris);
 
 int  rtggx_sync(rtggx_context* ctx);
 /* Number of non-degenerate rays (TMax > TMin) traced by the last rtggx_ray_trace; synchronises. */

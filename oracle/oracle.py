@@ -53,7 +53,7 @@ def lib():
         L.orc_f16_to_f32.restype = C.c_float
         L.orc_f16_to_f32.argtypes = [C.c_uint16]
         L.orc_get_parity.restype = C.c_uint32
-        for name in ("orc_destroy", "orc_set_threads", "orc_set_mesh", "orc_set_pos_scale", "orc_set_metallic",
+        for name in ("orc_destroy", "orc_set_threads", "orc_set_mesh", "orc_set_pos_scale", "orc_set_metallic", "orc_set_sampler",
                      "orc_set_material", "orc_set_env_dds", "orc_set_env_rgba16f", "orc_env_texel_count", "orc_env_info",
                      "orc_env_copy", "orc_build_as", "orc_set_bvh", "orc_bvh_info", "orc_bvh_copy", "orc_update_frame",
                      "orc_set_frame_constants", "orc_get_frame_constants", "orc_halton", "orc_update_as",
@@ -132,6 +132,9 @@ class Oracle:
 
     def set_pos_scale(self, ps):
         self.L.orc_set_pos_scale(self.h, _fp(np.asarray(ps, np.float32)))
+
+    def set_sampler(self, vndf):
+        self.L.orc_set_sampler(self.h, C.c_int(1 if vndf else 0))
 
     def set_metallic(self, mesh, m):
         self.L.orc_set_metallic(self.h, C.c_uint32(mesh), C.c_float(m))

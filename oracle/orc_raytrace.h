@@ -168,6 +168,27 @@ static inline float3 local_to_world(float3 n, float3 l) {   // computeLocalToWor
   return (xAxis * l.x + yAxis * l.y) + n * l.z;
 }
 
+// Opt-in sampler of the product (rtggx_set_sampler), restated: the half vector from the distribution of visible normals (Heitz 2018,
+// "Sampling the GGX Distribution of Visible Normals", listing 1; isotropic, alpha = roughness^2), in the tangent frame of local_to_world.
+// Not the reference's sampler (that is computeLocalDirectionGGX, the default): north_star names it, SURVEY R4 scopes it as an opt-in variant.
+static inline float3 vndf_half_vector(float3 n, float3 v, float alpha, float cosPhi, float sinPhi, float u) {
+  const float3 up = std::fabs(n.y) < 0.999f ? f3(0, 1, 0) : f3(1, 0, 0);
+  const float3 xAxis = normalize(cross(up, n));
+  const float3 yAxis = cross(n, xAxis);
+  const float3 ve = f3(dot(v, xAxis), dot(v, yAxis), dot(v, n));
+  const float3 vh = normalize(f3(alpha * ve.x, alpha * ve.y, ve.z));
+  const float lensq = vh.x * vh.x + vh.y * vh.y;
+  const float3 t1v = lensq > 0.0f ? f3(-vh.y, vh.x, 0.0f) * (1.0f / std::sqrt(lensq)) : f3(1, 0, 0);
+  const float3 t2v = cross(vh, t1v);
+  const float r = std::sqrt(u);
+  const float t1 = r * cosPhi;
+  float t2 = r * sinPhi;
+  const float sw = 0.5f * (1.0f + vh.z);
+  t2 = (1.0f - sw) * std::sqrt(1.0f - t1 * t1) + sw * t2;
+  const float3 nh = (t1 * t1v + t2 * t2v) + std::sqrt(std::fmax(0.0f, (1.0f - t1 * t1) - t2 * t2)) * vh;
+  const float3 hl = normalize(f3(alpha * nh.x, alpha * nh.y, std::fmax(0.0f, nh.z)));
+  return (xAxis * hl.x + yAxis * hl.y) + n * hl.z;
+}
 struct Vertex3 { float3 pos[3], nrm[3]; };
 static inline Vertex3 get_vertices(const Ctx& c, uint32_t inst, uint32_t prim) {   // :230-244
   Vertex3 v; const Mesh& m = c.mesh[inst];
@@ -281,9 +302,13 @@ static inline uint32_t raygen_pixel(Ctx& c, uint32_t px, uint32_t py) {
   else {
     const float a = s.rghMtl.x * s.rghMtl.x;
     // computeLocalDirectionGGX :92-101 with cos/sin(2*pi*xi.x) from the table
-    const float cosTheta = std::sqrt((1.0f - xi.y) / (1.0f + (a * a - 1.0f) * xi.y));
-    const float sinTheta = std::sqrt(1.0f - cosTheta * cosTheta);
-    const float3 Hh = local_to_world(s.N, f3(c.cosTab[xi.s] * sinTheta, c.sinTab[xi.s] * sinTheta, cosTheta));
+    float3 Hh;
+    if (c.vndf) Hh = vndf_half_vector(s.N, s.V, a, c.cosTab[xi.s], c.sinTab[xi.s], xi.y);
+    else {
+      const float cosTheta = std::sqrt((1.0f - xi.y) / (1.0f + (a * a - 1.0f) * xi.y));
+      const float sinTheta = std::sqrt(1.0f - cosTheta * cosTheta);
+      Hh = local_to_world(s.N, f3(c.cosTab[xi.s] * sinTheta, c.sinTab[xi.s] * sinTheta, cosTheta));
+    }
     const float3 R = reflect(-s.V, Hh);
     const float NoL = dot(s.N, R);
     if (NoL <= 0.0f) refl = f3(0, 0, 0);                  // :459
@@ -306,6 +331,11 @@ static inline uint32_t raygen_pixel(Ctx& c, uint32_t px, uint32_t py) {
       const float NoH = saturate(dot(s.N, Hh));
       const float k = 4.0f * VoH / NoH;
       refl = f3(col.x * (((NoL * F.x) * vis) * k), col.y * (((NoL * F.y) * vis) * k), col.z * (((NoL * F.z) * vis) * k));   // :477
+      if (c.vndf) {      // F x G2 / G1(V) = F x G1(L), separable Smith terms of Vis_Smith
+        const float a2 = a * a;
+        const float g1l = (2.0f * NoL) / (NoL + std::sqrt(NoL * (NoL - NoL * a2) + a2));
+        refl = f3(col.x * (F.x * g1l), col.y * (F.y * g1l), col.z * (F.z * g1l));
+      }
     }
   }
   c.refl[pix] = pack_r11g11b10f(refl.x, refl.y, refl.z);

@@ -88,6 +88,7 @@ struct Ctx {
   float angle = 0.0f; uint32_t sFrameIndex = 0; bool havePrev = false;
   float prevWVP[2][16];
   int threads = 1;
+  bool vndf = false;                       // the product's opt-in sampler (orc_raytrace.h vndf_half_vector)
 };
 
 // XUSG::IncrementalHalton: n-th call returns (radical_inverse_2(n), radical_inverse_3(n)),

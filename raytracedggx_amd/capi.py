@@ -30,7 +30,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_debug_shader_clock"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_leaf_tris", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -161,6 +161,13 @@ class Context:
         """New vertex positions / normals for an unchanged topology: staged now, uploaded and refitted on stream B by the next frame."""
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 6)
         self._check(self.L.rtggx_refit_as(self.h, slot, _p(v), v.shape[0]))
+
+    def leaf_tris(self, n):
+        """Triangles per leaf of the 4-wide trees of later builds (diagnostic)."""
+        self._check(self.L.rtggx_debug_leaf_tris(self.h, n))
+
+    def set_sampler(self, vndf):
+        self._check(self.L.rtggx_set_sampler(self.h, 1 if vndf else 0))
 
     def set_refit_policy(self, rebuild_ratio=1.2, steps_per_frame=16):
         self._check(self.L.rtggx_set_refit_policy(self.h, rebuild_ratio, steps_per_frame))

@@ -219,6 +219,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   c->pipeline = getenv("RTGGX_PIPELINE") ? atoi(getenv("RTGGX_PIPELINE")) : 1;
   c->rebuildRatio = getenv("RTGGX_REBUILD_RATIO") ? (float)atof(getenv("RTGGX_REBUILD_RATIO")) : RT_REFIT_REBUILD_RATIO;
   c->rebuildSteps = getenv("RTGGX_REBUILD_STEPS") ? (uint32_t)atoi(getenv("RTGGX_REBUILD_STEPS")) : RT_REBUILD_STEPS;
+  { const int lt = getenv("RTGGX_LEAF_TRIS") ? atoi(getenv("RTGGX_LEAF_TRIS")) : 1; c->leafTris = lt < 1 ? 1u : lt > 4 ? 4u : (uint32_t)lt; }
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -254,9 +255,10 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     const uint32_t tiles = ((width + 15) / 16) * ((height + 15) / 16);
     c->numBinsMax = tiles * 4u;
     if (c->numBinsMax < 64u) c->numBinsMax = 64u;            // room for rtggx_trace_rays batches on tiny frames
+    c->binSlots = getenv("RTGGX_BIN_SLOTS") && atoi(getenv("RTGGX_BIN_SLOTS")) == 128 ? RT_BIN : RT_BIN_MIN;      // (all-metal default materials: one ray per pixel)
     for (int i = 0; i < RT_SETS; ++i) {
-      RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * RT_BIN * sizeof(rt::RayRec)));
-      RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * 128 * 8));
+      RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * c->binSlots * sizeof(rt::RayRec)));
+      RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * c->binSlots * 8));
       RT_HIP(hipMalloc(&c->binCountBuf[i], (size_t)c->numBinsMax * 4)); RT_HIP(hipMemset(c->binCountBuf[i], 0, (size_t)c->numBinsMax * 4));
     }
     c->selectSet(0);
@@ -397,6 +399,11 @@ int rtggx_set_material(rtggx_context* c, uint32_t mesh, const float baseColor[4]
   c->material.RoughMetals[mesh][0] = roughness; c->material.RoughMetals[mesh][1] = metallic;
   return 0;
 }
+int rtggx_set_sampler(rtggx_context* c, int vndf) {
+  RT_CHECK_CTX(c);
+  c->vndf = vndf != 0;      // takes effect with the next rtggx_update_frame
+  return 0;
+}
 int rtggx_set_metallic(rtggx_context* c, uint32_t mesh, float metallic) {   // RayTracer.cpp:244-248
   RT_CHECK_CTX(c);
   if (mesh >= RTGGX_NUM_MESH) { setError("rtggx_set_metallic: bad mesh"); return -1; }
@@ -533,14 +540,30 @@ static int issuePendingRefits(rtggx_context* c, bool* touched) {
   return 0;
 }
 
+// A material with metallic below 1 traces a diffuse ray per covered pixel as well: two ray slots per pixel.  The bins grow once, before
+// the first such frame (the frames in flight are waited for: the old bins are theirs).
+static int growBins(rtggx_context* c) {
+  RT_HIP(syncStreams(c));
+  for (int i = 0; i < RT_SETS; ++i) {
+    RT_HIP(hipFree(c->rayQueueBuf[i])); RT_HIP(hipFree(c->hitQueueBuf[i])); c->rayQueueBuf[i] = c->hitQueueBuf[i] = nullptr;
+    RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * RT_BIN * sizeof(rt::RayRec)));
+    RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * RT_BIN * 8));
+  }
+  if (c->testRayRange) { RT_HIP(hipFree(c->testRayRange)); c->testRayRange = nullptr; }
+  c->binSlots = RT_BIN;
+  c->selectSet(c->setIndex);
+  return 0;
+}
 int rtggx_update_frame(rtggx_context* c, const RtggxFrameConstants* k) {
   RT_CHECK_CTX(c);
   if (!k) { setError("rtggx_update_frame: null constants"); return -1; }
+  if (c->binSlots < RT_BIN && (c->material.RoughMetals[0][1] < 1.0f || c->material.RoughMetals[1][1] < 1.0f)) { const int r = growBins(c); if (r) return r; }
   c->slot = (c->slot + 1) % RT_SLOTS;   // RayTracer::FrameCount + 1 (rtggx_context.h)
   FrameParams& fp = c->slots[c->slot];
   fp.g = k->global; fp.rg = k->rayGen; fp.po[0] = k->perObject[0]; fp.po[1] = k->perObject[1];
   fp.mat = c->material;
   fp.W = c->W; fp.H = c->H; fp.rowBegin = c->rowBegin; fp.rowEnd = c->rowEnd;
+  fp.flags = c->vndf ? RT_FLAG_VNDF : 0u; fp.pad[0] = fp.pad[1] = fp.pad[2] = 0u;
   memcpy(fp.invWorld, c->invWorld, sizeof fp.invWorld);
   c->haveConstants = true; c->slotUploaded = false;
   return 0;
@@ -772,6 +795,13 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
   return 0;
 }
 
+// Triangles per leaf of the 4-wide trees built from now on (lbvh.hip emitNodes4 "multi-leaves"): 1 (every leaf one triangle), 2 or 4.
+int rtggx_debug_leaf_tris(rtggx_context* c, uint32_t leafTris) {
+  RT_CHECK_CTX(c);
+  if (leafTris < 1u || leafTris > 4u) { setError("rtggx_debug_leaf_tris: 1 .. 4"); return -1; }
+  c->leafTris = leafTris;
+  return 0;
+}
 int rtggx_debug_trace_residency(rtggx_context* c, uint32_t forceWaves, uint32_t* waves, float* share) {
   RT_CHECK_CTX(c);
   if (forceWaves != 0u && forceWaves != 10u && forceWaves != 12u && forceWaves != 14u && forceWaves != 16u) { setError("rtggx_debug_trace_residency: %u waves: 0, 10, 12, 14 or 16", forceWaves); return -1; }
@@ -987,7 +1017,7 @@ int rtggx_trace_rays(rtggx_context* c, const float* rays, uint32_t n, float* out
   RT_HIP(hipMalloc(&dR, (size_t)n * 32)); RT_HIP(hipMalloc(&dO, (size_t)n * 24));
   RT_HIP(hipMemcpy(dR, rays, (size_t)n * 32, hipMemcpyHostToDevice));
   int r = 0;
-  const uint32_t perLaunch = c->numBinsMax * 128u;
+  const uint32_t perLaunch = c->numBinsMax * c->binSlots;
   for (uint32_t done = 0; done < n && !r; done += perLaunch) {   // the ray bins' capacity per launch
     const uint32_t m = n - done < perLaunch ? n - done : perLaunch;
     r = launchTraceRays(c, c->slots[c->slot], dR + (size_t)done * 8, m, dO + (size_t)done * 6, c->streamMain);

@@ -253,7 +253,32 @@ RT_DEV int plocNearestOf(int i, int m, int radius, const float* __restrict__ clB
 // nearest neighbour of i's nearest neighbour (within the radius of i), whose own search reaches another radius further.  (Round 3
 // began with two kernels -- nearest, then flags + counts --: with ~14 rounds to issue, a launch less per round is 100 us of the build.)
 #define RT_PLOC_APRON (2 * RT_PLOC_RADIUS)
-__global__ void __launch_bounds__(256) plocNearest(const PlocState* __restrict__ state, uint32_t r, int radius, PlocArrays A, uint2* __restrict__ blockCounts) {
+#define RT_PLOC_LANES 4      // lanes that share one position's search (each a quarter of the neighbourhood): there are only ~1000 waves of work in
+                             // the largest round, one per SIMD, and a wave's search is a chain of dependent LDS reads -- four times the waves, each a quarter as long
+// The nearest neighbour of position i among [i - radius, i + radius] (boxes in LDS, entry e = position lo + e): smallest merged box, ties
+// to the lower position.  RT_PLOC_LANES consecutive lanes call it together for the same i, `sub` = the caller's share.
+RT_DEV int plocNearestShared(const float (*box)[256 + 2 * RT_PLOC_APRON], int i, int lo, int m, int radius, uint32_t sub) {
+  float best = __builtin_inff(); int bj = 0x7FFFFFFF;
+  if (i >= 0 && i < m) {
+    const int ei = i - lo;
+    float mine[6];
+    for (int k = 0; k < 6; ++k) mine[k] = box[k][ei];
+    const int jl = max(i - radius, 0), jh = min(i + radius, m - 1);
+    for (int j = jl + (int)sub; j <= jh; j += RT_PLOC_LANES) {
+      if (j == i) continue;
+      const int ej = j - lo;
+      const float ex = fmaxf(mine[3], box[3][ej]) - fminf(mine[0], box[0][ej]), ey = fmaxf(mine[4], box[4][ej]) - fminf(mine[1], box[1][ej]), ez = fmaxf(mine[5], box[5][ej]) - fminf(mine[2], box[2][ej]);
+      const float d = (ex * ey + ey * ez) + ez * ex;
+      if (d < best) { best = d; bj = j; }      // (ascending j: the first of equal distances stays)
+    }
+  }
+  for (int o = 1; o < RT_PLOC_LANES; o <<= 1) {      // the best of the group's shares: smaller distance, then lower position
+    const float od = __shfl_xor(best, o); const int oj = __shfl_xor(bj, o);
+    if (od < best || (od == best && oj < bj)) { best = od; bj = oj; }
+  }
+  return bj == 0x7FFFFFFF ? -1 : bj;
+}
+__global__ void __launch_bounds__(256 * RT_PLOC_LANES) plocNearest(const PlocState* __restrict__ state, uint32_t r, int radius, PlocArrays A, uint2* __restrict__ blockCounts) {
   __shared__ float box[6][256 + 2 * RT_PLOC_APRON];
   __shared__ int32_t nnS[256 + 2 * RT_PLOC_RADIUS];
   __shared__ uint32_t wk[4], wm[4];
@@ -262,35 +287,20 @@ __global__ void __launch_bounds__(256) plocNearest(const PlocState* __restrict__
   if (radius > RT_PLOC_RADIUS) radius = RT_PLOC_RADIUS;
   const float* __restrict__ clBox = A.clBox[r & 1u];
   const int b0 = (int)(blockIdx.x * 256), lo = b0 - RT_PLOC_APRON;      // LDS entry e holds position lo + e
-  for (int e = threadIdx.x; e < 256 + 2 * RT_PLOC_APRON; e += 256) {
+  for (int e = threadIdx.x; e < 256 + 2 * RT_PLOC_APRON; e += 256 * RT_PLOC_LANES) {
     const int pos = lo + e;
     if (pos >= 0 && pos < m) for (int k = 0; k < 6; ++k) box[k][e] = clBox[6 * (size_t)pos + k];
   }
   __syncthreads();
-  // nearest neighbour of positions [b0 - radius, b0 + 256 + radius): smallest merged box, ties to the lower position
-  for (int q = threadIdx.x; q < 256 + 2 * RT_PLOC_RADIUS; q += 256) {
-    const int i = b0 - RT_PLOC_RADIUS + q;
-    int bj = -1;
-    if (i >= 0 && i < m) {
-      const int ei = i - lo;
-      float mine[6];
-      for (int k = 0; k < 6; ++k) mine[k] = box[k][ei];
-      float best = __builtin_inff();
-      const int jl = max(i - radius, 0), jh = min(i + radius, m - 1);
-      for (int j = jl; j <= jh; ++j) {
-        if (j == i) continue;
-        const int ej = j - lo;
-        const float ex = fmaxf(mine[3], box[3][ej]) - fminf(mine[0], box[0][ej]), ey = fmaxf(mine[4], box[4][ej]) - fminf(mine[1], box[1][ej]), ez = fmaxf(mine[5], box[5][ej]) - fminf(mine[2], box[2][ej]);
-        const float d = (ex * ey + ey * ez) + ez * ex;
-        if (d < best) { best = d; bj = j; }
-      }
-    }
-    nnS[q] = bj;
+  // nearest neighbour of positions [b0 - radius, b0 + 256 + radius)
+  for (int q = threadIdx.x / RT_PLOC_LANES; q < 256 + 2 * RT_PLOC_RADIUS; q += 256) {      // (uniform per group of lanes; whole waves run the same number of rounds)
+    const int bj = plocNearestShared(box, b0 - RT_PLOC_RADIUS + q, lo, m, radius, threadIdx.x % RT_PLOC_LANES);
+    if (threadIdx.x % RT_PLOC_LANES == 0) nnS[q] = bj;
   }
   __syncthreads();
   const int i = b0 + (int)threadIdx.x;
   uint32_t keep = 0u, merge = 0u;
-  if (i < m) {
+  if (threadIdx.x < 256 && i < m) {
     const int j = nnS[i - b0 + RT_PLOC_RADIUS];
     A.nn[i] = j;
     const bool mutual = j >= 0 && nnS[j - b0 + RT_PLOC_RADIUS] == i;
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(256) plocNearest(const PlocState* __restrict__
     keep = mutual && i > j ? 0u : 1u;
   }
   const unsigned long long bk = __ballot(keep != 0u), bm = __ballot(merge != 0u);
-  if ((threadIdx.x & 63u) == 0u) { wk[threadIdx.x >> 6] = (uint32_t)__popcll(bk); wm[threadIdx.x >> 6] = (uint32_t)__popcll(bm); }
+  if (threadIdx.x < 256 && (threadIdx.x & 63u) == 0u) { wk[threadIdx.x >> 6] = (uint32_t)__popcll(bk); wm[threadIdx.x >> 6] = (uint32_t)__popcll(bm); }
   __syncthreads();
   if (threadIdx.x == 0) blockCounts[blockIdx.x] = make_uint2(wk[0] + wk[1] + wk[2] + wk[3], wm[0] + wm[1] + wm[2] + wm[3]);
 }
@@ -414,18 +424,27 @@ __global__ void __launch_bounds__(1024) plocFinal(const PlocState* __restrict__ 
   }
   __syncthreads();
   while (m > 1u) {
-    for (uint32_t i = threadIdx.x; i < m; i += 1024u) {      // nearest neighbour within the radius, smallest merged box, ties to the lower position
+    // nearest neighbour within the radius: smallest merged box, ties to the lower position.  As the list shrinks, more lanes share one
+    // position's search (`group` consecutive lanes, each every group-th neighbour, then the best of the group): the rounds of the tail
+    // are chains of dependent LDS reads, and a thousand threads are there anyway
+    uint32_t group = 1u;
+    while (group < 32u && group * 2u * m <= 1024u) group *= 2u;
+    for (uint32_t i = threadIdx.x / group; i < m; i += 1024u / group) {      // (uniform per wave: m and group are)
       float mine[6];
       for (int k = 0; k < 6; ++k) mine[k] = L.box[k][i];
-      float best = __builtin_inff(); int bj = -1;
+      float best = __builtin_inff(); int bj = 0x7FFFFFFF;
       const int lo = max((int)i - radius, 0), hi = min((int)i + radius, (int)m - 1);
-      for (int j = lo; j <= hi; ++j) {
+      for (int j = lo + (int)(threadIdx.x % group); j <= hi; j += (int)group) {
         if (j == (int)i) continue;
         const float ex = fmaxf(mine[3], L.box[3][j]) - fminf(mine[0], L.box[0][j]), ey = fmaxf(mine[4], L.box[4][j]) - fminf(mine[1], L.box[1][j]), ez = fmaxf(mine[5], L.box[5][j]) - fminf(mine[2], L.box[2][j]);
         const float d = (ex * ey + ey * ez) + ez * ex;
         if (d < best) { best = d; bj = j; }
       }
-      L.nn[i] = bj;
+      for (uint32_t o = 1u; o < group; o <<= 1) {
+        const float od = __shfl_xor(best, (int)o); const int oj = __shfl_xor(bj, (int)o);
+        if (od < best || (od == best && oj < bj)) { best = od; bj = oj; }
+      }
+      if (threadIdx.x % group == 0u) L.nn[i] = bj == 0x7FFFFFFF ? -1 : bj;
     }
     __syncthreads();
     // flags, ranks and everything a surviving position needs, into registers (two positions per thread) ...
@@ -514,24 +533,42 @@ __global__ void emitNodes(int n, const uint32_t* __restrict__ order, const float
 // 4-wide collapse: every internal node of even depth becomes a Bvh4Node whose entries are its grandchildren (or
 // its children where those are leaves).  Boxes are the binary tree's own child boxes, so the set of triangles a
 // ray reaches can only grow relative to the binary traversal (one box test per two levels is skipped).
+// Multi-leaves (round 3): a child or grandchild whose whole subtree holds at most `leafTris` triangles becomes ONE entry, a leaf of
+// several triangles -- reference ~(first slot | (count - 1) << 28), box = the subtree's -- and the nodes below it are never visited:
+// the bottom level or two of the tree, the ones that miss the LDS table and the L1, go away for one more triangle test or two per
+// leaf step (the leaf slots are in depth-first order, leafRankKernel, so a subtree's triangles are consecutive).  leafTris = 1: none.
+RT_DEV int32_t multiLeafRef(int32_t x, const int32_t* __restrict__ left, const uint32_t* __restrict__ cnt0) {
+  int32_t y = x;
+  while (y >= 0) y = left[y];      // the subtree's first slot: its leftmost leaf
+  return ~(int32_t)((uint32_t)~y | (cnt0[x] << 28));      // cnt0 = internal nodes of the subtree = triangles - 1
+}
 __global__ void emitNodes4(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
                            const int32_t* __restrict__ right, const int32_t* __restrict__ nodeParent, const float* __restrict__ nodeBox,
-                           Bvh4Node* __restrict__ nodes4) {
+                           const uint32_t* __restrict__ cnt0, uint32_t leafTris, Bvh4Node* __restrict__ nodes4) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
+  const auto small = [&](int32_t x) { return cnt0 != nullptr && cnt0[x] + 1u <= leafTris; };
   int depth = 0;
   for (int p = nodeParent[i]; p >= 0; p = nodeParent[p]) ++depth;
   if (depth & 1) return;
-  int32_t refs[4]; int cnt = 0;
+  if (depth != 0 && small(i)) return;      // inside a multi-leaf: nobody refers to it (the root is always a node)
+  int32_t refs[4], boxOf[4]; int cnt = 0;      // boxOf: the leaf slot (< 0: ~slot) or node whose box the entry carries
   const int32_t ch[2] = {left[i], right[i]};
   for (int s = 0; s < 2; ++s) {
-    if (ch[s] < 0) refs[cnt++] = ch[s];
-    else { refs[cnt++] = left[ch[s]]; refs[cnt++] = right[ch[s]]; }
+    if (ch[s] < 0) { refs[cnt] = ch[s]; boxOf[cnt++] = ch[s]; }
+    else if (small(ch[s])) { refs[cnt] = multiLeafRef(ch[s], left, cnt0); boxOf[cnt++] = ch[s]; }
+    else {
+      const int32_t g[2] = {left[ch[s]], right[ch[s]]};
+      for (int q = 0; q < 2; ++q) {
+        if (g[q] >= 0 && small(g[q])) { refs[cnt] = multiLeafRef(g[q], left, cnt0); boxOf[cnt++] = g[q]; }
+        else { refs[cnt] = g[q]; boxOf[cnt++] = g[q]; }
+      }
+    }
   }
   Bvh4Node nd;
   for (int k = 0; k < 4; ++k) {
     if (k < cnt) {
-      const float* b = refs[k] < 0 ? &triBox[6 * (size_t)order[~refs[k]]] : &nodeBox[6 * (size_t)refs[k]];
+      const float* b = boxOf[k] < 0 ? &triBox[6 * (size_t)order[~boxOf[k]]] : &nodeBox[6 * (size_t)boxOf[k]];
       nd.minx[k] = b[0]; nd.miny[k] = b[1]; nd.minz[k] = b[2]; nd.maxx[k] = b[3]; nd.maxy[k] = b[4]; nd.maxz[k] = b[5];
       nd.ref[k] = refs[k];
     } else {
@@ -542,6 +579,34 @@ __global__ void emitNodes4(int n, const uint32_t* __restrict__ order, const floa
   }
   nd.pad[0] = depth >> 1;      // level in the 4-wide tree (read by -DRT_TRACE_STATS builds only)
   nodes4[i] = nd;
+}
+// Leaf slots in depth-first order of the finished tree.  PLOC starts from the Morton order, and the clusters it merges are neighbours
+// within its search radius, not adjacent ones: a subtree's triangles are scattered over up to ~32 slots.  The rank of a leaf in a
+// depth-first walk is the number of triangles to its left: on the way up to the root, the left sibling's subtree wherever the path
+// arrives from the right (cnt0: internal nodes below a node = its triangles - 1).  leafPermuteKernel then moves every per-slot array
+// to the new slots and rewrites the leaf references of the nodes.
+__global__ void leafRankKernel(int n, const int32_t* __restrict__ left, const int32_t* __restrict__ right, const int32_t* __restrict__ nodeParent,
+                               const int32_t* __restrict__ leafParent, const uint32_t* __restrict__ cnt0, uint32_t* __restrict__ rank) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  uint32_t r = 0;
+  int32_t ref = ~s;
+  for (int32_t cur = leafParent[s]; cur >= 0; cur = nodeParent[cur]) {
+    const int32_t l = left[cur];
+    if (right[cur] == ref) r += l < 0 ? 1u : cnt0[l] + 1u;
+    ref = cur;
+  }
+  rank[s] = r;
+}
+__global__ void leafPermuteKernel(int n, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ orderIn, const int32_t* __restrict__ leafParentIn,
+                                  uint32_t* __restrict__ orderOut, int32_t* __restrict__ leafParentOut, int32_t* __restrict__ left, int32_t* __restrict__ right) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const uint32_t r = rank[i]; orderOut[r] = orderIn[i]; leafParentOut[r] = leafParentIn[i]; }
+  if (i < n - 1) {
+    const int32_t l = left[i], rr = right[i];
+    if (l < 0) left[i] = ~(int32_t)rank[~l];
+    if (rr < 0) right[i] = ~(int32_t)rank[~rr];
+  }
 }
 __global__ void emitTris(int n, const uint32_t* __restrict__ order, const float* __restrict__ verts, const uint32_t* __restrict__ idx, BvhTri* __restrict__ tris) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,6 +620,7 @@ __global__ void emitTris(int n, const uint32_t* __restrict__ order, const float*
   }
   t.prim = prim;
   for (int k = 0; k < 3; ++k) { t.pad0[k] = 0; t.pad1[k] = 0; }
+  t.pad0[0] = prim;      // once more in the record's third 16-byte word: the trace kernel fetches three words per triangle, not four
   tris[s] = t;
 }
 // The table of the tree's top for the trace kernel's LDS (rtggx_device.h RT_TOP_*): entry k = the 4-wide node topList[k], its
@@ -575,7 +641,8 @@ __global__ void emitTop(int count, const int32_t* __restrict__ topList, const in
 // and every node's rank in it (topRank: -1 elsewhere, cleared by the caller).  One workgroup walks the tree level by level; the order
 // is the one a queue would give: a node's internal grandchildren left to right, nodes in list order.
 __global__ void __launch_bounds__(128) planTopKernel(uint32_t capacity, int32_t root, uint32_t numNodes, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
-                                                     int32_t* __restrict__ topList, int32_t* __restrict__ topRank, BuildResult* res) {
+                                                     const uint32_t* __restrict__ cnt0, uint32_t leafTris, int32_t* __restrict__ topList, int32_t* __restrict__ topRank, BuildResult* res) {
+  const auto small = [&](int32_t x) { return cnt0 != nullptr && cnt0[x] + 1u <= leafTris; };      // a multi-leaf of the 4-wide tree (emitNodes4), not a node
   __shared__ int32_t list[128]; __shared__ uint32_t offs[128]; __shared__ uint32_t sCount, sHead;
   if (capacity > 128u) capacity = 128u;
   if (threadIdx.x == 0) { sCount = 0u; sHead = 0u; if (root >= 0 && numNodes > 0u && capacity > 0u) { list[0] = root; sCount = 1u; } }
@@ -583,21 +650,26 @@ __global__ void __launch_bounds__(128) planTopKernel(uint32_t capacity, int32_t 
   for (;;) {
     const uint32_t head = sHead, count = sCount;
     if (head >= count || count >= capacity) break;
-    int32_t g[4]; uint32_t k = 0;
+    // the (at most four) grandchildren of my node that are 4-wide nodes themselves, in entry order; -1: none
+    int32_t g0 = -1, g1 = -1, g2 = -1, g3 = -1;
     if (head + threadIdx.x < count) {
       const int32_t v = list[head + threadIdx.x];
-      const int32_t ch[2] = {left[v], right[v]};
-      for (int side = 0; side < 2; ++side) {
-        if (ch[side] < 0) continue;
-        const int32_t gg[2] = {left[ch[side]], right[ch[side]]};
-        for (int q = 0; q < 2; ++q) if (gg[q] >= 0) g[k++] = gg[q];
-      }
+      const int32_t c0 = left[v], c1 = right[v];
+      if (c0 >= 0 && !small(c0)) { const int32_t a = left[c0], b = right[c0]; if (a >= 0 && !small(a)) g0 = a; if (b >= 0 && !small(b)) g1 = b; }
+      if (c1 >= 0 && !small(c1)) { const int32_t a = left[c1], b = right[c1]; if (a >= 0 && !small(a)) g2 = a; if (b >= 0 && !small(b)) g3 = b; }
     }
+    const uint32_t k = (g0 >= 0 ? 1u : 0u) + (g1 >= 0 ? 1u : 0u) + (g2 >= 0 ? 1u : 0u) + (g3 >= 0 ? 1u : 0u);
     offs[threadIdx.x] = k;
     __syncthreads();
     if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < count - head; ++t) { const uint32_t v = offs[t]; offs[t] = run; run += v; } sHead = count; sCount = min(capacity, count + run); }
     __syncthreads();
-    for (uint32_t q = 0; q < k; ++q) { const uint32_t pos = count + offs[threadIdx.x] + q; if (pos < capacity) list[pos] = g[q]; }
+    {
+      uint32_t pos = count + offs[threadIdx.x];
+      if (g0 >= 0) { if (pos < capacity) list[pos] = g0; ++pos; }
+      if (g1 >= 0) { if (pos < capacity) list[pos] = g1; ++pos; }
+      if (g2 >= 0) { if (pos < capacity) list[pos] = g2; ++pos; }
+      if (g3 >= 0) { if (pos < capacity) list[pos] = g3; ++pos; }
+    }
     __syncthreads();
   }
   const uint32_t count = sCount;
@@ -683,6 +755,7 @@ __global__ void refitTris(int n, const uint32_t* __restrict__ order, const float
   BvhTri t;
   t.prim = prim;
   for (int k = 0; k < 3; ++k) { t.pad0[k] = 0; t.pad1[k] = 0; }
+  t.pad0[0] = prim;
   for (int k = 0; k < 3; ++k) {
     const float a = verts[6 * (size_t)idx[3 * (size_t)prim] + k], b = verts[6 * (size_t)idx[3 * (size_t)prim + 1] + k], c = verts[6 * (size_t)idx[3 * (size_t)prim + 2] + k];
     t.v0[k] = a; t.v1[k] = b; t.v2[k] = c;
@@ -869,10 +942,17 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
       steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocInit, dim3(nb), dim3(256), 0, st, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, s.clRef[0], s.clBox[0]); });
       const uint32_t rounds = plocRoundsFor(n);
       for (uint32_t r = 0; r < rounds; ++r) {
-        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocNearest, dim3(nb), dim3(256), 0, st, (const PlocState*)s.state, r, radius, A, s.blockCounts); });
+        steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocNearest, dim3(nb), dim3(256 * RT_PLOC_LANES), 0, st, (const PlocState*)s.state, r, radius, A, s.blockCounts); });
         steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocScatter, dim3(nb), dim3(256), 0, st, s.state, r, (const uint2*)s.blockCounts, A); });
       }
       steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocFinal, dim3(1), dim3(1024), 0, st, (const PlocState*)s.state, rounds, radius, n, A); });
+      // leaf slots in depth-first order (multi-leaves: emitNodes4); scratch: codes[1] = ranks, order2 / clRef[0] = the moved arrays
+      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(leafRankKernel, dim3(nb), dim3(256), 0, st, (int)n, (const int32_t*)t.left, (const int32_t*)t.right, (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent,
+                                                               (const uint32_t*)t.cnt[0], s.codes[1]); });
+      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(leafPermuteKernel, dim3(nb), dim3(256), 0, st, (int)n, (const uint32_t*)s.codes[1], (const uint32_t*)t.order, (const int32_t*)t.leafParent,
+                                                               s.order2, s.clRef[0], t.left, t.right); });
+      steps.push_back([=](hipStream_t st) { hipMemcpyAsync(t.order, s.order2, 4 * (size_t)n, hipMemcpyDeviceToDevice, st); });
+      steps.push_back([=](hipStream_t st) { hipMemcpyAsync(t.leafParent, s.clRef[0], 4 * (size_t)n, hipMemcpyDeviceToDevice, st); });
       // the refit schedule
       const uint32_t treeletGrid = std::min<uint32_t>(std::max<uint32_t>((n + RT_TREELET_NODES / 4 - 1) / (RT_TREELET_NODES / 4), 1u), 2048u);
       for (int l = 0; l < RT_TREELET_LEVELS; ++l) {
@@ -885,7 +965,9 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
     const uint32_t topCap = slot == 0 ? RT_TOP_SLOT0 : RT_TOP_SLOT1;
     const int32_t root = t.root;
     steps.push_back([=](hipStream_t st) { hipMemsetAsync(t.topRank, 0xFF, 4 * (size_t)(n - 1), st); });
-    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(planTopKernel, dim3(1), dim3(128), 0, st, topCap, root, n - 1, (const int32_t*)t.left, (const int32_t*)t.right, t.topList, t.topRank, t.dResult); });
+    const uint32_t* cnt0 = t.refittable ? t.cnt[0] : nullptr; const uint32_t leafTris = t.refittable ? c->leafTris : 1u;
+    t.leafTris = leafTris;
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(planTopKernel, dim3(1), dim3(128), 0, st, topCap, root, n - 1, (const int32_t*)t.left, (const int32_t*)t.right, cnt0, leafTris, t.topList, t.topRank, t.dResult); });
     steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, st, (int)n, (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent, &t.dResult->depth); });
     steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(treeCostKernel, dim3(std::min<uint32_t>((n - 1 + 255) / 256, 48u)), dim3(256), 0, st, (int)n - 1, (const float*)t.nodeBox, &t.dResult->cost); });
   }
@@ -901,7 +983,7 @@ static void emitTree(MeshDev& m, const BvhTopo& t, uint32_t set, bool full, hipS
     if (full) hipMemsetAsync(m.nodes4Buf[set], 0, sizeof(Bvh4Node) * (size_t)(n - 1), s);
     hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right, (const float*)t.nodeBox, m.nodesBuf[set]);
     hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right,
-                       (const int32_t*)t.nodeParent, (const float*)t.nodeBox, m.nodes4Buf[set]);
+                       (const int32_t*)t.nodeParent, (const float*)t.nodeBox, t.refittable ? (const uint32_t*)t.cnt[0] : (const uint32_t*)nullptr, t.leafTris, m.nodes4Buf[set]);
     if (t.result.topCount) hipLaunchKernelGGL(emitTop, dim3((t.result.topCount + 63) / 64), dim3(64), 0, s, (int)t.result.topCount, (const int32_t*)t.topList, (const int32_t*)t.topRank, (const Bvh4Node*)m.nodes4Buf[set], m.topBuf[set]);
   }
   m.topCountBuf[set] = n > 1 ? t.result.topCount : 0u;
@@ -915,6 +997,14 @@ static int harvest(MeshDev& m, BvhTopo& t, uint32_t slot) {
   static const bool log = getenv("RTGGX_BUILD_LOG") != nullptr;
   if (log) fprintf(stderr, "[rtggx] build of mesh %u: %u triangles, %u rounds (%u clusters handed to the last workgroup, %u at the start of its LDS rounds), treelets %u / %u / %u, table %u, depth %u, cost %.1f\n",
                    slot, t.numTris, t.result.numRounds, t.result.finalEntry, t.result.finalLds, t.result.treelets[0], t.result.treelets[1], t.result.treelets[2], t.result.topCount, t.result.depth, t.result.cost);
+  if (log && t.numTris > 1 && t.numTris <= 64) {      // small trees: the arrays themselves
+    const uint32_t nn = t.numTris - 1;
+    std::vector<int32_t> l(nn), r(nn), tl(128), tr(nn); std::vector<uint32_t> c0(nn);
+    hipMemcpy(l.data(), t.left, 4 * nn, hipMemcpyDeviceToHost); hipMemcpy(r.data(), t.right, 4 * nn, hipMemcpyDeviceToHost); hipMemcpy(c0.data(), t.cnt[0], 4 * nn, hipMemcpyDeviceToHost);
+    hipMemcpy(tl.data(), t.topList, 4 * 128, hipMemcpyDeviceToHost); hipMemcpy(tr.data(), t.topRank, 4 * nn, hipMemcpyDeviceToHost);
+    for (uint32_t i = 0; i < nn; ++i) fprintf(stderr, "   node %u: left %d right %d cnt0 %u topRank %d\n", i, l[i], r[i], c0[i], tr[i]);
+    fprintf(stderr, "   topList:"); for (uint32_t k = 0; k < t.result.topCount; ++k) fprintf(stderr, " %d", tl[k]); fprintf(stderr, "  (root %d, leafTris %u)\n", t.root, t.leafTris);
+  }
   return 0;
 }
 

@@ -157,6 +157,28 @@ RT_DEV f3 localToWorld(f3 n, f3 l) {   // :129-147
   const f3 yAxis = cross3(n, xAxis);
   return (xAxis * l.x + yAxis * l.y) + n * l.z;
 }
+// Opt-in sampler (rtggx_set_sampler; north_star: "GGX-VNDF importance sampling in the hit path"): the half vector from the distribution of
+// VISIBLE normals (Heitz 2018, "Sampling the GGX Distribution of Visible Normals", listing 1; isotropic, alpha = roughness^2 as in
+// computeLocalDirectionGGX), in the tangent frame of localToWorld.  The reference samples the plain GGX NDF (RayTracing.hlsl:92-101,
+// 424-484): that stays the default and the parity path; this one has its own oracle counterpart (orc_raytrace.h vndf_half_vector).
+RT_DEV f3 vndfHalfVector(f3 n, f3 v, float alpha, float cosPhi, float sinPhi, float u) {
+  const f3 up = fabsf(n.y) < 0.999f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+  const f3 xAxis = normalize3(cross3(up, n));
+  const f3 yAxis = cross3(n, xAxis);
+  const f3 ve = mk3(dot3(v, xAxis), dot3(v, yAxis), dot3(v, n));
+  const f3 vh = normalize3(mk3(alpha * ve.x, alpha * ve.y, ve.z));
+  const float lensq = vh.x * vh.x + vh.y * vh.y;
+  const f3 t1v = lensq > 0.0f ? mk3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : mk3(1.0f, 0.0f, 0.0f);
+  const f3 t2v = cross3(vh, t1v);
+  const float r = sqrtf(u);
+  const float t1 = r * cosPhi;
+  float t2 = r * sinPhi;
+  const float sw = 0.5f * (1.0f + vh.z);
+  t2 = (1.0f - sw) * sqrtf(1.0f - t1 * t1) + sw * t2;
+  const f3 nh = (t1 * t1v + t2 * t2v) + sqrtf(fmaxf(0.0f, (1.0f - t1 * t1) - t2 * t2)) * vh;
+  const f3 hl = normalize3(mk3(alpha * nh.x, alpha * nh.y, fmaxf(0.0f, nh.z)));
+  return (xAxis * hl.x + yAxis * hl.y) + n * hl.z;
+}
 struct Tri3 { f3 pos[3], nrm[3]; };
 RT_DEV Tri3 getVertices(const float4* __restrict__ fat, uint32_t prim) {   // :230-244, from the primitive's fat triangle (rtggx_context.h): five 16-byte loads, one dependent step
   const float4* p = fat + 5 * (size_t)prim;
@@ -209,7 +231,7 @@ struct GenArgs {
   const float4* fat0; const float4* fat1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* cosSin;
-  RayRec* rays; HitKey* hits; uint32_t* binCount;
+  RayRec* rays; HitKey* hits; uint32_t* binCount; uint32_t binSlots;      // slots per bin (rt_queue.h)
   uint32_t* frameRays;      // 256 per-frame ray counters, zeroed here, added to by the trace kernel
   uint32_t tilesX, numTiles, rowBegin, rowEnd;
   // adaptive split (trace.hip): null / 0 when off
@@ -295,9 +317,14 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
       const uint32_t skip = (inst << 24) | prim;
       {  // computeReflection depth 0 :424-484
         const float a = rghMtl.x * rghMtl.x;
-        const float cosTheta = sqrtf((1.0f - xiY) / (1.0f + (a * a - 1.0f) * xiY));
-        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-        const f3 Hh = localToWorld(N, mk3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta));
+        const bool vndf = (fp.flags & RT_FLAG_VNDF) != 0u;      // uniform
+        f3 Hh;
+        if (vndf) Hh = vndfHalfVector(N, V, a, cosPhi, sinPhi, xiY);
+        else {
+          const float cosTheta = sqrtf((1.0f - xiY) / (1.0f + (a * a - 1.0f) * xiY));
+          const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+          Hh = localToWorld(N, mk3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta));
+        }
         const f3 R = reflect3(-V, Hh);
         const float NoL = dot3(N, R);
         if (NoL <= 0.0f) A.reflOut[pix] = 0u;   // :459
@@ -314,6 +341,11 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
           rr.dx = R.x; rr.dy = R.y; rr.dz = R.z;
           rr.pixel = (uint32_t)pix; rr.skip = skip; rr.flags = 0u;
           rr.wx = ((NoL * F.x) * vis) * k; rr.wy = ((NoL * F.y) * vis) * k; rr.wz = ((NoL * F.z) * vis) * k;   // :477
+          if (vndf) {      // BRDF x NoL / pdf of the visible-normal sampler = F x G2 / G1(V) = F x G1(L), with the separable Smith terms of Vis_Smith
+            const float a2 = a * a;
+            const float g1l = (2.0f * NoL) / (NoL + sqrtf(NoL * (NoL - NoL * a2) + a2));
+            rr.wx = F.x * g1l; rr.wy = F.y * g1l; rr.wz = F.z * g1l;
+          }
         }
       }
       if (rghMtl.y < 1.0f) {   // :559-564, computeDiffuse depth 0 :486-535
@@ -332,8 +364,8 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
   const uint32_t bin = blockIdx.x * 4u + wave;
   const unsigned long long maskR = __ballot(wantRefl), maskD = __ballot(wantDiff), below = (1ull << lane) - 1ull;
   const uint32_t nR = (uint32_t)__popcll(maskR);
-  RayRec* dst = A.rays + (size_t)bin * RT_BIN;
-  HitKey* keys = A.hits + (size_t)bin * RT_BIN;      // every ray starts as a miss at TMax
+  RayRec* dst = A.rays + (size_t)bin * A.binSlots;
+  HitKey* keys = A.hits + (size_t)bin * A.binSlots;      // every ray starts as a miss at TMax
   if (wantRefl) { const uint32_t k = (uint32_t)__popcll(maskR & below); dst[k] = rr; keys[k] = hitKey(RT_RAY_TMAX, 0xFFFFFFFFu); }
   if (wantDiff) { const uint32_t k = nR + (uint32_t)__popcll(maskD & below); dst[k] = rd; keys[k] = hitKey(RT_RAY_TMAX, 0xFFFFFFFFu); }
   const uint32_t nRaysInBin = nR + (uint32_t)__popcll(maskD);
@@ -373,7 +405,7 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
 // Kernel 3: hit / miss shading
 // =========================================================================================================
 struct ShadeArgs {
-  const RayRec* rays; const HitKey* hits; const uint32_t* binCount;
+  const RayRec* rays; const HitKey* hits; const uint32_t* binCount; uint32_t binSlots;
   const float4* fat0; const float4* fat1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* sh;
@@ -416,9 +448,9 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) shadeKernel(const Fram
       if (vis != 0u && ((A.carryMask >> ((vis - 1u) >> 24)) & 1u)) A.diffOut[pix] = A.diffPrev[pix];
     }
   }
-  const uint32_t count = min(A.binCount[bin] & 0xFFu, RT_BIN);
+  const uint32_t count = min(A.binCount[bin] & 0xFFu, A.binSlots);
   for (uint32_t i = threadIdx.x & 63u; i < count; i += 64u) {
-    const size_t slot = (size_t)bin * RT_BIN + i;
+    const size_t slot = (size_t)bin * A.binSlots + i;
     const float4* rp = reinterpret_cast<const float4*>(A.rays + slot);
     const float4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
     // the round-1 names: ra = origin, rb = direction, rc = (pixel, skip, flags), rw = weight
@@ -481,7 +513,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
   G.fat0 = c->mesh[0].fat; G.fat1 = c->mesh[1].fat;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
-  G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.frameRays = c->rayCounter32;
+  G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.binSlots = c->binSlots; G.frameRays = c->rayCounter32;
   G.tilesX = tilesX; G.numTiles = tilesX * tilesY; G.rowBegin = rb; G.rowEnd = re;
   const uint32_t splitWork = c->splitWork, splitMaxShift = c->splitMaxShift;
   const uint32_t sliceShift = chooseSliceShift(c, true, G.numTiles * 4u);
@@ -526,7 +558,7 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
   ShadeArgs S;
   S.diffPrev = c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS]; S.visDepth = c->visDepth; S.tilesX = tilesX; S.rowBegin = rb; S.rowEnd = re;
   S.carryMask = (fp.mat.RoughMetals[0][1] >= 1.0f ? 1u : 0u) | (fp.mat.RoughMetals[1][1] >= 1.0f ? 2u : 0u);      // rghMtl.y < 1 is the test of :559; it is the instance's constant
-  S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitKey*)c->hitQueue; S.binCount = c->binCount;
+  S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitKey*)c->hitQueue; S.binCount = c->binCount; S.binSlots = c->binSlots;
   S.fat0 = c->mesh[0].fat; S.fat1 = c->mesh[1].fat;
   S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;
   S.reflOut = c->rtRefl; S.diffOut = c->rtDiff;
@@ -540,9 +572,9 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
 }
 
 // ---- test entry: closest-hit queries for an explicit ray list (through the same trace kernel) ---------------
-__global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, RayRec* q0, HitKey* keys, uint32_t* binCount, float2* tRange) {
+__global__ void fillTestQueue(const float* __restrict__ rays, uint32_t n, uint32_t binSlots, RayRec* q0, HitKey* keys, uint32_t* binCount, float2* tRange) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i % RT_BIN == 0 && i < n) binCount[i / RT_BIN] = n - i < RT_BIN ? n - i : RT_BIN;   // bins are filled densely, in order
+  if (i % binSlots == 0 && i < n) binCount[i / binSlots] = n - i < binSlots ? n - i : binSlots;   // bins are filled densely, in order
   if (i >= n) return;
   const float* r = rays + 8 * (size_t)i;
   RayRec rr;
@@ -574,12 +606,12 @@ __global__ void exportTestHits(const FrameParams* __restrict__ fpp, const RayRec
 }
 int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s) {
   if (!n) return 0;
-  if (n > c->numBinsMax * RT_BIN) { setError("rtggx_trace_rays: at most %u rays per launch", c->numBinsMax * RT_BIN); return -1; }
-  const uint32_t numBins = (((n + RT_BIN - 1u) / RT_BIN) + 3u) & ~3u;   // whole tiles of four bins
+  if (n > c->numBinsMax * c->binSlots) { setError("rtggx_trace_rays: at most %u rays per launch", c->numBinsMax * c->binSlots); return -1; }
+  const uint32_t numBins = (((n + c->binSlots - 1u) / c->binSlots) + 3u) & ~3u;   // whole tiles of four bins
   RT_HIP(hipMemsetAsync(c->binCount, 0, (size_t)numBins * 4, s));
   // the rays' own (TMin, TMax): one float2 per slot, kept for the context's lifetime once a caller has used this entry point
   if (!c->testRayRange) RT_HIP(hipMalloc(&c->testRayRange, (size_t)c->numBinsMax * RT_BIN * sizeof(float2)));
-  hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, (RayRec*)c->rayQueue, (HitKey*)c->hitQueue, c->binCount, (float2*)c->testRayRange);
+  hipLaunchKernelGGL(fillTestQueue, dim3((n + 255) / 256), dim3(256), 0, s, dRays, n, c->binSlots, (RayRec*)c->rayQueue, (HitKey*)c->hitQueue, c->binCount, (float2*)c->testRayRange);
   c->traceRayRange = c->testRayRange;
   { const int r = launchTrace(c, fp, s, numBins, false, 0u, 0u, chooseSliceShift(c, false, numBins), -1); c->traceRayRange = nullptr; if (r) return r; }
   hipLaunchKernelGGL(exportTestHits, dim3((n + 255) / 256), dim3(256), 0, s, c->dParams + c->slot, (const RayRec*)c->rayQueue, (const HitKey*)c->hitQueue, n,

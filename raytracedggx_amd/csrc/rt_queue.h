@@ -11,7 +11,12 @@
 
 namespace rt {
 
-#define RT_BIN 128u          // ray slots per bin = 2 rays x 64 pixels (64-byte ray record + 8-byte hit key per slot)
+// Ray slots per bin (48-byte ray record + 8-byte hit key per slot): a bin is a wave's 8x8 pixel sub-tile, at most one reflection ray per
+// pixel -- and one diffuse ray where a material's metallic is below 1.  The context allocates RT_BIN_MIN slots per bin while both
+// materials are fully metallic (the sample's default) and grows to RT_BIN with the first frame whose constants carry a metallic below 1
+// (capi.hip rtggx_update_frame; round 3: the bins are the largest allocation of an input set, and three kernels stride over them).
+#define RT_BIN 128u
+#define RT_BIN_MIN 64u
 
 // Adaptive split of the trace launch (trace.hip): what a bin cost in the previous frame, in lane-steps, decides where and
 // how it is traced in this one.  Tuned on the 1080p bunny frame (mean bin: ~700 lane-steps, 14 steps of a wave):

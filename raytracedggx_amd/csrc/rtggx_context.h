@@ -68,6 +68,7 @@ struct BvhTopo {
   BuildResult* dResult = nullptr; BuildResult* hResult = nullptr;      // device record, pinned copy
   BuildResult result{};                      // the host's copy, valid once the build has ended
   uint32_t numTris = 0; int32_t root = -1;
+  uint32_t leafTris = 1;                     // triangles a leaf of the 4-wide tree may hold (emitNodes4); fixed when the build is planned
   bool refittable = false;                   // a PLOC build (the Karras radix tree of RTGGX_BVH_RADIX_TREE has no rounds)
 };
 
@@ -129,7 +130,9 @@ struct FrameParams {
   float invWorld[2][16];         // TLAS: world -> object, row-vector row-major
   uint32_t W, H;
   uint32_t rowBegin, rowEnd;     // strip of the frame this context renders
+  uint32_t flags, pad[3];        // RT_FLAG_*
 };
+#define RT_FLAG_VNDF 1u          // rtggx_set_sampler: visible-normal sampling of the reflection lobe instead of the reference's NDF sampling
 
 // Scene pointers as the trace/shade kernels see them (device-resident copy in rtggx_context::dScene).
 struct Scene {
@@ -180,7 +183,9 @@ struct rtggx_context {
   bool fltRflIsFltDff = false;          // the last denoise ran without diffuse passes: FilteredOut == FilteredOut1 and only the latter was written
   bool externalStream = false;
 
+  bool vndf = false;             // rtggx_set_sampler
   float rebuildRatio = 1.2f; uint32_t rebuildSteps = 16;      // rtggx_set_refit_policy
+  uint32_t leafTris = 1;         // triangles per leaf of the 4-wide trees built from now on (RTGGX_LEAF_TRIS, rtggx_debug_leaf_tris; 2-4: "multi-leaves", lbvh.hip emitNodes4)
   rt::MeshDev mesh[2];
   rt::EnvDev env;
   float* sh = nullptr;           // 27 floats
@@ -236,7 +241,7 @@ struct rtggx_context {
   void* rayQueue = nullptr;
   void* hitQueue = nullptr;
   uint32_t* binCount = nullptr;         // rays in each bin
-  uint32_t numBinsMax = 0;
+  uint32_t numBinsMax = 0, binSlots = 64;      // bins per set; ray slots per bin (rt_queue.h RT_BIN_MIN / RT_BIN)
   void *testRayRange = nullptr, *traceRayRange = nullptr;      // rtggx_trace_rays: the rays' own (TMin, TMax); set only around that entry point's launch
   int32_t* stackOverflow = nullptr;     // traversal-stack spill area (entries beyond the LDS stack), sized from
   uint32_t spillEntries = 0;            // the depth of the built trees: [spillEntries][numBinsMax * 128] words

@@ -42,8 +42,8 @@ struct TraceArgs {
   uint32_t haveMesh0, haveMesh1;
   const RayRec* rays; HitKey* hits;
   const float2* tRange;      // (TMin, TMax) per ray slot for rtggx_trace_rays; null: the shader's constants (rt_queue.h)
-  const uint32_t* binCount; uint32_t numBins;
-  int32_t* overflow;        // [entry][numBinsMax * RT_BIN] spill area for stacks deeper than RT_STACK
+  const uint32_t* binCount; uint32_t numBins, binSlots;      // slots per bin (rt_queue.h)
+  int32_t* overflow;        // [entry][RT_SPILL_WAVES * 64] spill area for stacks deeper than RT_STACK, by resident wave (see launchTrace)
   uint32_t* rayTotals;       // 256 per-frame partial counters (the current frame parity's half)
   uint32_t* stats;           // 768 RT_TRACE_STATS words
   unsigned long long* runTotals;   // 256 running totals (rtggx_ray_total)
@@ -98,6 +98,7 @@ struct TraceArgs {
 #ifndef RT_PREFETCH
 #define RT_PREFETCH 0     // touch-prefetch of the next record: measured +20 % kernel time (one more divergent load per step; profiles/r02_d_limiter.txt)
 #endif
+#define RT_SPILL_WAVES 16384u    // waves a trace launch may consist of (launchTrace: resident workgroups use 256 x 10-16 of them); sizes the stack spill area
 #define RT_TOP_FIELDS 7          // float4 fields of a Bvh4Node the traversal reads
 template <int WAVES, int TOP> struct TraceLds {
   int32_t stack[RT_STACK * 64 * WAVES];
@@ -110,7 +111,7 @@ typedef __attribute__((address_space(3))) int32_t LdsInt;
 typedef __attribute__((address_space(3))) uint32_t LdsUint;
 typedef float __attribute__((ext_vector_type(4))) NativeFloat4;      // float4 is a class: it has no copy from another address space
 typedef __attribute__((address_space(3))) NativeFloat4 LdsFloat4;
-template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& fp, const TraceArgs& A, LdsInt* const stackMem, LdsUint* const victimMem, const LdsFloat4* const topMem, const uint32_t item) {
+template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& fp, const TraceArgs& A, LdsInt* const stackMem, LdsUint* const victimMem, const LdsFloat4* const topMem, const uint32_t item, const uint32_t waveSlot) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (item >> 3) & 3u, vblock = ((item >> 5) << 3) | (item & 7u), ldsWave = threadIdx.x >> 6;
   // Workgroup -> tile.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2; handing every
@@ -150,13 +151,13 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
   const uint32_t raysPerWave = 64u >> shift;
   const uint32_t countWord = A.binCount[bin];
   if (vblock >= A.splitBlocks && A.binWork != nullptr && (countWord >> 8) != 0u) return;      // traced by the waves of the split list
-  const uint32_t count = min(countWord & 0xFFu, RT_BIN);
+  const uint32_t count = min(countWord & 0xFFu, A.binSlots);
   if (count <= slice * raysPerWave) return;
   LdsInt* const stackBase = stackMem + ldsWave * (RT_STACK * 64);                         // entry e of lane l at [e * 64 + l]
   LdsInt* const stack = stackBase + lane;
   LdsUint* const victims = victimMem + ldsWave * 64;
   const size_t spillStride = A.spillStride;
-  int32_t* const spill = A.overflow + (size_t)bin * 512u + slice * 64u + lane;            // entry e at spill[e * spillStride] (512 lanes per bin: up to 8 waves)
+  int32_t* const spill = A.overflow + (size_t)waveSlot * 64u + lane;                       // entry e at spill[e * spillStride]: a wave of the launch owns its 64 words of every entry
   const unsigned long long laneLt = (1ull << lane) - 1ull;
   uint32_t nRays = 0, work = 0;
 #ifdef RT_TRACE_STATS
@@ -165,11 +166,11 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
 #endif
   for (uint32_t base = 0; base < count; base += 64u) {
   const uint32_t rayIndex = base + slice * raysPerWave + lane;
-  const uint32_t slot = bin * RT_BIN + min(rayIndex, RT_BIN - 1u);
+  const uint32_t slot = bin * A.binSlots + min(rayIndex, A.binSlots - 1u);
   const bool hasRay = lane < raysPerWave && rayIndex < count;
 
   // ---- the ray (world space) ------------------------------------------------------------------------------------
-  const uint32_t raySlot = hasRay ? slot : bin * RT_BIN;
+  const uint32_t raySlot = hasRay ? slot : bin * A.binSlots;
   const float4* rp = reinterpret_cast<const float4*>(A.rays + raySlot);
   const float4 q0 = rp[0], q1 = rp[1];      // origin + dx | dy dz pixel skip
   const float4 ra = make_float4(q0.x, q0.y, q0.z, 0.0f), rb = make_float4(q0.w, q1.x, q1.y, 0.0f);
@@ -309,24 +310,36 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
         ++stLeafPhase;
 #endif
         if (atLeaf) {
-          const float4* rec = tris + (size_t)(~cur) * 4;
-          float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-          asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
-          asm volatile("" : "+v"(q2.x), "+v"(q3.x));
-          // q0 = v0.xyz v1.x | q1 = v1.yz v2.xy | q2 = v2.z pad pad pad | q3 = prim pad pad pad
-          const uint32_t id = (INST << 24) | __float_as_uint(q3.x);
-          if (id != skip) {
-            float t, b1, b2;
-            if (woopTest(r, q0, q1, q2, t, b1, b2) && t > tmin) {
-              const bool closer = t < myT;
-              const bool tie = myId != 0xFFFFFFFFu && t == myT && id < myId;
-              if (closer || tie) { myT = t; myId = id; }
-            }
+          // a leaf holds 1-4 consecutive triangles (lbvh.hip emitNodes4): reference ~(first slot | (count - 1) << 28)
+          const uint32_t lr = (uint32_t)~cur, nTri = (lr >> 28) + 1u;
+          const float4* rec = tris + (size_t)(lr & 0x0FFFFFFFu) * 4;
+          // two triangles per round trip: the second one's three words are fetched with the first one's (a leaf of one triangle fetches one)
+          for (uint32_t k = 0; k < nTri; k += 2u, rec += 8) {
+            const bool two = k + 1u < nTri;
+            float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            float4 p0 = q0, p1 = q1, p2 = q2;
+            if (two) { p0 = rec[4]; p1 = rec[5]; p2 = rec[6]; }
+            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+            asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(p2.x), "+v"(p2.y));
+            asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z), "+v"(p0.w), "+v"(p1.x), "+v"(p1.y), "+v"(p1.z), "+v"(p1.w));
+            // q0 = v0.xyz v1.x | q1 = v1.yz v2.xy | q2 = v2.z prim pad pad
+            const auto test = [&](const float4& t0, const float4& t1, const float4& t2) {
+              const uint32_t id = (INST << 24) | __float_as_uint(t2.y);
+              if (id == skip) return;
+              float t, b1, b2;
+              if (woopTest(r, t0, t1, t2, t, b1, b2) && t > tmin) {
+                const bool closer = t < myT;
+                const bool tie = myId != 0xFFFFFFFFu && t == myT && id < myId;
+                if (closer || tie) { myT = t; myId = id; }
+              }
+            };
+            test(q0, q1, q2);
+            if (two) test(p0, p1, p2);
+#ifdef RT_TRACE_STATS
+            stLeaf += two ? 2u : 1u;
+#endif
           }
           popOrFinish();
-#ifdef RT_TRACE_STATS
-          ++stLeaf;
-#endif
         }
       }
     }
@@ -335,7 +348,7 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
     //    behind that iteration's ballots, work sharing and LDS traffic; asking for the line now turns that fetch's L2 round trip
     //    (500-900 cycles under load) into an L1 hit.  One 4-byte load per lane, its value unused.
     if (job) {
-      const float* line = cur >= 0 ? reinterpret_cast<const float*>(nodes + (size_t)cur * 8) : reinterpret_cast<const float*>(tris + (size_t)(~cur) * 4);
+      const float* line = cur >= 0 ? reinterpret_cast<const float*>(nodes + (size_t)cur * 8) : reinterpret_cast<const float*>(tris + (size_t)((uint32_t)~cur & 0x0FFFFFFFu) * 4);
       pf = __builtin_nontemporal_load(line);
     }
 #endif
@@ -406,7 +419,7 @@ template <int WAVES, int PER_SIMD, int TOP> __global__ void __launch_bounds__(64
     j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
     const uint32_t item = ((blockIdx.x >> 3) + j * groupsPerXcd) * 8u + xcd;
     if (j >= 0x1000000u || item >= A.totalItems) break;
-    traceItem<TOP>(*fpp, A, (LdsInt*)lds.stack, (LdsUint*)lds.victims, (const LdsFloat4*)lds.top, item);
+    traceItem<TOP>(*fpp, A, (LdsInt*)lds.stack, (LdsUint*)lds.victims, (const LdsFloat4*)lds.top, item, blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6));
   }
   // the last wave of the workgroup to leave stamps the end (no barrier: a wave that is done gives its slot back at once)
   if ((threadIdx.x & 63u) == 0u && A.stamps != nullptr && atomicAdd(&lds.done, 1u) == (uint32_t)WAVES - 1u) atomicMax(A.stamps + 2u * (A.launch % 3u) + 1u, wall_clock64());
@@ -483,18 +496,21 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.tris1 = (const float4*)(have1 ? (const void*)c->mesh[1].tris : c->dummyRecord);
   T.root0 = c->mesh[0].root; T.root1 = c->mesh[1].root; T.haveMesh0 = have0; T.haveMesh1 = have1;
   T.rays = (const RayRec*)c->rayQueue; T.hits = (HitKey*)c->hitQueue; T.tRange = (const float2*)c->traceRayRange;
-  T.binCount = c->binCount; T.numBins = numBins;
-  // stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get
-  // (a 4-wide node leaves at most 3 entries behind, and there is one per two levels of the binary tree)
+  T.binCount = c->binCount; T.numBins = numBins; T.binSlots = c->binSlots;
+  // Stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get (a 4-wide node leaves at most 3
+  // entries behind, and there is one per two levels of the binary tree).  The spill area belongs to the launch's WAVES, not to the bins
+  // (round 3; per bin it was 2 x 20 entries x 32 640 bins x 2 KB = 2.7 GB for the bunny at 1080p, 4.3 GB for the dragon, four times
+  // that at 4K -- for an area the bunny and dragon frames touch a handful of times): at most RT_SPILL_WAVES waves per launch, which is
+  // what caps the grid of the single-wave variant below.
   const uint32_t deepest = 3u * ((c->mesh[0].depth > c->mesh[1].depth ? c->mesh[0].depth : c->mesh[1].depth) / 2u + 1u);
   if (deepest > RT_STACK + c->spillEntries) {
     RT_HIP(hipDeviceSynchronize());
     if (c->stackOverflow) { RT_HIP(hipFree(c->stackOverflow)); c->stackOverflow = nullptr; }
     c->spillEntries = deepest - RT_STACK;
-    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)2 * c->spillEntries * c->numBinsMax * 512 * 4));      // twice: two traversals can be in flight (traceSpillHalf)
+    RT_HIP(hipMalloc(&c->stackOverflow, (size_t)2 * c->spillEntries * RT_SPILL_WAVES * 64 * 4));      // twice: two traversals can be in flight (traceSpillHalf)
   }
-  T.overflow = c->stackOverflow + (size_t)c->traceSpillHalf * c->spillEntries * c->numBinsMax * 512; T.rayTotals = c->rayCounter32; T.stats = c->rayCounterBuf + 1024; T.runTotals = c->rayCounter + 256;
-  T.spillStride = (size_t)c->numBinsMax * 512;
+  T.overflow = c->stackOverflow + (size_t)c->traceSpillHalf * c->spillEntries * RT_SPILL_WAVES * 64; T.rayTotals = c->rayCounter32; T.stats = c->rayCounterBuf + 1024; T.runTotals = c->rayCounter + 256;
+  T.spillStride = (size_t)RT_SPILL_WAVES * 64;
   T.countRowBegin = countRays ? fp.rowBegin : 0u; T.countRowEnd = countRays ? fp.rowEnd : 0u; T.width = fp.W;
 #ifdef RT_TRACE_STATS
   hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounterBuf + 1024);
@@ -521,13 +537,15 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   static const int forced = getenv("RTGGX_TRACE_WAVES") ? atoi(getenv("RTGGX_TRACE_WAVES")) : 0;      // measurement: 1, 10, 12, 14, 16
   static const uint32_t tinyRays = getenv("RTGGX_TINY_RAYS") ? (uint32_t)atoi(getenv("RTGGX_TINY_RAYS")) : RT_TINY_RAYS;
   const uint32_t waves = forced ? (uint32_t)forced : (!countRays || c->lastFrameRays < tinyRays) ? 1u : c->traceWaves;
-  const uint32_t perCu = waves == 1u ? 0x10000u : 1u;      // single-wave workgroups: one per item, the dispatcher deals them
+  const uint32_t perCu = waves == 1u ? RT_SPILL_WAVES / 256u : 1u;      // single-wave workgroups: one per item, the dispatcher deals them -- up to RT_SPILL_WAVES of them (three times the
+                                                                         // wave slots the chip offers this kernel); beyond that they take a second item, a third, ... (the loop in the kernel)
   if (waves == 1u) T.topCount0 = T.topCount1 = 0u;
   T.stamps = waves == 1u ? nullptr : c->traceStamps; T.launch = c->traceStampLaunch++;      // (thousands of workgroups stamping one word would take longer than the launch)
   // as many workgroups as stay resident, a multiple of 8 so that every XCD gets its share; fewer when there is less to do
   const uint32_t wanted = (T.totalItems + waves - 1u) / waves;
   uint32_t blocks = c->numCUs * perCu < wanted ? c->numCUs * perCu : wanted;
   blocks = (blocks + 7u) & ~7u;
+  if (blocks * waves > RT_SPILL_WAVES) blocks = (RT_SPILL_WAVES / waves) & ~7u;      // (every wave of the launch owns a piece of the spill area)
   const FrameParams* const dfp = c->dParams + c->slot;
 #define RT_LAUNCH_TRACE(W, PER_SIMD, TOP) { if (start || stop) hipExtLaunchKernelGGL((traceKernel<W, PER_SIMD, TOP>), dim3(blocks), dim3(64 * W), 0, s, start, stop, 0, dfp, T); \
                                             else hipLaunchKernelGGL((traceKernel<W, PER_SIMD, TOP>), dim3(blocks), dim3(64 * W), 0, s, dfp, T); }

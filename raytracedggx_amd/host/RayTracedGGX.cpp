@@ -31,6 +31,7 @@ void RayTracedGGX::OnInit() {
   if (!m_rayTracer->BuildAccelerationStructures()) throw std::runtime_error("BuildAccelerationStructures failed: " + m_rayTracer->GetLastError());
   if (!m_rayTracer->Postinit()) throw std::runtime_error("Postinit failed");
   if (m_hasMetallicOverride) for (uint32_t i = 0; i < RayTracer::NUM_MESH; ++i) m_rayTracer->SetMetallic(i, m_metallics[i]);
+  if (m_vndf) m_rayTracer->SetSampler(true);            // -vndf: visible-normal sampling of the reflection lobe (opt-in; the reference samples the NDF)
   m_rayTracer->SetAsyncCompute(m_asyncCompute != 0);   // -sync: one stream, submission order (the sample's single command list)
 
   if (m_deformAmplitude != 0.0f) {       // key shapes of the breathing model: x and z displaced by a wave travelling up the y axis
@@ -190,7 +191,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     return (arg[0] == '-' || arg[0] == '/') && lower(arg + 1) == lower(name);
   };
   // On POSIX an absolute path also starts with '/': such a token is a flag only when it names one.
-  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "device", "dump", "gpus", "track", "deform", "rank", "idfile", "strips", "balance"};
+  static const char* const kFlags[] = {"warp", "uma", "mesh", "env", "width", "height", "frames", "dt", "metallic", "sharedmem", "sync", "vndf", "device", "dump", "gpus", "track", "deform", "rank", "idfile", "strips", "balance"};
   const auto isFlagName = [&](const char* name) { for (const char* f : kFlags) if (lower(name) == f) return true; return false; };
   const auto hasNextArgValue = [&](int i) {
     if (i + 1 >= argc) return false;
@@ -213,6 +214,7 @@ void RayTracedGGX::ParseCommandLineArgs(char* argv[], int argc) {
     else if (isArgMatched(i, "metallic")) { nextFloat(i, m_metallics[0]); nextFloat(i, m_metallics[1]); m_hasMetallicOverride = true; }
     else if (isArgMatched(i, "sharedmem")) m_useSharedMem = true;
     else if (isArgMatched(i, "sync")) m_asyncCompute = 0;
+    else if (isArgMatched(i, "vndf")) m_vndf = true;
     else if (isArgMatched(i, "device")) { if (hasNextArgValue(i)) m_device = std::atoi(argv[++i]); }
     else if (isArgMatched(i, "dump")) { if (hasNextArgValue(i)) m_dumpPrefix = argv[++i]; }
     else if (isArgMatched(i, "deform")) { nextFloat(i, m_deformAmplitude); }

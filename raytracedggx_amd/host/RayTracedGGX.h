@@ -97,6 +97,7 @@ class RayTracedGGX {
   std::string m_dumpPrefix;
   int m_gpus = 1, m_rank = -1, m_strips = 1; bool m_balance = true; std::string m_idFile;
   bool m_hasMetallicOverride = false;
+  bool m_vndf = false;                 // -vndf
   // -deform <amplitude>: the model breathes -- a travelling sine wave through its vertices, DeformPeriod key shapes computed once
   // at start-up and handed to RayTracer::UpdateMesh one per frame (per-frame host cost: one copy of the vertex array)
   float m_deformAmplitude = 0.0f;

@@ -65,6 +65,8 @@ bool RayTracer::Postinit() { return check(rtggx_sync(m_ctx), "rtggx_sync"); }
 
 void RayTracer::SetMetallic(uint32_t meshIdx, float metallic) { check(rtggx_set_metallic(m_ctx, meshIdx, metallic), "rtggx_set_metallic"); }
 
+void RayTracer::SetSampler(bool vndf) { check(rtggx_set_sampler(m_ctx, vndf ? 1 : 0), "rtggx_set_sampler"); }
+
 void RayTracer::SetAsyncCompute(bool asyncCompute) { check(rtggx_set_async_compute(m_ctx, asyncCompute ? 1 : 0), "rtggx_set_async_compute"); }
 
 void RayTracer::UpdateFrame(uint8_t frameIndex, const xm::Float3& eyePt, const xm::Matrix& viewProj, float timeStep) {

@@ -39,6 +39,7 @@ class RayTracer {
   // m_asyncCompute of the sample (RayTracedGGX.h:118): true = the multi-stream frame (its two queues), false = one stream in
   // submission order (its single command list, RayTracedGGX.cpp:513-556)
   void SetAsyncCompute(bool asyncCompute);
+  void SetSampler(bool vndf);            // rtggx_set_sampler: visible-normal (Heitz 2018) sampling of the reflection lobe, opt-in (-vndf)
   void UpdateFrame(uint8_t frameIndex, const xm::Float3& eyePt, const xm::Matrix& viewProj, float timeStep);
   void TransformSH();
   void Render(uint8_t frameIndex);

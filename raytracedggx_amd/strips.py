@@ -139,12 +139,12 @@ class StripRenderer:
             if transport is None or torch_buffers:
                 import torch
                 self.torch = torch
-                # The main-stream passes (shade, denoise, tone map) run on a torch stream of our own, and the RCCL ops
-                # are issued with that stream current: kernels and transfers are then ordered by the stream.  (Not
-                # torch's default stream: on ROCm that is the null stream, whose handle is 0 -- "no stream" to
-                # rtggx_set_stream -- and the library's own streams do not synchronise with it.)
-                self.stream = torch.cuda.Stream(device=device)
-                self.context.set_stream(self.stream.cuda_stream)
+                # The exchange is ordered behind the frame on the context's OWN main stream, wrapped for torch (ExternalStream) -- not on a
+                # stream torch creates: the library runs a frame on four streams, as many as HIP gives hardware queues by default, and a
+                # fifth stream shares a queue with one of them and serialises with it (round 3: a 1080p strip of eight took 0.124 ms on a
+                # torch stream against 0.076 on the library's own; profiles/r03_h_strip_projection.txt).  Asking for the stream also tells
+                # the library that the caller orders work of its own behind the frame (the tone map stays on this stream).
+                self.stream = torch.cuda.ExternalStream(self.context.stream(), device=device)
                 self._tss = [self._wrap(capi.BUF_TSS0, "<u8"), self._wrap(capi.BUF_TSS1, "<u8")]
                 self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
         self._last = None

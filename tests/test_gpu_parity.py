@@ -133,6 +133,58 @@ def test_bunny_three_frames(built, shared_mem):
         p.close()
 
 
+@pytest.mark.parametrize("leaf_tris", [2, 4])
+def test_multi_triangle_leaves(built, leaf_tris):
+    """Leaves of up to 2 / 4 triangles in the 4-wide tree (rtggx_debug_leaf_tris; the default is 1): the tree is structure-checked (every
+    leaf slot reached exactly once through the 4-wide nodes, every multi-leaf a subtree of the binary tree with that subtree's box),
+    rays against the oracle's walk of the binary tree, and two frames of the whole parity check."""
+    p = Pair(480, 270, metallic=(1.0, 0.5), shared_mem=True)
+    try:
+        p.ctx.leaf_tris(leaf_tris)
+        p.ctx.build_as()
+        p.give_oracle_the_device_trees()
+        n4 = p.ctx.readback(p.capi.BUF_BVH4_NODES1).reshape(-1, 32)
+        refs = n4[:, 24:28].view(np.int32)
+        multi = refs[(refs < 0) & ((~refs >> 28) > 0)]
+        assert multi.size > 1000 and ((~multi >> 28) + 1).max() == leaf_tris, "the tree holds leaves of several triangles"
+        for f in range(2):
+            p.frame(); p.check_frame("leaves of %d, frame %d" % (leaf_tris, f))
+        rng = np.random.default_rng(11)
+        n = 8000
+        org = np.array([10.0, 10.0, -24.0]) + rng.standard_normal((n, 3)) * 2.0
+        tgt = np.stack([rng.uniform(-8, 8, n), rng.uniform(-1, 10, n), rng.uniform(-8, 8, n)], 1)
+        rays = np.concatenate([org, tgt - org, np.full((n, 1), 1e-5), np.full((n, 1), 1e4)], 1).astype(np.float32)
+        g, c = p.ctx.trace_rays(rays), p.o.trace_rays(rays)      # the oracle walks the BINARY tree, one triangle per leaf
+        for k in ("valid", "inst", "prim", "t", "b1", "b2"):
+            sel = slice(None) if k == "valid" else c["valid"]
+            np.testing.assert_array_equal(g[k][sel], c[k][sel], err_msg=k)
+        assert g["valid"].sum() > n // 4
+    finally:
+        p.close()
+
+
+def test_vndf_sampler_against_its_oracle_counterpart(built):
+    """The opt-in sampler (rtggx_set_sampler / -vndf; north_star: "GGX-VNDF importance sampling"): visible-normal sampling of the reflection
+    lobe (Heitz 2018) in rayGenKernel against its restatement in the oracle -- the whole frame check, three frames, rays bit for bit.
+    It is a different estimator from the reference's NDF sampling (the default, every other test): the traced image differs, the
+    ray count differs (no sample below the view's horizon), and the mean radiance agrees (both are unbiased estimates of the same lobe)."""
+    p = Pair(480, 270, metallic=(1.0, 1.0), shared_mem=True)
+    q = Pair(480, 270, metallic=(1.0, 1.0), shared_mem=True)
+    try:
+        p.ctx.set_sampler(True); p.o.set_sampler(True)
+        for f in range(3):
+            p.frame(); p.check_frame("vndf frame %d" % f)
+            q.frame()
+        a, b = O.unpack_r11g11b10f(p.ctx.readback(p.capi.BUF_RT_REFL)).astype(np.float64), O.unpack_r11g11b10f(q.ctx.readback(q.capi.BUF_RT_REFL)).astype(np.float64)
+        covered = p.ctx.readback(p.capi.BUF_VISIBILITY) != 0
+        assert (np.abs(a - b).sum(axis=-1)[covered] > 0).mean() > 0.5, "a different sampler: most covered pixels trace another direction"
+        assert p.rays >= q.rays, "visible normals never reflect below the surface where the plain distribution does (%d vs %d rays)" % (p.rays, q.rays)
+        ma, mb = np.median(a[covered], axis=0), np.median(b[covered], axis=0)
+        assert np.all(np.abs(ma - mb) < 0.35 * np.maximum(mb, 1e-3)), "the two estimators agree on the typical radiance (%s vs %s)" % (ma, mb)
+    finally:
+        p.close(); q.close()
+
+
 def test_dragon_diffuse_path(built):
     # metallic < 1 on both meshes: second ray per pixel, SH irradiance, both closest-hit groups (RayTracing.hlsl:559-564, 593-614)
     p = Pair(480, 270, mesh="dragon.obj", metallic=(0.25, 0.5), shared_mem=True)
@@ -202,7 +254,7 @@ def test_lbvh_structure_and_device_traversal(built):
         assert depth <= 48, "unexpectedly deep tree for 69666 triangles: %d levels" % depth
         bvh_checks.bvh_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH_TRIS0), p.ctx.bvh_root(0), 12)
         used = bvh_checks.bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH4_NODES1), p.ctx.bvh_root(1))
-        assert 69665 // 3 <= used <= 69665, "4-wide nodes: %d" % used
+        assert 69665 // 16 <= used <= 69665, "4-wide nodes: %d" % used      # (multi-leaves of up to four triangles: ~10 000 nodes; with single-triangle leaves ~35 000)
         bvh_checks.bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH4_NODES0), p.ctx.bvh_root(0))
         rng = np.random.default_rng(11)
         n = 20000

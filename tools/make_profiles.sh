@@ -15,7 +15,8 @@ mkdir -p "$out" profiles
 summaries_only=$2
 if [ "$summaries_only" != "--summaries-only" ]; then
 tools/pmc.sh "$out/pmc" 1 2 > /dev/null
-tools/pmc.sh "$out/pmc" 10 11 > /dev/null
+tools/pmc.sh "$out/pmc" 4 4 > /dev/null      # TCP_TOTAL_CACHE_ACCESSES: the vector L1's request rate (roofline.l1_requests)
+tools/pmc.sh "$out/pmc" 9 11 > /dev/null     # GRBM_GUI_ACTIVE (cycles), FETCH_SIZE, WRITE_SIZE
 fi
 # the counter summaries come first: bench.py quotes the newest profiles/*_pmc_traffic.json in its roofline.traffic
 python3 tools/pmc_report.py "$out/pmc" > "profiles/${tag}_pmc_report.txt"
@@ -55,6 +56,16 @@ for block in blocks:
     if m and name.split("(")[0] in frame_kernels:
         valu += float(m.group(1))
 out["valu_instructions_per_frame"] = int(valu)
+# requests the trace kernel puts to the vector L1 per CU and cycle (DESIGN.md "what bounds it": a traversal step costs its divergent lane
+# requests, and the L1 takes ~one per cycle per CU): TCP_TOTAL_CACHE_ACCESSES / (CUs x GRBM_GUI_ACTIVE), both per dispatch of the
+# (serialised) counter passes
+for block in blocks:
+    if kernel_name(block) == "rt::traceKernel":
+        vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([0-9.]+) per dispatch", block, re.M)}
+        if "TCP_TOTAL_CACHE_ACCESSES" in vals and vals.get("GRBM_GUI_ACTIVE", 0) > 0:
+            out["trace_kernel_l1"] = {"requests_per_launch": int(vals["TCP_TOTAL_CACHE_ACCESSES"]), "cycles_per_launch": int(vals["GRBM_GUI_ACTIVE"]), "cus": 256,
+                                      "requests_per_cu_cycle": round(vals["TCP_TOTAL_CACHE_ACCESSES"] / (256.0 * vals["GRBM_GUI_ACTIVE"]), 4),
+                                      "source": "rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES and --pmc GRBM_GUI_ACTIVE (tools/pmc.sh groups 4, 9)"}
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 print("trace kernel traffic:", out["kernels"].get("rt::traceKernel"))
 EOF
