@@ -26,6 +26,9 @@ import subprocess
 import sys
 import time
 
+# The renderer runs a frame on four streams, five with the strip exchange of N > 1 (rtggx_get_exchange_stream): HIP's default of four hardware
+# queues would make two of them share one.  Read when the runtime initialises, i.e. before torch is imported; the ranks inherit it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -144,6 +144,16 @@ int  rtggx_set_stream(rtggx_context* ctx, void* hip_stream);
 /* The context's main stream (its own, or the one handed in): what a host enqueues there -- the per-frame RCCL exchange of the
  * multi-GPU host, host/Strips.cpp -- is ordered behind the frame's tone map and before the next frame's temporal pass. */
 int  rtggx_get_stream(rtggx_context* ctx, void** hip_stream);
+/* Multi-GPU strips: a stream of the context's for the caller's exchange of history rows between two frames (RCCL sends / receives), so
+ * that it runs beside the next frame's shading and spatial filters instead of in front of them:
+ *     rtggx_tone_map(f);  rtggx_exchange_begin(ctx);  <exchange on the stream of rtggx_get_exchange_stream>;  rtggx_exchange_end(ctx);
+ * begin orders that stream behind frame f's last kernel, end marks where the exchange ends; the TEMPORAL pass of frame f + 1 waits for it
+ * (and with it everything that could touch the rows exchanged: that frame's tone map, the next H pass).  The exchange may read and write
+ * TemporalSSOut[parity of f] and the back buffer.  (The frame's other consumers keep using rtggx_get_stream.  The library then runs five
+ * streams: export GPU_MAX_HW_QUEUES=8 before the process touches HIP, or two of them share a hardware queue.) */
+int  rtggx_get_exchange_stream(rtggx_context* ctx, void** stream);
+int  rtggx_exchange_begin(rtggx_context* ctx);
+int  rtggx_exchange_end(rtggx_context* ctx);
 /* Ordering of the back buffer.  A context left to itself may run a frame's tone map beside the NEXT frame's filters on another
  * stream (DESIGN.md "The frame on the device"): the back buffer is complete after rtggx_sync / rtggx_readback.  A caller that consumes
  * it by other means says so by calling rtggx_set_stream, rtggx_get_stream or rtggx_buffer_ptr(RTGGX_BUF_BACKBUFFER | TSS*): from then

@@ -29,7 +29,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
-           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream",
+           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream", "rtggx_get_exchange_stream", "rtggx_exchange_begin", "rtggx_exchange_end",
            "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_leaf_tris", "rtggx_debug_shader_clock"]
 
 
@@ -234,6 +234,19 @@ class Context:
         self.L.rtggx_debug_trace_split.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         self._check(self.L.rtggx_debug_trace_split(self.h, work_per_wave, max_shift, capacity, C.byref(d)))
         return int(d.value)
+
+    def exchange_stream(self):
+        """The context's exchange stream as an integer handle (rtggx_get_exchange_stream): for the caller's sends / receives between frames."""
+        h = C.c_void_p()
+        self.L.rtggx_get_exchange_stream.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.L.rtggx_get_exchange_stream(self.h, C.byref(h)))
+        return int(h.value or 0)
+
+    def exchange_begin(self):
+        self._check(self.L.rtggx_exchange_begin(self.h))
+
+    def exchange_end(self):
+        self._check(self.L.rtggx_exchange_end(self.h))
 
     def stream(self):
         """The context's main stream as an integer handle (rtggx_get_stream)."""

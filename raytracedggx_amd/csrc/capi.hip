@@ -108,6 +108,7 @@ static hipError_t syncStreams(rtggx_context* c) {
   flushToneMap(c);      // whoever waits for the streams wants the back buffer complete
   hipError_t e = c->ownVis ? hipStreamSynchronize(c->ownVis) : hipSuccess;
   if (e == hipSuccess && c->streamRefit) e = hipStreamSynchronize(c->streamRefit);
+  if (e == hipSuccess && c->streamExchange) e = hipStreamSynchronize(c->streamExchange);
   if (e == hipSuccess) e = hipStreamSynchronize(c->ownAS);
   if (e == hipSuccess) e = hipStreamSynchronize(c->streamMain);
   return e;
@@ -321,6 +322,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->ownAS); if (c->ownVis) hipStreamDestroy(c->ownVis);
   hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit); hipEventDestroy(c->evGen); for (auto e : c->evTraceRing) hipEventDestroy(e);
   if (c->streamRefit) hipStreamDestroy(c->streamRefit);
+  if (c->streamExchange) { hipStreamDestroy(c->streamExchange); hipEventDestroy(c->evExchange); hipEventDestroy(c->evFrameEnd); }
   delete c;
 }
 
@@ -354,6 +356,43 @@ int rtggx_set_stream(rtggx_context* c, void* stream) {
   if (stream) { c->streamMain = (hipStream_t)stream; c->externalStream = true; }
   else { c->streamMain = c->ownMain; c->externalStream = false; }
   if (!c->asyncCompute) c->streamAS = c->streamMain;
+  return 0;
+}
+
+// Multi-GPU strips: the exchange of history rows between two frames on a stream of its own.  Issued on the main stream (rtggx_get_stream)
+// the exchange -- an RCCL group of sends and receives, ~30 us on its stream -- sits in the main stream's chain between the tone map of
+// frame f and the SHADING of frame f + 1, although only the temporal pass of frame f + 1 needs what it delivers: the slowest of 8 strips of
+// the 1080p frame 0.077 -> 0.109 ms (profiles/r03_h_strip_projection.txt).  So the caller may put it on the context's exchange stream:
+//     rtggx_tone_map(f); rtggx_exchange_begin(ctx);  <sends / receives on the exchange stream>;  rtggx_exchange_end(ctx);
+// begin orders the exchange stream behind frame f's last kernel; end records where the exchange ends, and the temporal pass of frame f + 1
+// (nothing before it) waits for that.  The tone map of frame f + 1 -- which overwrites the back-buffer rows the exchange may still be
+// sending -- follows the temporal pass on the main stream; the H pass of frame f + 2, which reuses the history image as its scratch, too.
+int rtggx_get_exchange_stream(rtggx_context* c, void** stream) {
+  RT_CHECK_CTX(c);
+  if (!stream) { setError("rtggx_get_exchange_stream: null"); return -1; }
+  if (!c->streamExchange) {
+    int prioLeast = 0, prioGreatest = 0;
+    RT_HIP(hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
+    RT_HIP(hipStreamCreateWithPriority(&c->streamExchange, hipStreamNonBlocking, prioGreatest));      // on the history's critical cycle: temporal f -> exchange f -> temporal f + 1
+    RT_HIP(hipEventCreateWithFlags(&c->evExchange, hipEventDisableTiming)); RT_HIP(hipEventCreateWithFlags(&c->evFrameEnd, hipEventDisableTiming));
+  }
+  flushToneMap(c); c->callerOrdersOnMain = true;      // the caller consumes the frame outside the library: the tone map stays on the main stream (see rtggx_get_stream)
+  *stream = (void*)c->streamExchange;
+  return 0;
+}
+int rtggx_exchange_begin(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  if (!c->streamExchange) { setError("rtggx_exchange_begin: rtggx_get_exchange_stream has not been called"); return -1; }
+  flushToneMap(c);
+  if (c->lastFrameSet >= 0 && c->setReadRecorded[c->lastFrameSet]) RT_HIP(hipStreamWaitEvent(c->streamExchange, c->evSetRead[c->lastFrameSet], 0));      // rides on the frame's last kernel
+  else { RT_HIP(hipEventRecord(c->evFrameEnd, c->streamMain)); RT_HIP(hipStreamWaitEvent(c->streamExchange, c->evFrameEnd, 0)); }
+  return 0;
+}
+int rtggx_exchange_end(rtggx_context* c) {
+  RT_CHECK_CTX(c);
+  if (!c->streamExchange) { setError("rtggx_exchange_end: rtggx_get_exchange_stream has not been called"); return -1; }
+  RT_HIP(hipEventRecord(c->evExchange, c->streamExchange));
+  c->exchangePending = true;
   return 0;
 }
 
@@ -519,6 +558,11 @@ static int issuePendingRefits(rtggx_context* c, bool* touched) {
     const size_t bytes = sizeof(float) * 6 * (size_t)m.numVerts;
     const uint32_t set = c->setIndex;
     bool refit = true;
+    // MEASUREMENT (profiles/r03_i_deform_states.txt): hold this frame's refit until the previous frame's ray generation has ended (1) or its
+    // traversal has ended (2), instead of letting it start whenever the host gets to issue it
+    static const int refitPhase = getenv("RTGGX_REFIT_PHASE") ? atoi(getenv("RTGGX_REFIT_PHASE")) : 0;
+    if (refitPhase == 1 && c->asyncCompute && c->genStream && c->frameCounter > 1u) hipStreamWaitEvent(s, c->evGen, 0);
+    if (refitPhase == 2 && c->asyncCompute && c->traceRecorded[(c->frameCounter + 3u) & 3u]) hipStreamWaitEvent(s, c->evTraceRing[(c->frameCounter + 3u) & 3u], 0);
     if (m.pendingStage >= 0) {
       RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.stage[m.pendingStage], bytes, hipMemcpyHostToDevice, s));
       m.pendingStage = -1; ++m.version;
@@ -731,7 +775,8 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
   c->denoiseIssued = true;
   // the temporal pass is the last reader of the set; its event rides on the tone map instead when that follows on this stream (settleSetRead)
   const bool carry = !c->attachEvents || toneAsideEligible(c, c->slots[c->slot]);
-  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr);
+  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr, c->exchangePending ? c->evExchange : nullptr);
+  c->exchangePending = false;
   if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex;
   return r;
 }
@@ -761,6 +806,7 @@ int rtggx_tone_map(rtggx_context* c) {
   if (prepareToneMap(c, fp, &p)) {
     const bool carry = c->setReadDeferred >= 0 && c->attachEvents;
     r = launchPreparedToneMap(c, p, c->streamMain, carry ? c->evSetRead[c->setReadDeferred] : nullptr);
+    c->lastFrameSet = carry ? c->setReadDeferred : -1;      // its event completes with the frame's last kernel (rtggx_exchange_begin)
     if (carry) { c->setReadRecorded[c->setReadDeferred] = true; c->setReadDeferred = -1; }
   }
   settleSetRead(c);

@@ -484,7 +484,7 @@ static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass
   return T;
 }
 
-int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done) {
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done, hipEvent_t historyReady) {
   c->frameParity ^= 1u;   // Denoiser.cpp:69
   if (fp.rowEnd <= fp.rowBegin) return 0;
   const Targets TH = makeTargets(c, fp, ROWS_GBUFFER), TV = makeTargets(c, fp, ROWS_VFILTER), TT = makeTargets(c, fp, ROWS_TEMPORAL);
@@ -516,6 +516,7 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
     hipLaunchKernelGGL(spatialDirectKernel<2>, grid(TH, 64, 4), block, 0, s, TH); mark(6);
     hipLaunchKernelGGL(spatialDirectKernel<3>, grid(TV, 64, 4), block, 0, s, TV); mark(7);
   }
+  if (historyReady) RT_HIP(hipStreamWaitEvent(s, historyReady, 0));      // the caller's exchange of history rows, on its own stream (capi.hip rtggx_exchange_end): only the temporal pass needs them
   if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, nullptr, done, 0, TT);
   else { hipLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, TT); if (done) hipEventRecord(done, s); }
   mark(8);

@@ -1133,7 +1133,8 @@ int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
   }
   emitTree(m, t, set, m.topoVersionOfSet[set] != m.topoVersion, s);
   m.topoVersionOfSet[set] = m.topoVersion;
-  if (n > 1 && !m.costInFlight && (m.refits & 3u) == 0u) {
+  static const bool noCost = getenv("RTGGX_NO_COST_SAMPLE") != nullptr;      // measurement
+  if (n > 1 && !m.costInFlight && (m.refits & 3u) == 0u && !noCost) {
     { const int r = launchTreeCost(m, s); if (r) return r; }
     RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipEventRecord(m.evCost, s));

@@ -176,6 +176,8 @@ struct rtggx_context {
   hipEvent_t evRefit = nullptr;   // vertices of the current set uploaded and the tree refitted (stream B -> stream C)
   hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
   bool setReadRecorded[RT_SETS] = {};
+  // the caller's exchange between frames on a stream of its own (rtggx_get_exchange_stream / rtggx_exchange_begin / _end): multi-GPU strips
+  hipStream_t streamExchange = nullptr; hipEvent_t evExchange = nullptr, evFrameEnd = nullptr; bool exchangePending = false; int lastFrameSet = -1;
   int setReadDeferred = -1;      // the set whose event is still to ride on a later kernel of this frame (capi.hip settleSetRead)
   // a tone map that waits to be launched beside the NEXT frame's filters (capi.hip rtggx_tone_map), and the events of those launched that way
   bool tonePending = false, denoiseIssued = false, callerOrdersOnMain = false, toneAsideAllowed = true; rt::PreparedToneMap tonePrepared; uint32_t toneParity = 0;
@@ -327,7 +329,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
 // 5-7 us, and the frame's two chains had four of them (rocprofv3 kernel trace, profiles/).
 int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);      // hit / miss shading of the traced bins
 int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s);
-int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done = nullptr);
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done = nullptr, hipEvent_t historyReady = nullptr);      // historyReady: waited for in front of the temporal pass
 int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s);
 bool prepareToneMap(rtggx_context* c, const FrameParams& fp, PreparedToneMap* out);      // false: nothing to do (empty strip)
 int launchPreparedToneMap(rtggx_context* c, const PreparedToneMap& p, hipStream_t s, hipEvent_t done);

@@ -558,7 +558,8 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
     default: setError("launchTrace: no kernel variant with %u waves", waves); return -1;
   }
 #undef RT_LAUNCH_TRACE
-  if (countRays && !c->rayCountersInFlight && (c->traceLaunches < 8u || (c->traceLaunches & 15u) == 0u)) {     // the first frames, then every 16th: ray counters and split demand, for later launches
+  static const uint32_t counterMask = getenv("RTGGX_COUNTER_PERIOD") ? (uint32_t)atoi(getenv("RTGGX_COUNTER_PERIOD")) - 1u : 15u;      // measurement: a power of two
+  if (countRays && !c->rayCountersInFlight && (c->traceLaunches < 8u || (c->traceLaunches & counterMask) == 0u)) {     // the first frames, then every 16th: ray counters and split demand, for later launches
     RT_HIP(hipMemcpyAsync(c->hostRayCounters, c->rayCounter32, 256 * 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->splitCount, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipMemcpyAsync(c->hostRayCounters + 258, c->traceStamps + 6, 16, hipMemcpyDeviceToHost, s)); c->traceSampleLaunch = c->traceLaunches;      // sum of the kernel's durations so far, start of this launch

@@ -4,11 +4,15 @@
 //   RayTracedGGX -mesh Assets/bunny.obj 0.0 0.0 0.0 1.0 -width 1920 -height 1080 -frames 64 -dump out
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <exception>
 #include "RayTracedGGX.h"
 #include "Strips.h"
 
 int main(int argc, char* argv[]) {
+  // five streams with the strip exchange of -gpus N (rtggx.h rtggx_get_exchange_stream): HIP's default is four hardware queues.  Read when
+  // the runtime initialises, which nothing has made it do yet; the ranks the launcher starts inherit it.
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   RayTracedGGX app(1280, 720, "DXR Ray-Traced GGX");   // Main.cpp:17
   try {
     app.ParseCommandLineArgs(argv, argc);

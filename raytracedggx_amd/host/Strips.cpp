@@ -278,7 +278,12 @@ int RunRank(RayTracedGGX& app, int rank, int world, const std::string& idFile, b
   const auto rows = takeStrip(app, rank, world, bounds, HistoryApron);
   Rccl rccl;
   rccl.InitRank(rank, world, idFile);
-  void* stream = nullptr; abi(rtggx_get_stream(ctx, &stream), "rtggx_get_stream");
+  // the exchange on the main stream, behind the frame -- or, RTGGX_EXCHANGE_BESIDE=1, on the context's exchange stream: beside the next frame's
+  // shading and filters, only its temporal pass waits (rtggx.h; off by default: slower in the one-GPU emulation, profiles/r03_h_strip_projection.txt)
+  const char* be = std::getenv("RTGGX_EXCHANGE_BESIDE");
+  const bool beside = be && std::atoi(be) == 1;
+  void* stream = nullptr;
+  if (beside) abi(rtggx_get_exchange_stream(ctx, &stream), "rtggx_get_exchange_stream"); else abi(rtggx_get_stream(ctx, &stream), "rtggx_get_stream");
   const std::vector<Op> plan = ExchangePlan(app.GetHeight(), rank, world, HistoryApron, &bounds);
   std::vector<RawOp> raw[2]; bool have[2] = {false, false};      // the pointers depend on the history target only: built once per parity
   const auto t0 = std::chrono::steady_clock::now();
@@ -286,7 +291,9 @@ int RunRank(RayTracedGGX& app, int rank, int world, const std::string& idFile, b
     app.OnUpdate(); app.OnRender();
     uint32_t parity = 0; abi(rtggx_frame_parity(ctx, &parity), "rtggx_frame_parity");
     if (!have[parity]) { raw[parity] = PlanToRaw(plan, app); have[parity] = true; }
+    if (beside) abi(rtggx_exchange_begin(ctx), "rtggx_exchange_begin");
     rccl.Exchange(raw[parity], stream);
+    if (beside) abi(rtggx_exchange_end(ctx), "rtggx_exchange_end");
   }
   uint64_t rays = 0; abi(rtggx_ray_count(ctx, &rays), "rtggx_ray_count");      // synchronises
   abi(rtggx_sync(ctx), "rtggx_sync");

@@ -108,7 +108,7 @@ class StripRenderer:
     SKY_ROW_WEIGHT = float(os.environ.get("RTGGX_SKY_ROW_WEIGHT", 0.5))
 
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
-                 transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON):
+                 transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON, overlap_exchange=None):
         """dist: torch.distributed (one process per GPU).  transport: instead of dist, a callable
         transport(renderer, plan) that carries out the plan some other way (tests drive several strips from one process).
         torch_buffers: wrap the exchanged targets as torch tensors and render on torch's current stream (default: only
@@ -116,6 +116,11 @@ class StripRenderer:
         balance: False = equal strips; a list of world + 1 row numbers = these boundaries; True = every rank first renders
         PROFILE_FRAMES full frames and cuts the frame where the covered pixels (= rays, the expensive rows) balance --
         rendering is deterministic, so all ranks arrive at the same boundaries without talking to each other.
+        overlap_exchange: issue the exchange on the context's exchange stream (rtggx_get_exchange_stream), beside the next frame's shading
+        and spatial filters, instead of on the main stream in front of them (a transport that wants it issues its transfers on
+        renderer.xstream).  Default: off, or RTGGX_EXCHANGE_BESIDE=1 -- on the one GPU available to the builder the RCCL group of a one-rank
+        communicator takes 0.27 ms per frame there against 0.03 on the main stream (its send and receive workgroups wait for each other
+        while the frame's kernels hold the CUs; profiles/r03_h_strip_projection.txt): whether it pays across real links is the driver's to see.
         apron: history rows exchanged beyond each strip edge (HISTORY_APRON = 18 covers 16 px of vertical reprojection per
         frame).  A faster motion -- an orbit drag of a -track script -- makes the strips differ from the single-GPU frame:
         the temporal pass detects that (history_overreach() > 0), and a wider apron, the same on every rank, is the remedy."""
@@ -145,6 +150,8 @@ class StripRenderer:
                 # torch stream against 0.076 on the library's own; profiles/r03_h_strip_projection.txt).  Asking for the stream also tells
                 # the library that the caller orders work of its own behind the frame (the tone map stays on this stream).
                 self.stream = torch.cuda.ExternalStream(self.context.stream(), device=device)
+                self.overlap = bool(overlap_exchange) if overlap_exchange is not None else os.environ.get("RTGGX_EXCHANGE_BESIDE", "0") == "1"
+                self.xstream = torch.cuda.ExternalStream(self.context.exchange_stream(), device=device) if self.overlap else self.stream
                 self._tss = [self._wrap(capi.BUF_TSS0, "<u8"), self._wrap(capi.BUF_TSS1, "<u8")]
                 self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
         self._last = None
@@ -184,6 +191,15 @@ class StripRenderer:
     def exchange(self):
         if self.world == 1:
             return
+        overlap = getattr(self, "overlap", False)
+        if overlap:
+            self.context.exchange_begin()      # the exchange stream behind this frame's last kernel
+        try:
+            self._exchange_on(self.xstream if overlap else getattr(self, "stream", None))
+        finally:
+            if overlap:
+                self.context.exchange_end()    # the next frame's temporal pass waits for what has been issued
+    def _exchange_on(self, stream):
         if self.transport is not None:
             self.transport(self, exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds))
             return
@@ -191,11 +207,11 @@ class StripRenderer:
         if self._comm is not None:
             if self._ops[parity] is None:      # (is_send, pointer, bytes, peer), built once per history target
                 self._ops[parity] = self.raw_ops(exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds), parity)
-            self._comm.exchange(self._ops[parity], self.stream.cuda_stream)
+            self._comm.exchange(self._ops[parity], stream.cuda_stream)
             return
         if self._ops[parity] is None:          # built once per history target: the per-frame host cost is the batch call alone
             self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds), self.exchange_buffers())
-        with self.torch.cuda.stream(self.stream):
+        with self.torch.cuda.stream(stream):
             run_exchange(self.dist, None, None, ops=self._ops[parity])
 
     def raw_ops(self, plan, parity):

@@ -552,7 +552,7 @@ def test_free_running_frames_equal_synchronised_frames(built):
             a.OnDestroy(); b.OnDestroy()
 
 
-def _strips_through_rccl_equal_the_full_frame(W, H, world, balance, frames, mesh="bunny.obj", extra=()):
+def _strips_through_rccl_equal_the_full_frame(W, H, world, balance, frames, mesh="bunny.obj", extra=(), overlap=False):
     """`world` strips of one process, each its own context, exchanging through the direct RCCL path (raytracedggx_amd/rccl.py:
     ncclSend/ncclRecv in one group on the renderer's stream, pointers from StripRenderer.raw_ops) on the one GPU of the box: a
     single-rank communicator whose sends and receives pair up with each other -- against the single-context frame.  (Across
@@ -571,12 +571,13 @@ def _strips_through_rccl_equal_the_full_frame(W, H, world, balance, frames, mesh
                 src = strips[peer]
                 ops += src.raw_ops([("send", name, r0, r1, 0)], src.context.frame_parity())
                 ops += r.raw_ops([("recv", name, r0, r1, 0)], r.context.frame_parity())
+        # (`overlap`: on the strips' exchange streams, rtggx_get_exchange_stream -- begin / end are StripRenderer.exchange's)
         for t in strips:
-            r.stream.wait_stream(t.stream)
-        comm.exchange(ops, r.stream.cuda_stream)
+            r.xstream.wait_stream(t.xstream); r.xstream.wait_stream(t.stream)
+        comm.exchange(ops, r.xstream.cuda_stream)
 
     full = StripRenderer(W, H, mesh, env, extra_args=("-sharedmem",) + tuple(extra))
-    strips += [StripRenderer(W, H, mesh, env, rank=r, world=world, transport=transport, torch_buffers=True, extra_args=("-sharedmem",) + tuple(extra), balance=balance) for r in range(world)]
+    strips += [StripRenderer(W, H, mesh, env, rank=r, world=world, transport=transport, torch_buffers=True, extra_args=("-sharedmem",) + tuple(extra), balance=balance, overlap_exchange=overlap) for r in range(world)]
     if balance is True:
         assert all(s.bounds == strips[0].bounds for s in strips) and strips[0].bounds != [(r * H) // world for r in range(world + 1)]
         for _ in range(StripRenderer.PROFILE_FRAMES):          # the strips have rendered these as whole frames: the reference follows
@@ -590,7 +591,7 @@ def _strips_through_rccl_equal_the_full_frame(W, H, world, balance, frames, mesh
                 s.exchange()
             for s in strips:
                 for t in strips:
-                    s.stream.wait_stream(t.stream)
+                    s.stream.wait_stream(t.stream); s.stream.wait_stream(t.xstream)
             torch.cuda.synchronize(); full.context.sync()
             np.testing.assert_array_equal(strips[0].context.readback(capi.BUF_BACKBUFFER), full.context.readback(capi.BUF_BACKBUFFER), err_msg="frame %d" % f)
             bid = capi.BUF_TSS1 if full.context.frame_parity() else capi.BUF_TSS0
@@ -615,6 +616,14 @@ def test_strip_exchange_through_rccl_send_recv(built, world, balance):
     `balanced`: every strip first profiles two whole frames and cuts the frame where the covered pixels balance, as bench.py
     does for N > 1."""
     _strips_through_rccl_equal_the_full_frame(480, 272, world, balance, 3)
+
+
+def test_strip_exchange_on_the_exchange_stream(built):
+    """The exchange beside the next frame's shading and filters (rtggx_get_exchange_stream / rtggx_exchange_begin / _end, round 3) instead of
+    on the main stream in front of them: 8 balanced strips, free-running for 6 frames -- the assembled back buffer and every strip's
+    history bit-identical to the single-context frame, as with the exchange on the main stream."""
+    _strips_through_rccl_equal_the_full_frame(480, 272, 8, True, 6, overlap=True)
+    _strips_through_rccl_equal_the_full_frame(1920, 1080, 8, True, 4, overlap=True)
 
 
 def test_c4_bunny_4k_full_frame_and_eight_strips(built):

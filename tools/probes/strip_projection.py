@@ -4,6 +4,8 @@ strip, the strip rendered alone with balanced boundaries --
    +rccl     render + the rank's OWN exchange plan issued every frame through the real RCCL group on the rendering stream, against a
              one-rank communicator: every send of the plan is paired with a receive into a scratch buffer and every receive with a
              send from one, so the group launch, its kernel and its bytes are all there -- only the wire is missing
+   +beside   the same exchange on the context's exchange stream (rtggx_get_exchange_stream): beside the next frame's shading and filters,
+             only the temporal pass waits for it (what bench.py --gpus N and the executable's -gpus N do since round 3)
    wire      the bytes the rank sends / receives per frame and what they take over xGMI at 153 GB/s per link (history rows go to the
              two neighbours, one link each; rank 0 receives N - 1 back-buffer strips over N - 1 links in parallel): not included in
              +rccl (an intra-GPU copy stands in), listed beside it
@@ -42,12 +44,13 @@ for N in (1, 2, 4, 8):
                 ops.append((is_send, ptr, nbytes, 0))
                 ops.append((not is_send, scratch.data_ptr() + off, nbytes, 0))
                 off += (nbytes + 255) // 256 * 256
-            comm.exchange(ops, renderer.stream.cuda_stream)
+            comm.exchange(ops, renderer.xstream.cuda_stream)
 
         res = {}
-        for mode in ("compute", "+rccl"):
+        for mode in ("compute", "+rccl", "+beside"):
             transport = (lambda *_: None) if (mode == "compute" or N == 1) else self_exchange
-            s = StripRenderer(W, H, mesh, env, rank=r, world=N, transport=transport if N > 1 else None, torch_buffers=N > 1, extra_args=("-sharedmem",), balance=bounds if N > 1 else False)
+            s = StripRenderer(W, H, mesh, env, rank=r, world=N, transport=transport if N > 1 else None, torch_buffers=N > 1, extra_args=("-sharedmem",), balance=bounds if N > 1 else False,
+                              overlap_exchange=mode == "+beside")
             for _ in range(FRAMES): s.frame()
             s.context.sync(); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -55,10 +58,10 @@ for N in (1, 2, 4, 8):
             s.context.sync(); torch.cuda.synchronize()
             res[mode] = (time.perf_counter() - t0) / FRAMES * 1e3
             s.close()
-        rows.append((r, res["compute"], res["+rccl"], sent, recv, wire_us))
-        print("  N=%d strip %d: compute %.4f  +rccl %.4f   sends %7.0f KB, receives %7.0f KB per frame, longest transfer on the wire %.1f us" % (N, r, res["compute"], res["+rccl"], sent / 1e3, recv / 1e3, wire_us), flush=True)
-    slow_c, slow_x = max(x[1] for x in rows), max(x[2] for x in rows)
+        rows.append((r, res["compute"], res["+rccl"], sent, recv, wire_us, res["+beside"]))
+        print("  N=%d strip %d: compute %.4f  +rccl %.4f  +beside %.4f   sends %7.0f KB, receives %7.0f KB per frame, longest transfer on the wire %.1f us" % (N, r, res["compute"], res["+rccl"], res["+beside"], sent / 1e3, recv / 1e3, wire_us), flush=True)
+    slow_c, slow_x, slow_b = max(x[1] for x in rows), max(x[2] for x in rows), max(x[6] for x in rows)
     if N == 1: base = slow_c
-    print("N=%d: slowest strip compute %.4f ms (x%.2f), with its exchange through the RCCL group %.4f ms (x%.2f); rank 0 gathers %.0f KB per frame (%.1f us over %d links in parallel); bounds %s" % (
-        N, slow_c, base / slow_c, slow_x, base / slow_x, rows[0][4] / 1e3, max([0.0] + [(bounds[k + 1] - bounds[k]) * W * 4 / (LINK_GBS * 1e3) for k in range(1, N)]) if N > 1 else 0.0, max(N - 1, 0), bounds), flush=True)
+    print("N=%d: slowest strip compute %.4f ms (x%.2f), with its exchange through the RCCL group on the main stream %.4f ms (x%.2f), on the exchange stream %.4f ms (x%.2f); rank 0 gathers %.0f KB per frame (%.1f us over %d links in parallel); bounds %s" % (
+        N, slow_c, base / slow_c, slow_x, base / slow_x, slow_b, base / slow_b, rows[0][4] / 1e3, max([0.0] + [(bounds[k + 1] - bounds[k]) * W * 4 / (LINK_GBS * 1e3) for k in range(1, N)]) if N > 1 else 0.0, max(N - 1, 0), bounds), flush=True)
 comm.destroy()
