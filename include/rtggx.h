@@ -252,7 +252,8 @@ int  rtggx_kernel_times(rtggx_context* ctx, float* ms, uint32_t capacity, uint32
 int  rtggx_debug_shader_clock(rtggx_context* ctx, double* mhz);
 
 /* Attainable HBM bandwidth of the device (GB/s, read + written bytes): a float4 copy kernel over two buffers of `bytes` each,
- * `iterations` timed launches.  For the measured peak bench.py quotes beside the vendor figure; synchronises. */
+ * `iterations` timed launches for each of four launch shapes (2 / 4 / 8 / 16 workgroups per CU: the shape matters by 20 % on MI355X), the
+ * best one reported.  For the measured peak bench.py quotes beside the vendor figure; synchronises. */
 int  rtggx_copy_bandwidth(rtggx_context* ctx, size_t bytes, int iterations, double* gbytes_per_s);
 
 /* Size in bytes of a buffer / synchronous copy into caller memory / raw device pointer. */

@@ -293,6 +293,9 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   memset(c->slots, 0, sizeof c->slots);
   const int r = setMeshImpl(c, RTGGX_GROUND, &kGroundVerts[0][0], 24, kGroundIdx, 36);
   if (r) { return r; }
+  // hipMemset of device memory does not wait on the host, and the null stream it runs on is not ordered against this context's
+  // (non-blocking) streams: nothing of the first frame may overtake a clear
+  RT_HIP(hipStreamSynchronize(nullptr));
   *out = c;
   return 0;
 }
@@ -346,7 +349,7 @@ int rtggx_history_overreach(rtggx_context* c, uint32_t* rows, int reset) {
   if (!rows) { setError("rtggx_history_overreach: null result"); return -1; }
   RT_HIP(syncStreams(c));
   RT_HIP(hipMemcpy(rows, c->histReach, 4, hipMemcpyDeviceToHost));
-  if (reset) RT_HIP(hipMemset(c->histReach, 0, 4));
+  if (reset) { RT_HIP(hipMemset(c->histReach, 0, 4)); RT_HIP(hipStreamSynchronize(nullptr)); }
   return 0;
 }
 
@@ -494,6 +497,11 @@ int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
     }
     for (int i = 0; i < RT_SLOTS; ++i) m.stage[i] = st[i];
     { const int r = splitBvhPerSet(c, slot); if (r) return r; }
+    // A device-to-device hipMemcpy does NOT wait on the host (only its issue is synchronous) and runs on the null stream, which the
+    // non-blocking streams of this context are not ordered against: the next frame's refit on stream R wrote a set's nodes while the copy
+    // of the OLD nodes into the same array was still on its way, and the copy landed last (found once GPU_MAX_HW_QUEUES=8 gave the null
+    // stream a hardware queue of its own: test_deforming_mesh_async_refit_against_the_oracle, "child box must contain the child").
+    RT_HIP(hipStreamSynchronize(nullptr));
     m.deforming = true; m.latestSet = c->setIndex;
     c->selectSet(c->setIndex);
   }
@@ -837,7 +845,7 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
   if (n > 768) { setError("rtggx_debug_counters: at most 768 words"); return -1; }
   RT_HIP(syncStreams(c));
   RT_HIP(hipMemcpy(out, c->rayCounterBuf + 1024, (size_t)n * 4, hipMemcpyDeviceToHost));
-  if (reset) RT_HIP(hipMemset(c->rayCounterBuf + 1024, 0, 768 * 4));
+  if (reset) { RT_HIP(hipMemset(c->rayCounterBuf + 1024, 0, 768 * 4)); RT_HIP(hipStreamSynchronize(nullptr)); }
   return 0;
 }
 
@@ -876,7 +884,7 @@ int rtggx_ray_total(rtggx_context* c, uint64_t* rays, int reset) {
   RT_HIP(hipMemcpy(h, c->rayCounter + 256, sizeof h, hipMemcpyDeviceToHost));
   uint64_t s = 0; for (auto v : h) s += v;
   *rays = s;
-  if (reset) RT_HIP(hipMemset(c->rayCounter + 256, 0, sizeof h));
+  if (reset) { RT_HIP(hipMemset(c->rayCounter + 256, 0, sizeof h)); RT_HIP(hipStreamSynchronize(nullptr)); }
   return 0;
 }
 
@@ -1003,7 +1011,10 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
 
 // Attainable HBM bandwidth of the device, for the roofline's "peak measured beside the vendor figure" (SURVEY 8d): a float4
 // copy kernel over two buffers of `bytes` each (far larger than the 256 MiB Infinity Cache when bytes >= 1 GiB), timed with
-// events on the main stream; gbytes_per_s = (bytes read + bytes written) / time.
+// events on the main stream; gbytes_per_s = (bytes read + bytes written) / time.  The launch shape matters by 20 % on this part
+// (tools/microbench/copy_bw.hip, profiles/r03_h_copy_peak.txt: 2 x 1 GiB grid-stride at 4 workgroups per CU 5.6 TB/s, at 16 per CU
+// 4.6 TB/s, hipMemcpyAsync 4.8): the shapes of kCopyShapes each get `iterations` launches and the best one is reported.
+static const uint32_t kCopyShapes[] = {2u, 4u, 8u, 16u};   // workgroups per CU
 int rtggx_copy_bandwidth(rtggx_context* c, size_t bytes, int iterations, double* gbytesPerS) {
   RT_CHECK_CTX(c);
   if (!gbytesPerS || bytes < 1024 || iterations < 1) { setError("rtggx_copy_bandwidth: bad arguments"); return -1; }
@@ -1014,17 +1025,24 @@ int rtggx_copy_bandwidth(rtggx_context* c, size_t bytes, int iterations, double*
   if (hipMalloc(&dst, n * 16) != hipSuccess) { hipFree(src); setError("rtggx_copy_bandwidth: out of device memory"); return -2; }
   hipMemsetAsync(src, 0x3C, n * 16, c->streamMain);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const uint32_t blocks = c->numCUs * 16u;
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
-  hipEventRecord(e0, c->streamMain);
-  for (int i = 0; i < iterations; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
-  hipEventRecord(e1, c->streamMain);
-  hipError_t e = hipEventSynchronize(e1);
-  float ms = 0.0f;
-  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  hipError_t e = hipSuccess;
+  double best = 0.0;
+  for (uint32_t shape : kCopyShapes) {
+    const uint32_t blocks = c->numCUs * shape;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
+    hipEventRecord(e0, c->streamMain);
+    for (int i = 0; i < iterations; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
+    hipEventRecord(e1, c->streamMain);
+    e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e != hipSuccess || !(ms > 0.0f)) { if (e == hipSuccess) e = hipErrorUnknown; break; }
+    const double rate = 2.0 * (double)(n * 16) * iterations / ((double)ms * 1e-3) / 1e9;
+    if (rate > best) best = rate;
+  }
   hipEventDestroy(e0); hipEventDestroy(e1); hipFree(src); hipFree(dst);
-  if (e != hipSuccess || !(ms > 0.0f)) { setError("rtggx_copy_bandwidth: %s", hipGetErrorString(e)); return -2; }
-  *gbytesPerS = 2.0 * (double)(n * 16) * iterations / ((double)ms * 1e-3) / 1e9;
+  if (e != hipSuccess) { setError("rtggx_copy_bandwidth: %s", hipGetErrorString(e)); return -2; }
+  *gbytesPerS = best;
   return 0;
 }
 

@@ -203,16 +203,40 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
   }
 }
 
-// The queued large triangles merged into the target: one lane per pixel of the rows, 64 x 4 pixels per workgroup.
+// The queued large triangles merged into the target: 64 x 16 pixels per workgroup, four per lane (rows y, y + 4, y + 8, y + 12).  One
+// pixel per lane made this a kernel of 32 400 waves at 1080p that each fetched the list, rejected most of it by bounding box and left:
+// 30 M wave quad-cycles per frame for 8 us of work (profiles/r03_k_pmc_report.txt); a quarter of the waves do the same work.
+#define RT_LARGE_ROWS 16
 __global__ void __launch_bounds__(256) rasterLarge(uint32_t W, uint32_t rowBegin, uint32_t rowEnd, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
                                                    const uint32_t* __restrict__ largeCount, uint32_t largeCap) {
   const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63);
-  const uint32_t py = rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const uint32_t y0 = rowBegin + blockIdx.y * RT_LARGE_ROWS, py0 = y0 + (threadIdx.x >> 6);
   const uint32_t n = min(*largeCount, largeCap);
-  const unsigned long long best = mergeLargeTris(~0ull, px, py, blockIdx.x * 64, rowBegin + blockIdx.y * 4, blockIdx.x * 64 + 63, rowBegin + blockIdx.y * 4 + 3, large, n);
-  if (px < W && py < rowEnd && best != ~0ull) {
-    unsigned long long* dst = vd + (size_t)py * W + px;
-    if (best < *dst) *dst = best;
+  const int32_t bx0 = (int32_t)(blockIdx.x * 64) * 256 + 128, bx1 = bx0 + 63 * 256, by0 = (int32_t)y0 * 256 + 128, by1 = by0 + (RT_LARGE_ROWS - 1) * 256;
+  const int32_t PX = (int32_t)px * 256 + 128;
+  unsigned long long best[RT_LARGE_ROWS / 4];
+#pragma unroll
+  for (int k = 0; k < RT_LARGE_ROWS / 4; ++k) best[k] = ~0ull;
+  for (uint32_t i = 0; i < n; ++i) {
+    const LargeTri lt = large[i];
+    const int32_t minX = min(lt.X[0], min(lt.X[1], lt.X[2])), maxX = max(lt.X[0], max(lt.X[1], lt.X[2]));
+    const int32_t minY = min(lt.Y[0], min(lt.Y[1], lt.Y[2])), maxY = max(lt.Y[0], max(lt.Y[1], lt.Y[2]));
+    if (maxX < bx0 || minX > bx1 || maxY < by0 || minY > by1) continue;   // uniform per workgroup
+    const double z0 = (double)lt.z[0], dz1 = (double)lt.z[1] - z0, dz2 = (double)lt.z[2] - z0;
+#pragma unroll
+    for (int k = 0; k < RT_LARGE_ROWS / 4; ++k) {
+      const unsigned long long key = fragmentKey(PX, (int32_t)(py0 + 4u * k) * 256 + 128, lt.X, lt.Y, lt.tl & 1u, (lt.tl >> 1) & 1u, (lt.tl >> 2) & 1u, lt.invA, z0, dz1, dz2, lt.word);
+      best[k] = key < best[k] ? key : best[k];
+    }
+  }
+  if (px >= W) return;
+#pragma unroll
+  for (int k = 0; k < RT_LARGE_ROWS / 4; ++k) {
+    const uint32_t py = py0 + 4u * k;
+    if (py < rowEnd && best[k] != ~0ull) {
+      unsigned long long* dst = vd + (size_t)py * W + px;
+      if (best[k] < *dst) *dst = best[k];
+    }
   }
 }
 
@@ -244,7 +268,7 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   hipLaunchKernelGGL(rasterSmall, grid, dim3(256), 0, s, fp, dst, rb, re, (const float*)c->mesh[0].verts, (const uint32_t*)c->mesh[0].indices, c->mesh[0].numTris,
                      (const float*)c->mesh[1].verts, (const uint32_t*)c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
   if (nt) {
-    const dim3 lgrid((fp.W + 63) / 64, (re - rb + 3) / 4);
+    const dim3 lgrid((fp.W + 63) / 64, (re - rb + RT_LARGE_ROWS - 1) / RT_LARGE_ROWS);
     if (done && c->attachEvents) {      // the event rides on the pass's last kernel (rtggx_context.h)
       hipExtLaunchKernelGGL(rasterLarge, lgrid, dim3(256), 0, s, nullptr, done, 0, fp.W, rb, re, c->visDepth, (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity);
       done = nullptr;

@@ -63,9 +63,10 @@ for block in blocks:
     if kernel_name(block) == "rt::traceKernel":
         vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\S+)\s+([0-9.]+) per dispatch", block, re.M)}
         if "TCP_TOTAL_CACHE_ACCESSES" in vals and vals.get("GRBM_GUI_ACTIVE", 0) > 0:
-            out["trace_kernel_l1"] = {"requests_per_launch": int(vals["TCP_TOTAL_CACHE_ACCESSES"]), "cycles_per_launch": int(vals["GRBM_GUI_ACTIVE"]), "cus": 256,
-                                      "requests_per_cu_cycle": round(vals["TCP_TOTAL_CACHE_ACCESSES"] / (256.0 * vals["GRBM_GUI_ACTIVE"]), 4),
-                                      "source": "rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES and --pmc GRBM_GUI_ACTIVE (tools/pmc.sh groups 4, 9)"}
+            cycles = vals["GRBM_GUI_ACTIVE"] / 8.0      # the counter is summed over the 8 XCDs (2.66 M for a 0.138 ms launch at 2.4 GHz)
+            out["trace_kernel_l1"] = {"requests_per_launch": int(vals["TCP_TOTAL_CACHE_ACCESSES"]), "cycles_per_launch": int(cycles), "cus": 256,
+                                      "requests_per_cu_cycle": round(vals["TCP_TOTAL_CACHE_ACCESSES"] / (256.0 * cycles), 4),
+                                      "source": "rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES and --pmc GRBM_GUI_ACTIVE / 8 XCDs (tools/pmc.sh groups 4, 9); the launch alone on the chip (counter passes serialise the kernels)"}
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 print("trace kernel traffic:", out["kernels"].get("rt::traceKernel"))
 EOF

@@ -1,0 +1,83 @@
+// What HBM bandwidth does a plain device-to-device copy reach on this box, and with which shape of the loop?  (bench.py reports the
+// attainable peak beside the vendor's 8 TB/s; MI355X_MICROARCH.md quotes 6.29 TB/s for "a float4 copy", rtggx_copy_bandwidth read 4.5-4.8.)
+// Variants over 2 x 1 GiB (far beyond the 256 MiB Infinity Cache), 20 launches each after 5, HIP events:
+//   grid-stride float4, 256 threads, 16 workgroups per CU            (rtggx_copy_bandwidth as of round 2)
+//   the same with 4 / 8 independent loads in flight per thread
+//   non-temporal loads and stores (the data is used once)
+//   one contiguous chunk per workgroup instead of a grid stride
+//   read only (sum) and write only (fill)
+// Build: hipcc -O3 --offload-arch=gfx950 copy_bw.hip -o copy_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef float __attribute__((ext_vector_type(4))) v4;
+
+__global__ void __launch_bounds__(256) copy1(const v4* __restrict__ s, v4* __restrict__ d, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) d[i] = s[i];
+}
+template <int U, bool NT> __global__ void __launch_bounds__(256) copyU(const v4* __restrict__ s, v4* __restrict__ d, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256u;
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i + (U - 1) * stride < n; i += U * stride) {
+    v4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = NT ? __builtin_nontemporal_load(&s[i + u * stride]) : s[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(r[u], &d[i + u * stride]); else d[i + u * stride] = r[u]; }
+  }
+}
+template <int U> __global__ void __launch_bounds__(256) copyChunk(const v4* __restrict__ s, v4* __restrict__ d, size_t n) {
+  const size_t per = (n + gridDim.x - 1) / gridDim.x, b = (size_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+  for (size_t i = b + threadIdx.x; i + (U - 1) * 256u < e; i += U * 256u) {
+    v4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = s[i + u * 256u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) d[i + u * 256u] = r[u];
+  }
+}
+__global__ void __launch_bounds__(256) readOnly(const v4* __restrict__ s, float* __restrict__ out, size_t n) {
+  v4 a = {0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * 256u;
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i + 3 * stride < n; i += 4 * stride) { a += s[i]; a += s[i + stride]; a += s[i + 2 * stride]; a += s[i + 3 * stride]; }
+  if (a.x + a.y + a.z + a.w == 12345.678f) out[0] = 1.0f;
+}
+__global__ void __launch_bounds__(256) writeOnly(v4* __restrict__ d, size_t n) {
+  const v4 v = {1, 2, 3, 4};
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) d[i] = v;
+}
+
+int main() {
+  const size_t bytes = 1ull << 30, n = bytes / 16;
+  v4 *s, *d; float* o;
+  CK(hipMalloc(&s, bytes)); CK(hipMalloc(&d, bytes)); CK(hipMalloc(&o, 16));
+  CK(hipMemset(s, 0x3C, bytes)); CK(hipMemset(d, 0, bytes));
+  hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+  const int cus = p.multiProcessorCount;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto run = [&](const char* name, double moved, auto&& launch) {
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) launch();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-64s %7.1f GB/s\n", name, moved * 20 / (ms * 1e-3) / 1e9);
+  };
+  // warm the clocks: 100 ms of copies
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(copy1, dim3(cus * 16), dim3(256), 0, 0, (const v4*)s, d, n);
+  CK(hipDeviceSynchronize());
+  for (int wpc : {4, 8, 16, 32}) {
+    char nm[96]; snprintf(nm, sizeof nm, "grid-stride float4, %d workgroups per CU", wpc);
+    run(nm, 2.0 * bytes, [&] { hipLaunchKernelGGL(copy1, dim3(cus * wpc), dim3(256), 0, 0, (const v4*)s, d, n); });
+  }
+  run("4 loads in flight per thread, 8 workgroups per CU", 2.0 * bytes, [&] { hipLaunchKernelGGL((copyU<4, false>), dim3(cus * 8), dim3(256), 0, 0, (const v4*)s, d, n); });
+  run("8 loads in flight per thread, 8 workgroups per CU", 2.0 * bytes, [&] { hipLaunchKernelGGL((copyU<8, false>), dim3(cus * 8), dim3(256), 0, 0, (const v4*)s, d, n); });
+  run("4 loads in flight, non-temporal, 8 workgroups per CU", 2.0 * bytes, [&] { hipLaunchKernelGGL((copyU<4, true>), dim3(cus * 8), dim3(256), 0, 0, (const v4*)s, d, n); });
+  run("8 loads in flight, non-temporal, 16 workgroups per CU", 2.0 * bytes, [&] { hipLaunchKernelGGL((copyU<8, true>), dim3(cus * 16), dim3(256), 0, 0, (const v4*)s, d, n); });
+  run("contiguous chunk per workgroup, 4 loads in flight, 16 per CU", 2.0 * bytes, [&] { hipLaunchKernelGGL((copyChunk<4>), dim3(cus * 16), dim3(256), 0, 0, (const v4*)s, d, n); });
+  run("contiguous chunk per workgroup, 8 loads in flight, 64 per CU", 2.0 * bytes, [&] { hipLaunchKernelGGL((copyChunk<8>), dim3(cus * 64), dim3(256), 0, 0, (const v4*)s, d, n); });
+  run("read only (4 loads in flight), 16 workgroups per CU", 1.0 * bytes, [&] { hipLaunchKernelGGL(readOnly, dim3(cus * 16), dim3(256), 0, 0, (const v4*)s, o, n); });
+  run("write only, 16 workgroups per CU", 1.0 * bytes, [&] { hipLaunchKernelGGL(writeOnly, dim3(cus * 16), dim3(256), 0, 0, d, n); });
+  run("hipMemcpyAsync device to device", 2.0 * bytes, [&] { CK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, 0)); });
+  return 0;
+}

@@ -20,6 +20,13 @@ struct Params { float v[200]; };      // ~800 bytes by value, like FrameParams
 __global__ void tiny(float* p, int n, int tag) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = p[i] * 1.0001f + (float)tag; }
 __global__ void tinyBig(float* p, int n, Params q) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] += q.v[i % 200]; }
 
+// a stand-in of given duration that leaves the chip free for others: 64 workgroups wait on the 100 MHz counter
+__global__ void spin(float* p, int ticks, int tag) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = (float)tag;
+}
+
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
@@ -98,5 +105,44 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(tinyBig, g, b, 0, sM, d, n, P); for (int k = 1; k < 10; ++k) hipLaunchKernelGGL(tiny, g, b, 0, sM, d, n, k);
   CK(hipStreamEndCapture(sM, &g2)); CK(hipGraphInstantiate(&e2, g2, nullptr, nullptr, 0));
   run("graph, linear 10 kernels", [&] { CK(hipGraphLaunch(e2, sM)); });
+
+  // ---- a frame per stream: the WHOLE frame one linear graph (9 kernels with the durations of a 1920 x 171 strip, 123 us in all),
+  // K frames in flight on K streams; what joins consecutive frames -- the history: temporal(f) after temporal(f - 1) -- is an event
+  // record node behind node 7 and an event wait node before it (external events, baked per graph: graph k records E[k], waits E[k - 1]).
+  const int dur[9] = {13, 9, 10, 47, 11, 8, 10, 10, 5};
+  for (int K : {1, 2, 3, 4}) {
+    std::vector<hipStream_t> st(K); std::vector<hipEvent_t> ev(K); std::vector<hipGraphExec_t> ex(K);
+    for (int k = 0; k < K; ++k) { CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); }
+    for (int k = 0; k < K; ++k) {
+      hipGraph_t fg; CK(hipGraphCreate(&fg, 0));
+      hipGraphNode_t prev = nullptr;
+      for (int j = 0; j < 9; ++j) {
+        if (j == 7 && K > 1) {      // wait for the previous frame's temporal pass
+          hipGraphNode_t w; CK(hipGraphAddEventWaitNode(&w, fg, prev ? &prev : nullptr, prev ? 1 : 0, ev[(k + K - 1) % K])); prev = w;
+        }
+        float* pp = d + (size_t)k * 64; int ticks = dur[j] * 100, tag = j;
+        void* args[3] = {&pp, &ticks, &tag};
+        hipKernelNodeParams kp = {}; kp.func = (void*)spin; kp.gridDim = dim3(64); kp.blockDim = dim3(64); kp.kernelParams = args;
+        hipGraphNode_t nd; CK(hipGraphAddKernelNode(&nd, fg, prev ? &prev : nullptr, prev ? 1 : 0, &kp)); prev = nd;
+        if (j == 7 && K > 1) { hipGraphNode_t r; CK(hipGraphAddEventRecordNode(&r, fg, &prev, 1, ev[k])); prev = r; }
+      }
+      CK(hipGraphInstantiate(&ex[k], fg, nullptr, nullptr, 0));
+    }
+    if (K > 1) for (int k = 0; k < K; ++k) CK(hipEventRecord(ev[k], st[k]));     // the first frame's wait finds a recorded event
+    char name[64]; snprintf(name, sizeof name, "frame graph per stream, K = %d", K);
+    int f = 0;
+    run(name, [&] { CK(hipGraphLaunch(ex[f % K], st[f % K])); ++f; });
+    // the same frames as individual launches on the K streams (events by hipExtLaunchKernelGGL)
+    snprintf(name, sizeof name, "frame per stream, launches, K = %d", K);
+    f = 0;
+    run(name, [&] {
+      const int k = f % K; ++f;
+      for (int j = 0; j < 9; ++j) {
+        if (j == 7 && K > 1) CK(hipStreamWaitEvent(st[k], ev[(k + K - 1) % K], 0));
+        if (j == 7 && K > 1) hipExtLaunchKernelGGL(spin, dim3(64), dim3(64), 0, st[k], nullptr, ev[k], 0, d + (size_t)k * 64, dur[j] * 100, j);
+        else hipLaunchKernelGGL(spin, dim3(64), dim3(64), 0, st[k], d + (size_t)k * 64, dur[j] * 100, j);
+      }
+    });
+  }
   return 0;
 }
