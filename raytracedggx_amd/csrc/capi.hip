@@ -315,7 +315,7 @@ void rtggx_destroy(rtggx_context* c) {
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTrisBuf[0]); hipFree(c->largeTrisBuf[1]); hipFree(c->largeCountBase); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->rayQueueBuf[i]); hipFree(c->hitQueueBuf[i]); hipFree(c->binCountBuf[i]); }
-  hipFree(c->binWorkBuf[0]); hipFree(c->binWorkBuf[1]); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
+  for (auto b : c->binWorkBuf) hipFree(b); for (int i = 0; i < RT_SETS; ++i) hipFree(c->splitListBuf[i]);
   hipFree(c->stackOverflow); hipFree(c->testRayRange); hipFree(c->dummyRecord); hipFree(c->histReach);
   hipFree(c->dEnvMipOffset); hipFree(c->rayCounterBuf); hipFree(c->traceStamps); hipHostFree(c->hostRayCounters); hipEventDestroy(c->evRayCounters);
   for (auto& e : c->kevBegin) hipEventDestroy(e);
@@ -733,6 +733,9 @@ int rtggx_ray_trace(rtggx_context* c) {
   // who needs its results waits for its event, not for its stream; the stack spill area exists twice (launchTrace).
   // The second stream is the refit stream, idle unless a mesh deforms: a FIFTH stream would share one of the four hardware queues
   // with another one (measured: the deforming bunny went from 0.22 to 0.40 ms per frame when a fifth stream merely existed).
+  // (Round 3, with eight hardware queues configured: a THIRD traversal stream, so that three traversals are in flight, loses everywhere --
+  // 1920 x 171 0.053 -> 0.086 ms per frame, 1920 x 400 0.083 -> 0.112, the slowest of eight 1080p strips 0.083 -> 0.081 with every
+  // other strip slower: beyond four streams with work on them the queues take turns.  profiles/r03_c_strip_chain.txt)
   static const bool twoTraceStreams = !(getenv("RTGGX_TRACE_STREAMS") && atoi(getenv("RTGGX_TRACE_STREAMS")) == 1);
   const bool deforming = c->mesh[0].deforming || c->mesh[1].deforming;
   const bool alternate = twoTraceStreams && c->pipeline != 0 && c->asyncCompute && sGen != c->streamAS && c->streamRefit != nullptr && !deforming && c->lastTraceSmall && (f & 1u) != 0u;
@@ -749,17 +752,57 @@ int rtggx_ray_trace(rtggx_context* c) {
     if (syncPipe && c->pipeline != 0 && c->setReadRecorded[(c->setIndex + 2u) % RT_SETS]) RT_HIP(hipStreamWaitEvent(sTrace, c->evSetRead[(c->setIndex + 2u) % RT_SETS], 0)); }
   if (c->timing) hipEventRecord(c->tev[3], sGen);
   hipEvent_t evDone = c->evTraceRing[f & 3u];
-  int r = launchRayTrace(c, c->slots[c->slot], sGen, sTrace, evDone);
+  // Small launches: the hit shading runs on the TRAVERSAL's stream, behind the trace kernel, not on the main stream.  The main stream's
+  // chain (shading, two filters, temporal pass, tone map) is the longest stage of a thin strip's frame, and the two traversal streams
+  // alternate, so theirs may be twice as long: 1920 x 171 0.060 -> <<SHADE_B>> ms per frame (the stand-in model of
+  // tools/microbench/frame_graph.hip: 60.9 -> 49.1 us; profiles/r03_c_strip_chain.txt).  The event the main stream -- and ray generation
+  // two frames on -- waits for then rides on the shading kernel.  Full-size frames keep the shading on the main stream: there the
+  // traversal is the longest kernel of the frame and its stream has the low priority.
+  static const bool shadeBesideTrace = !(getenv("RTGGX_SHADE_WITH_TRACE") && atoi(getenv("RTGGX_SHADE_WITH_TRACE")) == 0);
+  static const uint32_t shadeRays = getenv("RTGGX_SHADE_WITH_TRACE_RAYS") ? (uint32_t)atoi(getenv("RTGGX_SHADE_WITH_TRACE_RAYS")) : RT_WIDE_RAYS;
+  const bool shadeWithTrace = shadeBesideTrace && c->pipeline != 0 && c->asyncCompute && c->attachEvents && !c->timing && sTrace != c->streamMain && sGen != sTrace && !deforming && c->lastTraceSmall
+                              && c->lastFrameRays < shadeRays;
+  // who carries RayTracingOut1 over from the previous set where this frame traces no diffuse ray (raytrace.hip launchShade)
+  static const bool genMayCarry = !(getenv("RTGGX_GEN_CARRIES_DIFF") && atoi(getenv("RTGGX_GEN_CARRIES_DIFF")) == 0);
+  { const FrameParams& fpNow = c->slots[c->slot];
+    const bool diffuseNow = fpNow.mat.RoughMetals[0][1] < 1.0f || fpNow.mat.RoughMetals[1][1] < 1.0f;
+    // back to ray generation after frames with diffuse rays: once, ray generation waits for the previous frame's shading kernel (one
+    // bubble in the pipeline), so that the previous set's image is final when it reads it
+    if (genMayCarry && c->shadeWroteDiff && !diffuseNow && !c->lastFrameDiffuse && c->shadeStream) {
+      if (c->shadeStream != sGen) { RT_HIP(hipEventRecord(c->evRT, c->shadeStream)); RT_HIP(hipStreamWaitEvent(sGen, c->evRT, 0)); }
+      c->shadeWroteDiff = false;
+    }
+    c->lastFrameDiffuse = diffuseNow; }
+  c->genCarriesDiff = genMayCarry && !c->shadeWroteDiff;
+  int r = launchRayTrace(c, c->slots[c->slot], sGen, sTrace, shadeWithTrace ? nullptr : evDone);
   c->traceRecorded[f & 3u] = true;
   c->lastRayCounter32 = c->rayCounter32;
-  // stream B runs ahead with the traversal; shading and the denoiser consume the bins, the G-buffer and the traced images on
-  // the main stream (the event completes with the trace kernel)
-  RT_HIP(hipStreamWaitEvent(c->streamMain, evDone, 0));
-  // the main stream has now been given work that reads the current input set: that set may not be overwritten (three frames
-  // from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
-  { const bool carry = c->tonePending || !c->attachEvents;      // an aside tone map (below) waits for this kernel
+  { const FrameParams& fpNow = c->slots[c->slot];
+    c->shadeWroteDiff = !c->genCarriesDiff || fpNow.mat.RoughMetals[0][1] < 1.0f || fpNow.mat.RoughMetals[1][1] < 1.0f; }
+  if (shadeWithTrace) {
+    flushToneMap(c);      // (a tone map put aside by a full-size frame before waits for a shading kernel on the MAIN stream: none comes)
+    // the shading of frame f copies what it does not trace from the image of frame f - 1 (launchShade: diffPrev), which the other
+    // traversal stream's shading kernel wrote, or the main stream's if this is the first frame shaded here
+    if (!c->genCarriesDiff && c->shadeStream && c->shadeStream != sTrace) {
+      if (c->shadeStream == c->streamMain) { RT_HIP(hipEventRecord(c->evRT, c->streamMain)); RT_HIP(hipStreamWaitEvent(sTrace, c->evRT, 0)); }
+      else if (c->traceRecorded[(f + 3u) & 3u]) RT_HIP(hipStreamWaitEvent(sTrace, c->evTraceRing[(f + 3u) & 3u], 0));
+    }
+    if (!r) r = launchShade(c, c->slots[c->slot], sTrace, evDone);
+    c->shadeStream = sTrace;
+    RT_HIP(hipStreamWaitEvent(c->streamMain, evDone, 0));
+    c->setReadDeferred = (int)c->setIndex;      // the main stream's kernels of this frame read the set after the shading: the last of them carries the set's event
+  } else {
+    // stream B runs ahead with the traversal; shading and the denoiser consume the bins, the G-buffer and the traced images on
+    // the main stream (the event completes with the trace kernel; a shading kernel of the frame before on a traversal stream has been
+    // waited for by the main stream in its own frame)
+    RT_HIP(hipStreamWaitEvent(c->streamMain, evDone, 0));
+    // the main stream has now been given work that reads the current input set: that set may not be overwritten (three frames
+    // from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
+    const bool carry = c->tonePending || !c->attachEvents;      // an aside tone map (below) waits for this kernel
     if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr);
-    if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex; }
+    c->shadeStream = c->streamMain;
+    if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex;
+  }
   if (c->tonePending) {      // the previous frame's tone map: beside this frame's filters (rtggx_tone_map)
     if (c->attachEvents && c->streamRefit != nullptr && !(c->mesh[0].deforming || c->mesh[1].deforming) && !alternate && c->streamMain == c->ownMain) {
       c->tonePending = false;

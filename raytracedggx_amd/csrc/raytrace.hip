@@ -228,6 +228,7 @@ struct GenArgs {
   unsigned long long* visNext; uint32_t* zeroNext0; uint32_t* zeroNext1;
   uint32_t* normalOut; uint16_t* roughMetalOut; uint32_t* velocityOut; uint32_t* reflOut; uint32_t* diffOut;
   const uint16_t* roughMetalPrev;   // the previous frame's input set = what this target held before this frame
+  const uint32_t* diffPrev;         // likewise RayTracingOut1, or null: the hit shading carries it over (launchShade)
   const float4* fat0; const float4* fat1;
   const uint2* env; const uint32_t* envMipOffset; uint32_t envSize, envMips;
   const float* cosSin;
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
     A.normalOut[pix] = packR10G10B10A2(N.x * 0.5f + 0.5f, N.y * 0.5f + 0.5f, N.z * 0.5f + 0.5f, hit ? 1.0f : 0.0f);
     // the reference leaves RoughMetal untouched where nothing is hit, and RayTracingOut1 where no diffuse ray is traced:
     // with several input sets "untouched" means carrying the word of the previous frame's set over.  RoughMetal is carried here
-    // (the previous set's was written by the previous ray generation, earlier on this stream); RayTracingOut1 by shadeKernel
+    // (the previous set's was written by the previous ray generation, earlier on this stream); RayTracingOut1 below or by shadeKernel
     A.roughMetalOut[pix] = hit ? (uint16_t)packR8G8(rghMtl.x, rghMtl.y) : A.roughMetalPrev[pix];
     A.velocityOut[pix] = packR16G16F(velocity.x, velocity.y);
 
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
         rd.dx = dir.x; rd.dy = dir.y; rd.dz = dir.z;
         rd.pixel = (uint32_t)pix; rd.skip = skip; rd.flags = 1u;
         rd.wx = color.x * (1.0f - 0.04f); rd.wy = color.y * (1.0f - 0.04f); rd.wz = color.z * (1.0f - 0.04f);   // :532
-      }      // else: RayTracingOut1 keeps what it held -- carried over from the previous frame's set by shadeKernel (see there)
+      } else if (A.diffPrev != nullptr) A.diffOut[pix] = A.diffPrev[pix];      // RayTracingOut1 keeps what it held: carried over from the previous frame's set, here or by shadeKernel (launchShade)
     }
   }
   // wave-level compaction into this wave's own bin (rt_queue.h): reflection rays first, then diffuse rays
@@ -511,6 +512,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
     c->visClearedFor = G.visNext; c->visClearedRows[0] = rb; c->visClearedRows[1] = re; }
   G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
+  G.diffPrev = c->genCarriesDiff ? c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS] : nullptr;
   G.fat0 = c->mesh[0].fat; G.fat1 = c->mesh[1].fat;
   G.env = c->env.texels; G.envMipOffset = c->dEnvMipOffset; G.envSize = c->env.size; G.envMips = c->env.mips; G.cosSin = c->cosSinTab;
   G.rays = (RayRec*)c->rayQueue; G.hits = (HitKey*)c->hitQueue; G.binCount = c->binCount; G.binSlots = c->binSlots; G.frameRays = c->rayCounter32;
@@ -558,6 +560,11 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
   ShadeArgs S;
   S.diffPrev = c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS]; S.visDepth = c->visDepth; S.tilesX = tilesX; S.rowBegin = rb; S.rowEnd = re;
   S.carryMask = (fp.mat.RoughMetals[0][1] >= 1.0f ? 1u : 0u) | (fp.mat.RoughMetals[1][1] >= 1.0f ? 2u : 0u);      // rghMtl.y < 1 is the test of :559; it is the instance's constant
+  // ... unless ray generation has carried those pixels over already.  It can when the previous frame's shading kernel wrote nothing
+  // into the previous set's image (no diffuse rays, no carrying): that image was final when the previous ray generation ended, earlier
+  // on the same stream.  The steady state of an all-metal scene: 8 bytes per covered pixel less (this loop reads the visibility word
+  // again), and no dependency between the shading kernels of consecutive frames (capi.hip rtggx_ray_trace).
+  if (c->genCarriesDiff) S.carryMask = 0u;
   S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitKey*)c->hitQueue; S.binCount = c->binCount; S.binSlots = c->binSlots;
   S.fat0 = c->mesh[0].fat; S.fat1 = c->mesh[1].fat;
   S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;

@@ -250,6 +250,10 @@ struct rtggx_context {
   void* dummyRecord = nullptr;          // 128 zero bytes: record base for meshes without nodes / absent meshes
   uint32_t* dEnvMipOffset = nullptr;    // device copy of env.mipOffset
   bool lastTraceSmall = false; uint32_t traceSpillHalf = 0;
+  hipStream_t shadeStream = nullptr;     // the stream the most recent hit shading ran on (capi.hip rtggx_ray_trace: the main stream, or the traversal's for small launches)
+  // RayTracingOut1 keeps what it held where no diffuse ray is traced: with several input sets, carried over from the previous set -- by ray
+  // generation when the previous frame's shading kernel wrote nothing into that set (genCarriesDiff), else by the shading kernel (raytrace.hip)
+  bool genCarriesDiff = false, shadeWroteDiff = false, lastFrameDiffuse = false;
   uint32_t numCUs = 256;
   // the trace kernel's workgroup size (full-size launches) and the time stamps it takes of itself (trace.hip): stamps = 3 x (start, end) + (sum of durations, latest start)
   uint32_t traceWaves = 12, traceWavesForced = 0; float traceShare = 0.0f; unsigned long long* traceStamps = nullptr; uint32_t traceStampLaunch = 0;

@@ -25,7 +25,9 @@ comm = rccl.Communicator(None, 0, 1)
 scratch = torch.empty(W * H * 8, dtype=torch.uint8, device="cuda")      # stands in for the peers' buffers
 print("%dx%d, bunny, %d frames per measurement; ms per frame" % (W, H, FRAMES), flush=True)
 base = None
-for N in (1, 2, 4, 8):
+NS = tuple(int(x) for x in os.environ.get("PROJ_NS", "1,2,4,8").split(","))                    # e.g. PROJ_NS=8 PROJ_MODES=compute for an A/B
+MODES = tuple(os.environ.get("PROJ_MODES", "compute,+rccl,+beside").split(","))
+for N in NS:
     bounds = None
     if N > 1:
         p = StripRenderer(W, H, mesh, env, rank=0, world=N, transport=lambda *_: None, extra_args=("-sharedmem",), balance=True)
@@ -46,8 +48,8 @@ for N in (1, 2, 4, 8):
                 off += (nbytes + 255) // 256 * 256
             comm.exchange(ops, renderer.xstream.cuda_stream)
 
-        res = {}
-        for mode in ("compute", "+rccl", "+beside"):
+        res = {m: float("nan") for m in ("compute", "+rccl", "+beside")}
+        for mode in MODES:
             transport = (lambda *_: None) if (mode == "compute" or N == 1) else self_exchange
             s = StripRenderer(W, H, mesh, env, rank=r, world=N, transport=transport if N > 1 else None, torch_buffers=N > 1, extra_args=("-sharedmem",), balance=bounds if N > 1 else False,
                               overlap_exchange=mode == "+beside")
