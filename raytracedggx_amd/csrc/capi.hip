@@ -754,7 +754,7 @@ int rtggx_ray_trace(rtggx_context* c) {
   hipEvent_t evDone = c->evTraceRing[f & 3u];
   // Small launches: the hit shading runs on the TRAVERSAL's stream, behind the trace kernel, not on the main stream.  The main stream's
   // chain (shading, two filters, temporal pass, tone map) is the longest stage of a thin strip's frame, and the two traversal streams
-  // alternate, so theirs may be twice as long: 1920 x 171 0.060 -> <<SHADE_B>> ms per frame (the stand-in model of
+  // alternate, so theirs may be twice as long: 1920 x 171 0.060 -> 0.052 ms per frame (the stand-in model of
   // tools/microbench/frame_graph.hip: 60.9 -> 49.1 us; profiles/r03_c_strip_chain.txt).  The event the main stream -- and ray generation
   // two frames on -- waits for then rides on the shading kernel.  Full-size frames keep the shading on the main stream: there the
   // traversal is the longest kernel of the frame and its stream has the low priority.
