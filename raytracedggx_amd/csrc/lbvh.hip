@@ -212,7 +212,15 @@ __global__ void fitKernel(int n, const uint32_t* __restrict__ order, const float
 #define RT_PLOC_RADIUS 16
 #define RT_MAX_ROUNDS 1024
 #define RT_TREELET_NODES 1024
-struct PlocState { uint32_t m, nodeBase, rounds, pad; };
+// plocFinal's LDS holds RT_PLOC_LDS clusters (44 bytes each: 135 KB of the 160 KB a gfx950 workgroup may have).  The multi-workgroup rounds
+// before it stop by themselves once RT_PLOC_STOP clusters are left: the host issues rounds as if every round kept RT_PLOC_KEEP of its
+// clusters, and a round that finds the list short enough returns at once and hands the state on.  Measured (profiles/r03_g_build.txt):
+// a round in LDS costs ~6 us at 3000 clusters and ~2 at 1000, a multi-workgroup round ~13 us of kernels + two launch gaps, a round of ONE
+// workgroup on the lists in global memory ~90 us -- so the list should reach plocFinal below its LDS capacity, but not far below.
+#define RT_PLOC_LDS 3072
+#define RT_PLOC_STOP 2048
+#define RT_PLOC_KEEP 0.80
+struct PlocState { uint32_t m, nodeBase, rounds, buf; };      // clusters left, next node index, rounds done, which of the two cluster lists holds them
 struct PlocArrays {      // what a round reads and writes (by value to the kernels)
   int32_t* clRef[2]; float* clBox[2]; int32_t* nn;
   int32_t *left, *right, *nodeParent, *leafParent; float* nodeBox; uint32_t* cnt[RT_TREELET_LEVELS];
@@ -225,7 +233,7 @@ RT_DEV float mergedArea(const float* a, const float* b) {
 // first kernel of a build: the device records start clean
 __global__ void buildBegin(uint32_t n, PlocState* state, BuildResult* res, uint32_t* bounds) {
   if (threadIdx.x == 0) {
-    state[0].m = n; state[0].nodeBase = 0u; state[0].rounds = 0u; state[0].pad = 0u; state[1] = state[0];
+    state[0].m = n; state[0].nodeBase = 0u; state[0].rounds = 0u; state[0].buf = 0u; state[1] = state[0];
     BuildResult z{}; *res = z;
     for (int k = 0; k < 3; ++k) { bounds[k] = 0xFFFFFFFFu; bounds[3 + k] = 0u; }
   }
@@ -282,10 +290,11 @@ __global__ void __launch_bounds__(256 * RT_PLOC_LANES) plocNearest(const PlocSta
   __shared__ float box[6][256 + 2 * RT_PLOC_APRON];
   __shared__ int32_t nnS[256 + 2 * RT_PLOC_RADIUS];
   __shared__ uint32_t wk[4], wm[4];
-  const int m = (int)state[r & 1u].m;
-  if (m <= 1 || (int)(blockIdx.x * 256) >= m) return;
+  const PlocState st = state[r & 1u];
+  const int m = (int)st.m;
+  if (m <= RT_PLOC_STOP || (int)(blockIdx.x * 256) >= m) return;      // (a list this short is left to plocFinal: this round is skipped)
   if (radius > RT_PLOC_RADIUS) radius = RT_PLOC_RADIUS;
-  const float* __restrict__ clBox = A.clBox[r & 1u];
+  const float* __restrict__ clBox = A.clBox[st.buf];
   const int b0 = (int)(blockIdx.x * 256), lo = b0 - RT_PLOC_APRON;      // LDS entry e holds position lo + e
   for (int e = threadIdx.x; e < 256 + 2 * RT_PLOC_APRON; e += 256 * RT_PLOC_LANES) {
     const int pos = lo + e;
@@ -349,7 +358,7 @@ RT_DEV void plocEmit(int i, int j, bool mutual, uint32_t p, int node, const int3
 __global__ void __launch_bounds__(256) plocScatter(PlocState* __restrict__ state, uint32_t r, const uint2* __restrict__ blockCounts, PlocArrays A) {
   const PlocState st = state[r & 1u];
   const int m = (int)st.m;
-  if (m <= 1) { if (blockIdx.x == 0 && threadIdx.x == 0) state[(r + 1u) & 1u] = st; return; }      // done: the state is handed on as it is
+  if (m <= RT_PLOC_STOP) { if (blockIdx.x == 0 && threadIdx.x == 0) state[(r + 1u) & 1u] = st; return; }      // skipped (plocNearest): the state is handed on as it is
   const uint32_t nblocks = ((uint32_t)m + 255u) / 256u;
   if (blockIdx.x >= nblocks) return;
   // kept positions / merges in the workgroups before this one
@@ -367,10 +376,10 @@ __global__ void __launch_bounds__(256) plocScatter(PlocState* __restrict__ state
   const uint32_t baseK = redK[0] + redK[1] + redK[2] + redK[3], baseM = redM[0] + redM[1] + redM[2] + redM[3];
   uint32_t rk = (uint32_t)__popcll(bk & below), rm = (uint32_t)__popcll(bm & below);
   for (uint32_t w = 0; w < wave; ++w) { rk += wk[w]; rm += wm[w]; }
-  if (keep) plocEmit(i, j, mutual, baseK + rk, (int)(st.nodeBase + baseM + rm), A.clRef[r & 1u], A.clBox[r & 1u], A.clRef[(r + 1u) & 1u], A.clBox[(r + 1u) & 1u], A);
+  if (keep) plocEmit(i, j, mutual, baseK + rk, (int)(st.nodeBase + baseM + rm), A.clRef[st.buf], A.clBox[st.buf], A.clRef[st.buf ^ 1u], A.clBox[st.buf ^ 1u], A);
   if (blockIdx.x == nblocks - 1u && threadIdx.x == 0) {      // the last workgroup knows the totals
     PlocState nx;
-    nx.m = baseK + wk[0] + wk[1] + wk[2] + wk[3]; nx.nodeBase = st.nodeBase + baseM + wm[0] + wm[1] + wm[2] + wm[3]; nx.rounds = st.rounds + 1u; nx.pad = 0u;
+    nx.m = baseK + wk[0] + wk[1] + wk[2] + wk[3]; nx.nodeBase = st.nodeBase + baseM + wm[0] + wm[1] + wm[2] + wm[3]; nx.rounds = st.rounds + 1u; nx.buf = st.buf ^ 1u;
     if (st.rounds < RT_MAX_ROUNDS) A.roundBase[st.rounds] = st.nodeBase; else atomicOr(&A.res->error, 1u);
     state[(r + 1u) & 1u] = nx;
   }
@@ -381,7 +390,6 @@ __global__ void __launch_bounds__(256) plocScatter(PlocState* __restrict__ state
 // reference, box, subtree counts -- live in LDS: the tail of the clustering is ~40 rounds that merge a handful of pairs each, and
 // from global memory a round of ONE workgroup is a chain of L2 round trips (9.5 us per round, 360 us for the bunny: a quarter of its
 // build; in LDS 1 us).  A round compacts the list in place: every thread first reads what it needs into registers, then writes.
-#define RT_PLOC_LDS 2048
 struct PlocLds {
   int32_t ref[RT_PLOC_LDS]; float box[6][RT_PLOC_LDS]; uint32_t cnt[RT_TREELET_LEVELS][RT_PLOC_LDS]; int32_t nn[RT_PLOC_LDS];
   uint32_t wk[16], wm[16];
@@ -389,7 +397,7 @@ struct PlocLds {
 __global__ void __launch_bounds__(1024) plocFinal(const PlocState* __restrict__ state, uint32_t r, int radius, uint32_t n, PlocArrays A) {
   __shared__ PlocLds L;
   const PlocState st = state[r & 1u];
-  uint32_t m = st.m, nodeBase = st.nodeBase, rounds = st.rounds, p = r & 1u;
+  uint32_t m = st.m, nodeBase = st.nodeBase, rounds = st.rounds, p = st.buf;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
   while (m > RT_PLOC_LDS) {      // (only when the rounds before merged less than expected)
@@ -891,13 +899,15 @@ static int allocScratch(BuildScratch& s, uint32_t n, uint32_t nv, bool snapshot)
   if (snapshot) RT_HIP(hipMalloc(&s.vertsSnapshot, sizeof(float) * 6 * (size_t)nv));
   return 0;
 }
-// How many multi-workgroup rounds the host issues: until RT_PLOC_LDS clusters are expected to be left, at the ~0.77 of its clusters a
-// round keeps (bunny: 69 666 -> 6 252 in nine rounds, dragon: 100 000 -> 14 319 in ten; RTGGX_BUILD_LOG), plus one.  A round that keeps
-// more only leaves plocFinal more to do: it starts on the lists in global memory.
+// How many multi-workgroup rounds the host issues: until RT_PLOC_STOP clusters are expected to be left if every round kept RT_PLOC_KEEP of
+// its clusters (measured, RTGGX_BUILD_LOG: the bunny keeps ~0.77 per round, the dragon ~0.835).  A round that is not needed returns at
+// once (plocNearest); a mesh that keeps more reaches plocFinal with more clusters -- up to RT_PLOC_LDS of them go straight into LDS,
+// beyond that it starts with rounds on the lists in global memory.  (Round 3's first version budgeted for 0.77 + one round and 2048
+// clusters in LDS: the dragon's plocFinal then started with 5523 clusters and took 481 us of the build's 881.)
 static uint32_t plocRoundsFor(uint32_t n) {
   uint32_t rounds = 0; double m = (double)n;
-  while (m > (double)RT_PLOC_LDS) { m *= 0.77; ++rounds; }
-  return rounds ? rounds + 1u : 0u;
+  while (m > (double)RT_PLOC_STOP) { m *= RT_PLOC_KEEP; ++rounds; }
+  return rounds;
 }
 
 // The launches of one build of mesh `slot` from `verts` (device; the job's snapshot when `snapshotFrom` is given), into job.topo.
