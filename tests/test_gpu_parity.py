@@ -957,6 +957,37 @@ def test_small_frames_two_traversals_in_flight_equal_synchronised(built):
             a.OnDestroy(); b.OnDestroy()
 
 
+def test_diffuse_image_carry_hands_over_between_ray_generation_and_shading(built):
+    """RayTracingOut1 keeps what it held where no diffuse ray is traced; with several input sets that is a carry-over from the previous set,
+    done by ray generation while the previous frame's shading kernel wrote nothing into that set and by the shading kernel otherwise
+    (capi.hip rtggx_ray_trace: genCarriesDiff / shadeWroteDiff).  Metal -> diffuse -> metal again, with the camera turning (pixels change
+    from sky to covered and back): every frame against the oracle, which has ONE such image -- and the same schedule free-running against
+    synchronised at a size that shades on the traversal's streams (640x360) and at one that shades on the main stream (1920x1080)."""
+    from raytracedggx_amd import app, capi
+    schedule = {3: 0.5, 5: 1.0, 9: 0.25, 10: 1.0}      # frame -> metallic of the ground from that frame on
+    p = Pair(320, 180)
+    try:
+        for f in range(13):
+            if f in schedule: p.ctx.set_metallic(0, schedule[f]); p.o.set_metallic(0, schedule[f])
+            p.frame()
+            p.check_frame("carry frame %d" % f)
+    finally:
+        p.close()
+    for size in ((640, 360), (1920, 1080)):
+        args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", size[0], "-height", size[1], "-sharedmem", "-dt", 0.05]
+        a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+        try:
+            for f in range(16):
+                if f in schedule: a.context.set_metallic(0, schedule[f]); b.context.set_metallic(0, schedule[f])
+                a.OnUpdate(); a.OnRender(); a.context.sync()
+                b.OnUpdate(); b.OnRender()
+            b.context.sync()
+            for bid in (capi.BUF_ROUGH_METAL, capi.BUF_RT_REFL, capi.BUF_RT_DIFF, capi.BUF_FLT_RFL, capi.BUF_FLT_DFF, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_BACKBUFFER):
+                np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="%dx%d buffer %d" % (size + (bid,)))
+        finally:
+            a.OnDestroy(); b.OnDestroy()
+
+
 def test_trace_workgroup_size_changes_nothing(built):
     """The traversal's resident workgroup has 12 waves, or 14 / 16 when a trial says so (trace.hip steerTraceWaves); launches with few
     rays use single-wave workgroups.  rtggx_debug_trace_residency pins the size: five frames of the turning dragon with diffuse rays at
