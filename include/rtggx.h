@@ -219,6 +219,11 @@ int  rtggx_tone_map(rtggx_context* ctx);
  * subtrees of up to that many triangles become one entry of their (grand)parent node -- fewer node visits per ray, more triangle
  * tests per leaf visit (measured: profiles/r03_e_multi_leaf.txt).  Results do not depend on it. */
 int  rtggx_debug_leaf_tris(rtggx_context* ctx, uint32_t leaf_tris);
+/* Diagnostic: put the tone map of full-size static frames aside and launch it beside the NEXT frame's filters, on the refit stream
+ * (round 2's arrangement; 1) or keep it at the end of the main stream's chain (0; the default since round 3, or RTGGX_TONEMAP_ASIDE).
+ * Measured neutral to slightly slower in round 3's pipeline and the wider of the two in run-to-run spread.
+ * Results do not depend on it. */
+int  rtggx_debug_tone_map_aside(rtggx_context* ctx, int on);
 
 int  rtggx_sync(rtggx_context* ctx);
 /* Number of non-degenerate rays (TMax > TMin) traced by the last rtggx_ray_trace; synchronises. */

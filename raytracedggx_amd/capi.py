@@ -30,7 +30,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream", "rtggx_get_exchange_stream", "rtggx_exchange_begin", "rtggx_exchange_end",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_leaf_tris", "rtggx_debug_shader_clock"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_leaf_tris", "rtggx_debug_tone_map_aside", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -165,6 +165,10 @@ class Context:
     def leaf_tris(self, n):
         """Triangles per leaf of the 4-wide trees of later builds (diagnostic)."""
         self._check(self.L.rtggx_debug_leaf_tris(self.h, n))
+
+    def tone_map_aside(self, on):
+        """The tone map of full-size static frames beside the next frame's filters (diagnostic; off by default)."""
+        self._check(self.L.rtggx_debug_tone_map_aside(self.h, 1 if on else 0))
 
     def set_sampler(self, vndf):
         self._check(self.L.rtggx_set_sampler(self.h, 1 if vndf else 0))

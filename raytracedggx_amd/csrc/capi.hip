@@ -89,8 +89,7 @@ static void flushToneMap(rtggx_context* c) {
 }
 // Would rtggx_tone_map put this frame's tone map aside (see there)?  Everything but "the denoiser ran this frame".
 static bool toneAsideEligible(const rtggx_context* c, const FrameParams& fp) {
-  static const bool toneAside = !(getenv("RTGGX_TONEMAP_ASIDE") && atoi(getenv("RTGGX_TONEMAP_ASIDE")) == 0);
-  return toneAside && !c->callerOrdersOnMain && c->toneAsideAllowed && c->pipeline != 0 && c->asyncCompute && c->attachEvents && c->streamMain == c->ownMain && c->streamRefit != nullptr && !c->timing
+  return c->toneAside && !c->callerOrdersOnMain && c->toneAsideAllowed && c->pipeline != 0 && c->asyncCompute && c->attachEvents && c->streamMain == c->ownMain && c->streamRefit != nullptr && !c->timing
          && !(c->mesh[0].deforming || c->mesh[1].deforming) && !c->lastTraceSmall && fp.rowBegin == 0u && fp.rowEnd == fp.H
          && (uint64_t)fp.W * fp.H <= RT_TONE_ASIDE_PIXELS;
 }
@@ -218,6 +217,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   { const int pr = getenv("RTGGX_PRIORITY_R") ? atoi(getenv("RTGGX_PRIORITY_R")) : 1;      // stream R: 0 low, 1 mid, 2 high
     RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, pr == 0 ? prioLeast : pr == 2 ? prioGreatest : prioMid)); }
   c->pipeline = getenv("RTGGX_PIPELINE") ? atoi(getenv("RTGGX_PIPELINE")) : 1;
+  c->toneAside = getenv("RTGGX_TONEMAP_ASIDE") && atoi(getenv("RTGGX_TONEMAP_ASIDE")) != 0;      // rtggx_tone_map; rtggx_debug_tone_map_aside
   c->rebuildRatio = getenv("RTGGX_REBUILD_RATIO") ? (float)atof(getenv("RTGGX_REBUILD_RATIO")) : RT_REFIT_REBUILD_RATIO;
   c->rebuildSteps = getenv("RTGGX_REBUILD_STEPS") ? (uint32_t)atoi(getenv("RTGGX_REBUILD_STEPS")) : RT_REBUILD_STEPS;
   { const int lt = getenv("RTGGX_LEAF_TRIS") ? atoi(getenv("RTGGX_LEAF_TRIS")) : 1; c->leafTris = lt < 1 ? 1u : lt > 4 ? 4u : (uint32_t)lt; }
@@ -835,7 +835,9 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
 int rtggx_tone_map(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_tone_map: no frame constants"); return -1; }
-  // The tone map of a full-size frame does not run at the end of the main stream's chain (shading, filters, temporal pass: the chain
+  // OPT-IN since round 3 (rtggx_debug_tone_map_aside / RTGGX_TONEMAP_ASIDE=1; with the shorter shading kernel it measures neutral at best
+  // and widens the run-to-run spread: DESIGN.md section 5).  When on:
+  // the tone map of a full-size frame does not run at the end of the main stream's chain (shading, filters, temporal pass: the chain
   // the frame waits for) but beside the NEXT frame's filters, on the refit stream: it needs the temporal pass's result only, moves
   // many bytes with little arithmetic, and the horizontal filter it then overlaps does the opposite.  It is prepared here and
   // launched by the next rtggx_ray_trace behind that frame's shading kernel (waitable: the kernel carries evSetRead); whoever
@@ -893,6 +895,12 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
 }
 
 // Triangles per leaf of the 4-wide trees built from now on (lbvh.hip emitNodes4 "multi-leaves"): 1 (every leaf one triangle), 2 or 4.
+int rtggx_debug_tone_map_aside(rtggx_context* c, int on) {
+  RT_CHECK_CTX(c);
+  flushToneMap(c);
+  c->toneAside = on != 0;
+  return 0;
+}
 int rtggx_debug_leaf_tris(rtggx_context* c, uint32_t leafTris) {
   RT_CHECK_CTX(c);
   if (leafTris < 1u || leafTris > 4u) { setError("rtggx_debug_leaf_tris: 1 .. 4"); return -1; }

@@ -1031,6 +1031,7 @@ def test_tone_map_beside_the_next_frame_equals_the_one_on_the_main_stream(built)
     args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 1920, "-height", 1080, "-sharedmem"]
     a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
     try:
+        b.context.tone_map_aside(True)      # (off by default since round 3: rtggx_debug_tone_map_aside)
         for f in range(12):
             a.OnUpdate(); a.OnRender(); a.context.sync()
             b.OnUpdate(); b.OnRender()
