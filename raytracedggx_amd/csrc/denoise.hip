@@ -445,7 +445,9 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
 // pixel, so a wave's life is its launch plus that round trip -- four pixels per thread put four times the bytes in flight per wave
 // and take a quarter of the waves (64 x 4 blocks: 32 400 waves, 37 M wave quad-cycles per frame; profiles/r02_d_limiter.txt), and
 // the one-texel apron costs 1.16 x instead of 1.55 x.
+#ifndef RT_TM_ROWS
 #define RT_TM_ROWS 16
+#endif
 __global__ void __launch_bounds__(256) toneMapKernel(Targets T) {
 #pragma clang fp contract(fast)
   __shared__ float4 tile[RT_TM_ROWS + 2][66];          // c / (c + 0.5) of the block's pixels and a one-texel apron, computed once per texel
