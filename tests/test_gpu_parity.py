@@ -1055,6 +1055,28 @@ def test_tone_map_beside_the_next_frame_equals_the_one_on_the_main_stream(built)
         a.OnDestroy(); b.OnDestroy()
 
 
+def test_tone_map_aside_toggled_in_the_middle_of_a_run(built):
+    """rtggx_debug_tone_map_aside may be switched at any frame boundary: a pending aside tone map is flushed onto the main stream, later
+    frames follow the new setting.  24 free-running 1080p frames with the switch flipped every third frame against 24 synchronised
+    frames that never used it; and rtggx_copy_bandwidth (the bench line's measured peak) leaves a context as it found it."""
+    from raytracedggx_amd import app, capi
+    args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 1920, "-height", 1080, "-sharedmem"]
+    a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+    try:
+        for f in range(24):
+            if f % 3 == 0: b.context.tone_map_aside((f // 3) % 2 == 0)
+            if f == 12:
+                gbs = b.context.copy_bandwidth(1 << 28, 2)
+                assert 500.0 < gbs < 8000.0, gbs      # read + written bytes per second of a device-to-device copy: below the 8 TB/s of the HBM
+            a.OnUpdate(); a.OnRender(); a.context.sync()
+            b.OnUpdate(); b.OnRender()
+        b.context.sync()
+        for bid in (capi.BUF_BACKBUFFER, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_FLT_DFF, capi.BUF_RT_REFL):
+            np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="buffer %d" % bid)
+    finally:
+        a.OnDestroy(); b.OnDestroy()
+
+
 def test_update_as_after_render_visibility(built):
     """The C ABI allows rtggx_update_as after rtggx_render_visibility of the same frame (the sample overlaps the two on its two
     queues, RayTracedGGX.cpp:304-339): the visibility pass has then carried the slot to the device with the previous frame's TLAS,

@@ -50,6 +50,17 @@ def test_product_fails_loudly_without_gpu(built):
         app.RayTracedGGX(["-mesh", assets.path("triangle.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 64, "-height", 64])
 
 
+def test_package_asks_for_eight_hardware_queues_before_the_runtime_starts():
+    """The frame runs on four HIP streams, RCCL and the strip exchange bring more; with HIP's default of four hardware queues a fifth
+    stream shares one (slowest of eight strips 0.137 ms instead of 0.077; profiles/r03_h_strip_projection.txt).  Importing the package sets
+    GPU_MAX_HW_QUEUES=8 unless the caller has chosen a value -- in a fresh interpreter, where nothing has initialised the runtime yet."""
+    import subprocess, sys
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import raytracedggx_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, check=True).stdout.strip() == "8"
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '6'; import raytracedggx_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, check=True).stdout.strip() == "6"
+
+
 def test_host_obj_importer_matches_golden_and_oracle(built):
     from raytracedggx_amd import app
     facts = json.load(open(os.path.join(ROOT, "tests", "golden", "obj_import.json")))
