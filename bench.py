@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--deform", type=float, default=0.0, help="amplitude of the breathing-model animation (-deform): new vertices and an asynchronous BVH refit every frame")
     ap.add_argument("--trace-waves", type=int, default=0, help="pin the size of the traversal's resident workgroup (10, 12, 14, 16) instead of letting the library steer it (measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
     ap.add_argument("--prime-frames", type=int, default=256, help="frames rendered during SET-UP, before the warm-up steps: the GPU's compute clock ramps for "
                     "30-50 ms after any idle period (profiles/r02_b_clock_ramp.txt), and the renderer's adaptive state settles over its first frames; 0 = none")
     ap.add_argument("--no-balance", action="store_true", help="N > 1: equal strips instead of strips balanced by covered pixels")
