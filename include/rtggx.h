@@ -150,7 +150,10 @@ int  rtggx_get_stream(rtggx_context* ctx, void** hip_stream);
  * begin orders that stream behind frame f's last kernel, end marks where the exchange ends; the TEMPORAL pass of frame f + 1 waits for it
  * (and with it everything that could touch the rows exchanged: that frame's tone map, the next H pass).  The exchange may read and write
  * TemporalSSOut[parity of f] and the back buffer.  (The frame's other consumers keep using rtggx_get_stream.  The library then runs five
- * streams: export GPU_MAX_HW_QUEUES=8 before the process touches HIP, or two of them share a hardware queue.) */
+ * streams: export GPU_MAX_HW_QUEUES=8 before the process touches HIP, or two of them share a hardware queue.  Measured on one GPU with
+ * every rank's real RCCL group it is SLOWER than the exchange on the main stream at 1080p and at 4K -- a fifth stream with work on it
+ * costs more than the overlap brings, profiles/r03_h_strip_projection.txt -- so strips.py and host/Strips.cpp keep the exchange on the
+ * main stream unless asked: RTGGX_EXCHANGE_BESIDE=1.) */
 int  rtggx_get_exchange_stream(rtggx_context* ctx, void** stream);
 int  rtggx_exchange_begin(rtggx_context* ctx);
 int  rtggx_exchange_end(rtggx_context* ctx);
