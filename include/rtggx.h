@@ -227,6 +227,10 @@ int  rtggx_debug_leaf_tris(rtggx_context* ctx, uint32_t leaf_tris);
  * Measured neutral to slightly slower in round 3's pipeline and the wider of the two in run-to-run spread.
  * Results do not depend on it. */
 int  rtggx_debug_tone_map_aside(rtggx_context* ctx, int on);
+/* Diagnostic: the host time (us) rtggx_render_visibility has spent WAITING at the frames-in-flight fence -- for the last reader of the
+ * input set it is about to overwrite, four frames back (RayTracedGGX.cpp:672-701) -- and how many frames had to wait, since the last reset.
+ * A frame loop that is bound by the GPU waits there every frame; one that is bound by its own submission never does. */
+int  rtggx_debug_fence_wait(rtggx_context* ctx, double* us_total, uint32_t* waits, int reset);
 
 int  rtggx_sync(rtggx_context* ctx);
 /* Number of non-degenerate rays (TMax > TMin) traced by the last rtggx_ray_trace; synchronises. */

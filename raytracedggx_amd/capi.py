@@ -30,7 +30,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream", "rtggx_get_exchange_stream", "rtggx_exchange_begin", "rtggx_exchange_end",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_leaf_tris", "rtggx_debug_tone_map_aside", "rtggx_debug_shader_clock"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_leaf_tris", "rtggx_debug_tone_map_aside", "rtggx_debug_fence_wait", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -165,6 +165,13 @@ class Context:
     def leaf_tris(self, n):
         """Triangles per leaf of the 4-wide trees of later builds (diagnostic)."""
         self._check(self.L.rtggx_debug_leaf_tris(self.h, n))
+
+    def fence_wait(self, reset=True):
+        """(us the host has waited at the frames-in-flight fence, frames that waited) since the last reset (diagnostic)."""
+        us, n = C.c_double(0.0), C.c_uint32(0)
+        self.L.rtggx_debug_fence_wait.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_int]
+        self._check(self.L.rtggx_debug_fence_wait(self.h, C.byref(us), C.byref(n), 1 if reset else 0))
+        return us.value, n.value
 
     def tone_map_aside(self, on):
         """The tone map of full-size static frames beside the next frame's filters (diagnostic; off by default)."""

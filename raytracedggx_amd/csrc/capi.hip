@@ -7,6 +7,7 @@
 #include <cmath>
 #include <vector>
 #include "rtggx_context.h"
+#include <chrono>
 #include "rt_queue.h"
 
 #ifndef RT_REFIT_REBUILD_RATIO
@@ -681,7 +682,11 @@ int rtggx_render_visibility(rtggx_context* c) {
   c->selectSet((c->setIndex + 1u) % RT_SETS);
   // the set was last read three frames ago: normally long done; a host that has run further ahead than that waits here (also what makes
   // it safe for this frame's ray generation to clear the NEXT frame's visibility target: rtggx_context.h RT_VIS_RING)
-  if (c->setReadRecorded[c->setIndex] && hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
+  if (c->setReadRecorded[c->setIndex] && hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) {
+    const auto t0 = std::chrono::steady_clock::now();
+    RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
+    c->fenceWaitUs += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++c->fenceWaits;      // rtggx_debug_fence_wait
+  }
   c->refitIssued = false;
   { const int r = issuePendingRefits(c, &c->refitIssued); if (r) return r; }
   if (c->refitIssued && c->asyncCompute) RT_HIP(hipEventRecord(c->evRefit, c->streamRefit));
@@ -895,6 +900,13 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
 }
 
 // Triangles per leaf of the 4-wide trees built from now on (lbvh.hip emitNodes4 "multi-leaves"): 1 (every leaf one triangle), 2 or 4.
+int rtggx_debug_fence_wait(rtggx_context* c, double* usTotal, uint32_t* waits, int reset) {
+  RT_CHECK_CTX(c);
+  if (usTotal) *usTotal = c->fenceWaitUs;
+  if (waits) *waits = c->fenceWaits;
+  if (reset) { c->fenceWaitUs = 0.0; c->fenceWaits = 0u; }
+  return 0;
+}
 int rtggx_debug_tone_map_aside(rtggx_context* c, int on) {
   RT_CHECK_CTX(c);
   flushToneMap(c);

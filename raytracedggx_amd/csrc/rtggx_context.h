@@ -180,6 +180,7 @@ struct rtggx_context {
   hipStream_t streamExchange = nullptr; hipEvent_t evExchange = nullptr, evFrameEnd = nullptr; bool exchangePending = false; int lastFrameSet = -1;
   int setReadDeferred = -1;      // the set whose event is still to ride on a later kernel of this frame (capi.hip settleSetRead)
   // a tone map that waits to be launched beside the NEXT frame's filters (capi.hip rtggx_tone_map), and the events of those launched that way
+  double fenceWaitUs = 0.0; uint32_t fenceWaits = 0;      // host time spent waiting at the frames-in-flight fence (rtggx_render_visibility; rtggx_debug_fence_wait)
   bool toneAside = false;        // off by default since round 3 (rtggx_debug_tone_map_aside, RTGGX_TONEMAP_ASIDE=1)
   bool tonePending = false, denoiseIssued = false, callerOrdersOnMain = false, toneAsideAllowed = true; rt::PreparedToneMap tonePrepared; uint32_t toneParity = 0;
   hipEvent_t evTone[2] = {}; bool toneRecorded[2] = {}; uint32_t toneAsideCount = 0, toneBesideCount = 0;
