@@ -687,6 +687,25 @@ int rtggx_render_visibility(rtggx_context* c) {
     RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
     c->fenceWaitUs += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++c->fenceWaits;      // rtggx_debug_fence_wait
   }
+  // A mesh that deforms on a full-size frame: THREE frames in flight, not four -- the host also waits for the end of frame f - 3.  With four,
+  // the stages in front (refit, visibility, ray generation, traversal) run ahead of the main stream as far as the sets allow, and the
+  // pipeline settles, whenever it fills, into one of two states: the deforming bunny at 1080p 0.212-0.219 ms per frame or 0.26-0.30, in
+  // 50-frame windows -8 / +29 % around a mean of 0.231; the deforming dragon 0.25-0.34 at 1080p.  With three there is one state: bunny
+  // 0.220-0.238 (mean 0.228: the model breathes, the work changes with it), dragon 1080p 0.238-0.282 (mean 0.263 against 0.301), dragon
+  // 4K a smooth curve 0.72-1.07 along the animation (mean 0.87 against 0.89-0.91, no window above 1.07 where there were 1.24).  Small
+  // launches and static meshes keep four (static 1080p 0.184 -> 0.196 with three, the deforming bunny at 640x360 0.128 -> 0.137).
+  // profiles/r03_i_deform_states.txt; RTGGX_FENCE_FRAMES overrides (1 .. RT_SETS).
+  { static const int forced = getenv("RTGGX_FENCE_FRAMES") ? atoi(getenv("RTGGX_FENCE_FRAMES")) : 0;
+    const bool deformingNow = c->mesh[0].deforming || c->mesh[1].deforming;
+    const uint32_t inFlight = forced >= 1 && forced <= RT_SETS ? (uint32_t)forced : (deformingNow && !c->lastTraceSmall && c->pipeline != 0 && c->asyncCompute) ? RT_SETS - 1u : RT_SETS;
+    if (inFlight < RT_SETS) {
+      const uint32_t idx = (c->setIndex + RT_SETS - inFlight) % RT_SETS;      // the set of frame f - inFlight
+      if (c->setReadRecorded[idx] && hipEventQuery(c->evSetRead[idx]) != hipSuccess) {
+        const auto t0 = std::chrono::steady_clock::now();
+        RT_HIP(hipEventSynchronize(c->evSetRead[idx]));
+        c->fenceWaitUs += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++c->fenceWaits;
+      }
+    } }
   c->refitIssued = false;
   { const int r = issuePendingRefits(c, &c->refitIssued); if (r) return r; }
   if (c->refitIssued && c->asyncCompute) RT_HIP(hipEventRecord(c->evRefit, c->streamRefit));
