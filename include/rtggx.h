@@ -196,7 +196,9 @@ int  rtggx_build_as(rtggx_context* ctx);
  * `rebuild_ratio` x that of the last build (rtggx_set_refit_policy, default 1.2), the mesh is REBUILT from its newest shape beside
  * the frames: `steps_per_frame` kernel launches of the build per frame (default 16; ~75 for the bunny) behind that frame's refit,
  * the new topology taking over between two frames when the last one has ended.  Neither call waits for the GPU (the first
- * rtggx_refit_as of a mesh allocates its per-set buffers).  rtggx_refit_stats: cost of the current tree relative to the last
+ * rtggx_refit_as of a mesh allocates its per-set buffers).  While a mesh deforms on a full-size frame the context keeps three frames in
+ * flight instead of four (rtggx_render_visibility waits for the end of frame f - 3): one frame time instead of two, DESIGN.md section 9.
+ * rtggx_refit_stats: cost of the current tree relative to the last
  * build, refits and rebuilds so far; synchronises (a rebuild in progress stays in progress). */
 int  rtggx_refit_as(rtggx_context* ctx, uint32_t slot, const float* verts, uint32_t num_verts);
 int  rtggx_set_refit_policy(rtggx_context* ctx, float rebuild_ratio, uint32_t steps_per_frame);
