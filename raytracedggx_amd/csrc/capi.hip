@@ -697,7 +697,14 @@ int rtggx_render_visibility(rtggx_context* c) {
   // profiles/r03_i_deform_states.txt; RTGGX_FENCE_FRAMES overrides (1 .. RT_SETS).
   { static const int forced = getenv("RTGGX_FENCE_FRAMES") ? atoi(getenv("RTGGX_FENCE_FRAMES")) : 0;
     const bool deformingNow = c->mesh[0].deforming || c->mesh[1].deforming;
-    const uint32_t inFlight = forced >= 1 && forced <= RT_SETS ? (uint32_t)forced : (deformingNow && !c->lastTraceSmall && c->pipeline != 0 && c->asyncCompute) ? RT_SETS - 1u : RT_SETS;
+    // ... and the same for frames that trace DIFFUSE rays (a material with metallic below 1: two rays per covered pixel, the traversal
+    // is the frame's longest stage by far): the dragon with diffuse rays 0.375-0.459 ms in five runs with four frames in flight (the
+    // "size trial that settles in most runs, not all" of round 2), 0.381-0.387 with three; only the model diffuse 0.305-0.343 -> 0.305-0.306;
+    // the bunny 0.302-0.312 -> 0.301-0.304; at 4K 1.140-1.154 -> 1.139-1.140.
+    const FrameParams& cur = c->slots[c->slot];
+    const bool diffuseNow = cur.mat.RoughMetals[0][1] < 1.0f || cur.mat.RoughMetals[1][1] < 1.0f;
+    const uint32_t inFlight = forced >= 1 && forced <= RT_SETS ? (uint32_t)forced
+                            : ((deformingNow || diffuseNow) && !c->lastTraceSmall && c->pipeline != 0 && c->asyncCompute) ? RT_SETS - 1u : RT_SETS;
     if (inFlight < RT_SETS) {
       const uint32_t idx = (c->setIndex + RT_SETS - inFlight) % RT_SETS;      // the set of frame f - inFlight
       if (c->setReadRecorded[idx] && hipEventQuery(c->evSetRead[idx]) != hipSuccess) {
