@@ -26,8 +26,8 @@ import subprocess
 import sys
 import time
 
-# The renderer runs a frame on four streams, five with the strip exchange of N > 1 (rtggx_get_exchange_stream): HIP's default of four hardware
-# queues would make two of them share one.  Read when the runtime initialises, i.e. before torch is imported; the ranks inherit it.
+# The renderer runs a frame on four streams, RCCL brings its own, the null stream is a fifth: HIP's default of four hardware queues would
+# make two of them share one.  Read when the runtime initialises, i.e. before torch is imported; the ranks inherit it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--deform", type=float, default=0.0, help="amplitude of the breathing-model animation (-deform): new vertices and an asynchronous BVH refit every frame")
     ap.add_argument("--trace-waves", type=int, default=0, help="pin the size of the traversal's resident workgroup (10, 12, 14, 16) instead of letting the library steer it (measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (default: the job's CPU share, at most 16)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
     ap.add_argument("--prime-frames", type=int, default=256, help="frames rendered during SET-UP, before the warm-up steps: the GPU's compute clock ramps for "
                     "30-50 ms after any idle period (profiles/r02_b_clock_ramp.txt), and the renderer's adaptive state settles over its first frames; 0 = none")
@@ -111,6 +112,7 @@ class StubRenderer:
             raise ValueError("strips of %d rows are thinner than the %d-row history apron" % (self.e - self.b, strips.HISTORY_APRON))
         self.history = torch.zeros((height, width), dtype=torch.int64)
         self.back = torch.zeros((height, width), dtype=torch.int32)
+        self.tokens = torch.zeros(2 * strips.capi.MAX_PEERS, dtype=torch.int32)      # the ordering tokens between ranks that exchange nothing else (strips.exchange_plan)
         self.frames = 0
         self.rays = 0
         self.plan = strips.exchange_plan(height, rank, world)
@@ -123,7 +125,11 @@ class StubRenderer:
         self.history[self.b:self.e] = self._truth(self.b, self.e, f)
         self.back[self.b:self.e] = self._truth(self.b, self.e, f + 7).to(self.torch.int32)
         if self.world > 1:
-            self.strips.run_exchange(self.dist, self.plan, {"history": self.history, "backbuffer": self.back})
+            self.tokens[self.rank] = f + 1
+            self.strips.run_exchange(self.dist, self.plan, {"history": self.history, "backbuffer": self.back, "token": self.tokens})
+            for op, name, r0, r1, peer in self.plan:
+                if op == "recv" and name == "token":
+                    assert int(self.tokens[r0]) == f + 1, "rank %d: token of rank %d in frame %d" % (self.rank, peer, f)
             lo, hi = max(self.b - self.strips.HISTORY_APRON, 0), min(self.e + self.strips.HISTORY_APRON, self.H)
             assert self.torch.equal(self.history[lo:hi], self._truth(lo, hi, f)), "rank %d: history apron of frame %d" % (self.rank, f)
             if self.rank == 0:
@@ -302,6 +308,9 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
                      "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(alg_bytes),
                      "algorithmic_bytes_per_ray": 40, "algorithmic_bytes_r01": int(alg_bytes_r01), "l1_requests": l1, "kernel_ms": round(k_ms, 4),
                      "kernel_ms_alone": None if k_alone != k_alone else round(k_alone, 4),
+                     # rays / trace-kernel time (the line's `value` is rays / whole-frame time)
+                     "trace_kernel_mrays": None if not (k_ms == k_ms and k_ms > 0) else round(rays_per_launch / (k_ms * 1e-3) / 1e6, 1),
+                     "trace_kernel_mrays_alone": None if k_alone != k_alone else round(rays_per_launch / (k_alone * 1e-3) / 1e6, 1),
                      "frac_alone": None if k_alone != k_alone else round(alg_bytes / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "peak_measured": None if peak_measured is None else round(peak_measured, 1),
                      "peak_measured_how": "float4 copy kernel, 2 x 1 GiB per launch, best of 2 / 4 / 8 / 16 workgroups per CU at 64 launches each (>= 25 ms), read + written bytes (rtggx_copy_bandwidth), on this box after the set-up priming frames",
@@ -334,7 +343,20 @@ def cpu_baseline(r, args, W, H):
     import assets
     from oracle import oracle as O
     from raytracedggx_amd import app, capi
-    cores = min(os.cpu_count() or 1, 16)
+    # How many host threads?  BASELINE.md 2 says "all hardware threads"; what a job on the GPU box may USE is its CPU share, not the host's
+    # core count: the box gives one GPU's job 16 CPUs (os.cpu_count() reports the host's 256).  The share is read from the scheduler
+    # affinity and the cgroup's CPU quota; the main leg runs on min(share, 16) threads (--cpu-threads overrides), and when the share is
+    # larger than that a second leg runs on all of it.  Both are in the line, with what was found.
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            quota = None if q == "max" else max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    share = min(affinity, quota) if quota else affinity
+    cores = args.cpu_threads if args.cpu_threads else min(share, 16)
 
     def leg(threads, frames):
         o = O.Oracle(W, H, threads=threads)
@@ -363,6 +385,7 @@ def cpu_baseline(r, args, W, H):
         return {"value": round(rays / t_total / 1e6, 4), "ms_per_frame": round(t_total * 1e3 / frames, 2), "trace_only_mrays": round(rays / t_trace / 1e6, 4)}
 
     multi = leg(cores, args.cpu_frames)
+    every = leg(share, args.cpu_frames) if share > cores and not args.cpu_threads else None
     single = leg(1, 1)
     cpu = ""
     try:
@@ -371,7 +394,9 @@ def cpu_baseline(r, args, W, H):
     except OSError:
         pass
     return {"value": multi["value"], "unit": "Mrays/s", "cores": cores, "kind": "port", "ms_per_frame": multi["ms_per_frame"],
-            "trace_only_mrays": multi["trace_only_mrays"], "cpu": cpu, "host_threads_available": os.cpu_count(),
+            "trace_only_mrays": multi["trace_only_mrays"], "cpu": cpu, "host_threads_available": os.cpu_count(), "cpu_share_of_this_job": share,
+            "cpu_share_how": "min(scheduler affinity %d, cgroup cpu.max %s)" % (affinity, quota if quota else "unlimited"),
+            "all_threads_of_the_share": None if every is None else dict(every, cores=share),
             "single_thread": dict(single, cores=1, sample="1 frame after 1 warm-up frame"),
             "sample": "%d frames (after 1 warm-up) of the same %dx%d workload, oracle on %d threads, same BVH arrays as the GPU; then 1 frame on 1 thread" % (args.cpu_frames, W, H, cores)}
 

@@ -100,13 +100,15 @@ enum {
   RTGGX_BUF_BVH_TRIS1 = 16,
   RTGGX_BUF_TLAS = 17,       /* 2 x 16 floats: world->object matrices (row-vector, row-major) */
   RTGGX_BUF_ENV = 18,        /* decoded RGBA16F environment, mip-major, 6 faces per mip */
-  RTGGX_BUF_BVH4_NODES0 = 19, /* 128-byte 4-wide nodes of mesh 0, indexed like the binary nodes (odd-depth slots unused, zero): */
+  RTGGX_BUF_BVH4_NODES0 = 19, /* 128-byte 4-wide nodes of mesh 0, indexed like the binary nodes (the slots of binary nodes folded into another: zero): */
   RTGGX_BUF_BVH4_NODES1 = 20, /*   minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4]; ref: >=0 node, <0 ~leaf slot, 0x7FFFFFFF none */
   RTGGX_BUF_BIN_WORK = 21,    /* uint32 per ray bin (8x8-pixel sub-tile; bin = 4 * (tileY * tilesX + tileX) + 2 * subY + subX over 16x16 tiles):
                                  lane-steps the last traversal spent on the bin's rays; zero unless that launch recorded them (full-size frames) */
   RTGGX_BUF_BVH4_TOP0 = 22,   /* the first (up to 16 / 96) 4-wide nodes of mesh 0 / 1 in breadth-first order, same 128-byte records; a reference to */
   RTGGX_BUF_BVH4_TOP1 = 23,   /*   a node that is in the table itself reads 0x40000000 | position (the copy the trace kernel keeps in LDS) */
-  RTGGX_BUF_COUNT = 24
+  RTGGX_BUF_EXCHANGE_TOKENS = 24, /* 2 x RTGGX_MAX_PEERS uint32: words a multi-GPU host may send from ([rank]) and receive into ([RTGGX_MAX_PEERS + peer]) --
+                                     the 4-byte messages that order two ranks without a neighbour's history rows between them (rtggx_set_history_peers) */
+  RTGGX_BUF_COUNT = 25
 };
 
 /* Per-pass GPU timings of the last completed frame, in milliseconds (hipEvent based). */
@@ -144,23 +146,29 @@ int  rtggx_set_stream(rtggx_context* ctx, void* hip_stream);
 /* The context's main stream (its own, or the one handed in): what a host enqueues there -- the per-frame RCCL exchange of the
  * multi-GPU host, host/Strips.cpp -- is ordered behind the frame's tone map and before the next frame's temporal pass. */
 int  rtggx_get_stream(rtggx_context* ctx, void** hip_stream);
-/* Multi-GPU strips: a stream of the context's for the caller's exchange of history rows between two frames (RCCL sends / receives), so
- * that it runs beside the next frame's shading and spatial filters instead of in front of them:
- *     rtggx_tone_map(f);  rtggx_exchange_begin(ctx);  <exchange on the stream of rtggx_get_exchange_stream>;  rtggx_exchange_end(ctx);
- * begin orders that stream behind frame f's last kernel, end marks where the exchange ends; the TEMPORAL pass of frame f + 1 waits for it
- * (and with it everything that could touch the rows exchanged: that frame's tone map, the next H pass).  The exchange may read and write
- * TemporalSSOut[parity of f] and the back buffer.  (The frame's other consumers keep using rtggx_get_stream.  The library then runs five
- * streams: export GPU_MAX_HW_QUEUES=8 before the process touches HIP, or two of them share a hardware queue.  Measured on one GPU with
- * every rank's real RCCL group it is SLOWER than the exchange on the main stream at 1080p and at 4K -- a fifth stream with work on it
- * costs more than the overlap brings, profiles/r03_h_strip_projection.txt -- so strips.py and host/Strips.cpp keep the exchange on the
- * main stream unless asked: RTGGX_EXCHANGE_BESIDE=1.) */
-int  rtggx_get_exchange_stream(rtggx_context* ctx, void** stream);
-int  rtggx_exchange_begin(rtggx_context* ctx);
-int  rtggx_exchange_end(rtggx_context* ctx);
-/* Ordering of the back buffer.  A context left to itself may run a frame's tone map beside the NEXT frame's filters on another
- * stream (DESIGN.md "The frame on the device"): the back buffer is complete after rtggx_sync / rtggx_readback.  A caller that consumes
- * it by other means says so by calling rtggx_set_stream, rtggx_get_stream or rtggx_buffer_ptr(RTGGX_BUF_BACKBUFFER | TSS*): from then
- * on every kernel whose output it may read runs on the main stream, in order. */
+/* Multi-GPU strips: history taps beyond the exchanged apron read the OWNER's image (round 4).  The reference samples its one history
+ * texture anywhere (CSTemporalSS.hlsl:259-265); a rank holds last frame's TemporalSSOut for its own rows and `apron` rows either side.
+ * With the other ranks' two history images mapped into this process the temporal pass reads a tap beyond those rows from the image of
+ * the rank whose strip holds the row: N strips equal the single-GPU frame at any velocity (rtggx_history_overreach keeps counting such
+ * taps; they are harmless then).
+ *   bounds      world + 1 ascending rows: rank r owns [bounds[r], bounds[r + 1]) -- every rank allocates full-size targets, so a row sits
+ *               at the same offset in every rank's image
+ *   tss0, tss1  world device pointers each, valid in THIS process: rank r's TemporalSSOut[0] / [1] (rtggx_buffer_ptr of a context in
+ *               the same process, or rtggx_history_ipc_open of another process's export); this rank's own entries may be null
+ *   world = 0   forget the peers
+ * Ordering is the caller's: rank A's temporal pass of frame f + 1 may read rank B's image once B's temporal pass of frame f has ended,
+ * and B's horizontal filter of frame f + 2 -- which reuses that image as its scratch -- must wait for A's temporal pass of frame f + 1.
+ * A per-frame exchange on the main streams (rtggx_get_stream) with a message in EACH direction between every two ranks orders both:
+ * the neighbours' history rows do between neighbours, host/Strips.cpp and strips.py add 4-byte tokens between the other pairs. */
+#define RTGGX_MAX_PEERS 16
+#define RTGGX_IPC_HANDLE_BYTES 64
+int  rtggx_set_history_peers(rtggx_context* ctx, uint32_t world, const uint32_t* bounds, void* const* tss0, void* const* tss1);
+/* One process per GPU: this context's two history images as inter-process handles (2 x RTGGX_IPC_HANDLE_BYTES: hipIpcMemHandle_t of
+ * TemporalSSOut[0], [1]; `bytes` = the room at `handles`) ... */
+int  rtggx_history_ipc_export(rtggx_context* ctx, void* handles, size_t bytes);
+/* ... and another process's handles opened in this one: two device pointers for rtggx_set_history_peers (unmapped by rtggx_destroy).
+ * (HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of both processes on hosts whose driver only supports dmabuf IPC.) */
+int  rtggx_history_ipc_open(rtggx_context* ctx, const void* handles, size_t bytes, void** tss0, void** tss1);
 
 /* The sample's asynchronous-compute toggle (m_asyncCompute, key [A]: RayTracedGGX.cpp:304-353 issues the frame over two
  * queues, :513-556 as one command list).  enable = 0: every pass is issued to the main stream in submission order (no
@@ -220,15 +228,22 @@ int  rtggx_ray_trace(rtggx_context* ctx);
 int  rtggx_denoise(rtggx_context* ctx, int use_shared_mem);
 int  rtggx_tone_map(rtggx_context* ctx);
 
-/* Diagnostic: triangles a leaf of the 4-wide trees may hold in builds from now on (1, 2, 3 or 4; default 1, or RTGGX_LEAF_TRIS).  Whole
- * subtrees of up to that many triangles become one entry of their (grand)parent node -- fewer node visits per ray, more triangle
- * tests per leaf visit (measured: profiles/r03_e_multi_leaf.txt).  Results do not depend on it. */
-int  rtggx_debug_leaf_tris(rtggx_context* ctx, uint32_t leaf_tris);
-/* Diagnostic: put the tone map of full-size static frames aside and launch it beside the NEXT frame's filters, on the refit stream
- * (round 2's arrangement; 1) or keep it at the end of the main stream's chain (0; the default since round 3, or RTGGX_TONEMAP_ASIDE).
- * Measured neutral to slightly slower in round 3's pipeline and the wider of the two in run-to-run spread.
- * Results do not depend on it. */
-int  rtggx_debug_tone_map_aside(rtggx_context* ctx, int on);
+/* Since round 4 rtggx_denoise's temporal pass also tone-maps its result (one kernel instead of two: Denoiser::Denoise and ::ToneMap
+ * follow each other in every frame of the sample, RayTracedGGX.cpp:341-350), and the rtggx_tone_map that follows it in the same frame
+ * finds its work done.  A tone map without a preceding rtggx_denoise in the frame, or after an rtggx_upload, runs as a kernel of its
+ * own.  Diagnostic: 0 = always two kernels (rounds 1-3's path, kept for comparison: the back buffer is bit-identical). */
+int  rtggx_debug_fuse_tone_map(rtggx_context* ctx, int on);
+/* Diagnostic: which streams a frame's kernels go to is decided from five facts (capi.hip placeFrame: small launch, strip, deforming
+ * mesh, diffuse rays, caller-owned main stream).  force_small = 0 / 1 pins the first of them whatever the ray count says (-1: by the
+ * count again).  key / where (may be null): the most recent rtggx_ray_trace's key (bit 0 small, 1 strip, 2 deforming, 3 diffuse,
+ * 4 caller-owned stream) and placement (bits 0-3 / 4-7 / 8-11: stream of ray generation / traversal / hit shading -- 0 main, 1 B, 2 C,
+ * 3 R --, bits 12-15 frames in flight).  Results do not depend on any of it. */
+int  rtggx_debug_placement(rtggx_context* ctx, int force_small, uint32_t* key, uint32_t* where);
+/* Diagnostic: the two weights of the 4-wide collapse's objective (lbvh.hip "the 4-wide collapse"): a 4-wide node costs
+ * area_weight x (its half-area / the root's) + tris_weight x (its triangles / all triangles) -- the chance that a random ray enters it,
+ * and the chance that a ray STARTING on the mesh's surface (every ray of this path does) starts inside it.  set (may be null): weights for
+ * builds from now on; get (may be null): the current ones.  Results do not depend on them. */
+int  rtggx_debug_collapse_weights(rtggx_context* ctx, const float* set, float* get);
 /* Diagnostic: the host time (us) rtggx_render_visibility has spent WAITING at the frames-in-flight fence -- for the last reader of the
  * input set it is about to overwrite, four frames back (RayTracedGGX.cpp:672-701) -- and how many frames had to wait, since the last reset.
  * A frame loop that is bound by the GPU waits there every frame; one that is bound by its own submission never does. */

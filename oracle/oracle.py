@@ -136,6 +136,11 @@ class Oracle:
     def set_sampler(self, vndf):
         self.L.orc_set_sampler(self.h, C.c_int(1 if vndf else 0))
 
+    def set_normal_weight(self, variant):
+        """How the spatial filters' pow(dot(N, Nc), 512 | 32) is evaluated, process-wide: "exact" (double, rounded once; the default),
+        "libm" (fp32 dot product, std::pow in fp32) or "squared" (round 3's nine / five squarings)."""
+        self.L.orc_set_normal_weight(C.c_int({"exact": 0, "libm": 1, "squared": 2}[variant]))
+
     def set_metallic(self, mesh, m):
         self.L.orc_set_metallic(self.h, C.c_uint32(mesh), C.c_float(m))
 

@@ -70,6 +70,7 @@ int orc_set_mesh(void* h, uint32_t slot, const float* verts, uint32_t nv, const 
 }
 void orc_set_pos_scale(void* h, const float* ps) { std::memcpy(((Ctx*)h)->posScale, ps, 16); }
 void orc_set_sampler(void* h, int vndf) { ((Ctx*)h)->vndf = vndf != 0; }
+void orc_set_normal_weight(int variant) { g_normalWeightVariant = variant; }      // orc_denoise.h normal_weight: 0 exact, 1 libm fp32, 2 round 3's squarings (process-wide)
 void orc_set_metallic(void* h, uint32_t mesh, float m) { ((Ctx*)h)->fc.mat.RoughMetals[mesh][1] = m; }   // RayTracer.cpp:244-248
 void orc_set_material(void* h, uint32_t mesh, const float* baseColor4, float rough, float metal) {
   Ctx* c = (Ctx*)h; std::memcpy(c->fc.mat.BaseColors[mesh], baseColor4, 16); c->fc.mat.RoughMetals[mesh][0] = rough; c->fc.mat.RoughMetals[mesh][1] = metal;

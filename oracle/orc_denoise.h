@@ -42,17 +42,28 @@ static inline void load_rgba16(const std::vector<uint64_t>& b, const Ctx& c, int
 // FilterCommon.hlsli
 static inline void TM3(float* rgb) { const float l = 1.0f + ((rgb[0] * 0.25f + rgb[1] * 0.5f) + rgb[2] * 0.25f); rgb[0] /= l; rgb[1] /= l; rgb[2] /= l; }     // :14-19
 static inline void ITM3(float* rgb) { const float l = 1.0f - ((rgb[0] * 0.25f + rgb[1] * 0.5f) + rgb[2] * 0.25f); rgb[0] /= l; rgb[1] /= l; rgb[2] /= l; }    // :24-27
-// pow(x, sigma) with sigma = 512 or 32, the only exponents the filters use (SpatialFilter.hlsli:62,73): by repeated squaring -- 9 or 5
-// fp32 multiplications, part of the numeric contract like pow(x, 5) by multiplication in the shading path (DESIGN.md "Oracle").  HLSL's
-// pow is exp2(y * log2(x)) on 1-ulp hardware functions: for x next to 1 its result is uncertain by ~1e-5, libm's pow is exact to half
-// an ulp, squaring nine times carries ~256 ulps.  None is "the" reference value; what matters downstream is that the two sides of the
-// parity check agree, because the temporal pass turns a 1e-5 difference of its input into a 1e-3 difference of its output on a few bright
-// pixels (variance clamp x inverse tone map; tools/probes/parity_probe.py, profiles/r03_d_parity_1080p.txt).  RTGGX_ORACLE_LIBM_POW=1
-// selects std::pow again (measurement).
+// pow(max(dot(nC, n), 0), sigma), sigma = 512 or 32 (SpatialFilter.hlsli:62,73; FilterCommon.hlsli:34-37).  HLSL's pow is exp2(y * log2(x))
+// on the hardware's 1-ulp functions -- for x next to 1 uncertain in the last few bits -- so no evaluation is "the" reference's; what the
+// oracle owes the parity check is one that owes nothing to the product's.  Round 3 had both sides square x nine (five) times -- the same
+// 423 ulps of error on both sides, and a temporal pass that turns a 1e-5 difference of its input into 1e-3 of its output made the check
+// pass BECAUSE the rounding was shared.  Round 4: the product computes v_exp_f32(sigma * v_log_f32(x)) (16 ulps where the weight counts),
+// and the oracle has three evaluations to hold against it (orc_set_normal_weight; the tests run the first two):
+//   0  EXACT    the dot product in double (exact for 10-bit normals), the power in double, rounded once -- the true value to half an ulp
+//   1  LIBM     what a plain C reading of the HLSL gives: fp32 dot product (two multiply-adds unfused: mul, mul, add, mul, add), std::pow in fp32
+//   2  SQUARED  round 3's: fused dot product, nine / five fp32 squarings (kept for measurement: tools/probes/parity_probe.py)
+static int g_normalWeightVariant = std::getenv("RTGGX_ORACLE_LIBM_POW") ? 1 : 0;
 static inline float normal_weight(const float* a, const float* b, float sigma) {   // :34-37
-  static const bool libmPow = std::getenv("RTGGX_ORACLE_LIBM_POW") != nullptr;
-  float p = std::fmax(std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])), 0.0f);      // a dp3: one multiplication, two fused multiply-adds (as the product's filter)
-  if (libmPow || (sigma != 512.0f && sigma != 32.0f)) return std::pow(p, sigma);
+  if (g_normalWeightVariant == 0) {
+    const double d = ((double)a[0] * (double)b[0] + (double)a[1] * (double)b[1]) + (double)a[2] * (double)b[2];
+    return (float)std::pow(d > 0.0 ? d : 0.0, (double)sigma);
+  }
+  if (g_normalWeightVariant == 1) {
+    const volatile float m0 = a[0] * b[0], m1 = a[1] * b[1], m2 = a[2] * b[2];      // (volatile: no contraction, whatever the flags)
+    const float p = std::fmax((m0 + m1) + m2, 0.0f);
+    return std::pow(p, sigma);
+  }
+  float p = std::fmax(std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])), 0.0f);
+  if (sigma != 512.0f && sigma != 32.0f) return std::pow(p, sigma);
   p *= p; p *= p; p *= p; p *= p; p *= p;        // ^32
   if (sigma == 512.0f) { p *= p; p *= p; p *= p; p *= p; }
   return p;

@@ -29,8 +29,8 @@ static inline float3 f3(float x, float y, float z) { return {x, y, z}; }
 static inline float exp2Contract(float x) {
   if (!(x > -126.0f)) return x != x ? x : 0.0f;      // (results below the normal range: zero -- the shading path asks for 2^(-9.28 NoV))
   if (!(x < 128.0f)) return x != x ? x : __builtin_inff();
-  const float n = __builtin_rintf(x);
-  const float t = (x - n) * 0.693147180559945f;      // e^t, |t| <= 0.347: Taylor to t^8 (next term 2e-10)
+  const float n = __builtin_fminf(__builtin_rintf(x), 127.0f);      // (x in (127.5, 128): 2^127 x e^t with t up to 0.693 -- finite, as the true value is; 2^128 does not exist)
+  const float t = (x - n) * 0.693147180559945f;      // e^t, |t| <= 0.347 (0.693 in that last half-octave): Taylor to t^8 (next term 2e-10; 1e-7 there)
   float p = 1.0f / 40320.0f;
   p = p * t + 1.0f / 5040.0f; p = p * t + 1.0f / 720.0f; p = p * t + 1.0f / 120.0f; p = p * t + 1.0f / 24.0f;
   p = p * t + 1.0f / 6.0f; p = p * t + 0.5f; p = p * t + 1.0f; p = p * t + 1.0f;

@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, "librtggx.so")
 # buffer ids (rtggx.h)
 BUF_VISIBILITY, BUF_DEPTH, BUF_NORMAL, BUF_ROUGH_METAL, BUF_VELOCITY, BUF_RT_REFL, BUF_RT_DIFF, BUF_TSS0, BUF_TSS1, \
     BUF_FLT_RFL, BUF_FLT_DFF, BUF_BACKBUFFER, BUF_SH_COEFFS, BUF_BVH_NODES0, BUF_BVH_TRIS0, BUF_BVH_NODES1, BUF_BVH_TRIS1, \
-    BUF_TLAS, BUF_ENV, BUF_BVH4_NODES0, BUF_BVH4_NODES1, BUF_BIN_WORK, BUF_BVH4_TOP0, BUF_BVH4_TOP1 = range(24)
+    BUF_TLAS, BUF_ENV, BUF_BVH4_NODES0, BUF_BVH4_NODES1, BUF_BIN_WORK, BUF_BVH4_TOP0, BUF_BVH4_TOP1, BUF_EXCHANGE_TOKENS = range(25)
+MAX_PEERS, IPC_HANDLE_BYTES = 16, 64
 FORMAT_RGBA32F, FORMAT_RGBA16F, FORMAT_BC6H_UF16, FORMAT_BC6H_SF16 = 2, 10, 95, 96
 
 _BUF_DTYPE = {BUF_VISIBILITY: np.uint32, BUF_DEPTH: np.uint32, BUF_NORMAL: np.uint32, BUF_ROUGH_METAL: np.uint16,
@@ -23,14 +24,14 @@ _BUF_DTYPE = {BUF_VISIBILITY: np.uint32, BUF_DEPTH: np.uint32, BUF_NORMAL: np.ui
               BUF_FLT_RFL: np.uint64, BUF_FLT_DFF: np.uint64, BUF_BACKBUFFER: np.uint32, BUF_SH_COEFFS: np.float32,
               BUF_BVH_NODES0: np.uint32, BUF_BVH_TRIS0: np.uint32, BUF_BVH_NODES1: np.uint32, BUF_BVH_TRIS1: np.uint32,
               BUF_TLAS: np.float32, BUF_ENV: np.uint16, BUF_BVH4_NODES0: np.uint32, BUF_BVH4_NODES1: np.uint32, BUF_BIN_WORK: np.uint32,
-              BUF_BVH4_TOP0: np.uint32, BUF_BVH4_TOP1: np.uint32}
+              BUF_BVH4_TOP0: np.uint32, BUF_BVH4_TOP1: np.uint32, BUF_EXCHANGE_TOKENS: np.uint32}
 
 EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip", "rtggx_set_stream", "rtggx_set_mesh",
            "rtggx_set_env", "rtggx_set_material", "rtggx_set_metallic", "rtggx_build_as", "rtggx_update_frame", "rtggx_update_as",
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
-           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream", "rtggx_get_exchange_stream", "rtggx_exchange_begin", "rtggx_exchange_end",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_leaf_tris", "rtggx_debug_tone_map_aside", "rtggx_debug_fence_wait", "rtggx_debug_shader_clock"]
+           "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream", "rtggx_set_history_peers", "rtggx_history_ipc_export", "rtggx_history_ipc_open",
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_fuse_tone_map", "rtggx_debug_placement", "rtggx_debug_collapse_weights", "rtggx_debug_fence_wait", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -162,10 +163,6 @@ class Context:
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 6)
         self._check(self.L.rtggx_refit_as(self.h, slot, _p(v), v.shape[0]))
 
-    def leaf_tris(self, n):
-        """Triangles per leaf of the 4-wide trees of later builds (diagnostic)."""
-        self._check(self.L.rtggx_debug_leaf_tris(self.h, n))
-
     def fence_wait(self, reset=True):
         """(us the host has waited at the frames-in-flight fence, frames that waited) since the last reset (diagnostic)."""
         us, n = C.c_double(0.0), C.c_uint32(0)
@@ -173,9 +170,58 @@ class Context:
         self._check(self.L.rtggx_debug_fence_wait(self.h, C.byref(us), C.byref(n), 1 if reset else 0))
         return us.value, n.value
 
-    def tone_map_aside(self, on):
-        """The tone map of full-size static frames beside the next frame's filters (diagnostic; off by default)."""
-        self._check(self.L.rtggx_debug_tone_map_aside(self.h, 1 if on else 0))
+    def fuse_tone_map(self, on):
+        """The temporal pass also tone-maps its result (default) / temporal pass and tone map as two kernels (diagnostic)."""
+        self._check(self.L.rtggx_debug_fuse_tone_map(self.h, 1 if on else 0))
+
+    def placement(self, force_small=-1):
+        """Pins the `small launch` fact of the stream placement (0 / 1; -1: by the ray count) and returns the key and placement of the most
+        recent ray_trace: ({small, strip, deforming, diffuse, caller_stream}, {gen, trace, shade: "main" | "B" | "C" | "R", frames_in_flight})."""
+        k, w = C.c_uint32(), C.c_uint32()
+        self.L.rtggx_debug_placement.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self._check(self.L.rtggx_debug_placement(self.h, int(force_small), C.byref(k), C.byref(w)))
+        names = ("main", "B", "C", "R", "?")
+        key = {n: bool((k.value >> i) & 1) for i, n in enumerate(("small", "strip", "deforming", "diffuse", "caller_stream"))}
+        where = {"gen": names[w.value & 15], "trace": names[(w.value >> 4) & 15], "shade": names[(w.value >> 8) & 15], "frames_in_flight": (w.value >> 12) & 15}
+        return key, where
+
+    def collapse_weights(self, area=None, tris=None):
+        """(area weight, triangle-count weight) of the 4-wide collapse's objective; given both, sets them for builds from now on (diagnostic)."""
+        self.L.rtggx_debug_collapse_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        get = (C.c_float * 2)()
+        if area is not None:
+            st = (C.c_float * 2)(float(area), float(tris))
+            self._check(self.L.rtggx_debug_collapse_weights(self.h, st, get))
+        else:
+            self._check(self.L.rtggx_debug_collapse_weights(self.h, None, get))
+        return float(get[0]), float(get[1])
+
+    def set_history_peers(self, bounds, tss0, tss1):
+        """Multi-GPU strips: every rank's TemporalSSOut[0] / [1] as device pointers valid in this process (0: this rank's own), and the
+        strip boundaries (world + 1 rows) -- history taps beyond the exchanged apron then read the owner's image.  bounds=None: forget them."""
+        self.L.rtggx_set_history_peers.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        if bounds is None:
+            self._check(self.L.rtggx_set_history_peers(self.h, 0, None, None, None))
+            return
+        world = len(bounds) - 1
+        b = (C.c_uint32 * (world + 1))(*[int(x) for x in bounds])
+        p0 = (C.c_void_p * world)(*[C.c_void_p(int(x) or None) for x in tss0])
+        p1 = (C.c_void_p * world)(*[C.c_void_p(int(x) or None) for x in tss1])
+        self._check(self.L.rtggx_set_history_peers(self.h, world, b, p0, p1))
+
+    def history_ipc_export(self):
+        """This context's two history images as inter-process handles (2 x 64 bytes) for another process's history_ipc_open."""
+        self.L.rtggx_history_ipc_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        buf = C.create_string_buffer(2 * IPC_HANDLE_BYTES)
+        self._check(self.L.rtggx_history_ipc_export(self.h, buf, len(buf.raw)))
+        return bytes(buf.raw)
+
+    def history_ipc_open(self, handles):
+        """Another process's history_ipc_export opened here: (TemporalSSOut[0], TemporalSSOut[1]) device pointers for set_history_peers."""
+        self.L.rtggx_history_ipc_open.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        p0, p1 = C.c_void_p(), C.c_void_p()
+        self._check(self.L.rtggx_history_ipc_open(self.h, bytes(handles), len(handles), C.byref(p0), C.byref(p1)))
+        return int(p0.value), int(p1.value)
 
     def set_sampler(self, vndf):
         self._check(self.L.rtggx_set_sampler(self.h, 1 if vndf else 0))
@@ -245,19 +291,6 @@ class Context:
         self.L.rtggx_debug_trace_split.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         self._check(self.L.rtggx_debug_trace_split(self.h, work_per_wave, max_shift, capacity, C.byref(d)))
         return int(d.value)
-
-    def exchange_stream(self):
-        """The context's exchange stream as an integer handle (rtggx_get_exchange_stream): for the caller's sends / receives between frames."""
-        h = C.c_void_p()
-        self.L.rtggx_get_exchange_stream.argtypes = [C.c_void_p, C.c_void_p]
-        self._check(self.L.rtggx_get_exchange_stream(self.h, C.byref(h)))
-        return int(h.value or 0)
-
-    def exchange_begin(self):
-        self._check(self.L.rtggx_exchange_begin(self.h))
-
-    def exchange_end(self):
-        self._check(self.L.rtggx_exchange_end(self.h))
 
     def stream(self):
         """The context's main stream as an integer handle (rtggx_get_stream)."""

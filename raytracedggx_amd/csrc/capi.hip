@@ -74,41 +74,18 @@ static void invert4x4(const float* a /*row-major*/, float* out) {
   for (int i = 0; i < 16; ++i) out[i] = (float)(inv[i] * rdet);
 }
 
-static hipStream_t mainStream(rtggx_context* c) { return c->streamMain; }
-// A tone map that rtggx_tone_map has put aside for the next frame (see there) and no next frame has claimed: on the main stream, now.
-#define RT_TONE_ASIDE_PIXELS (2560ull * 1440ull)
-// A tone map on the main stream writes the back buffer a tone map put aside earlier (on the refit stream, evTone) may still be writing: the
-// older frame must not land last.
-static void orderMainBehindTones(rtggx_context* c) {
-  for (uint32_t p = 0; p < 2u; ++p) if (c->toneRecorded[p]) { hipStreamWaitEvent(c->streamMain, c->evTone[p], 0); c->toneRecorded[p] = false; }
-}
-static void flushToneMap(rtggx_context* c) {
-  if (!c->tonePending) return;
-  c->tonePending = false;
-  orderMainBehindTones(c);
-  launchPreparedToneMap(c, c->tonePrepared, c->streamMain, nullptr);
-}
-// Would rtggx_tone_map put this frame's tone map aside (see there)?  Everything but "the denoiser ran this frame".
-static bool toneAsideEligible(const rtggx_context* c, const FrameParams& fp) {
-  return c->toneAside && !c->callerOrdersOnMain && c->toneAsideAllowed && c->pipeline != 0 && c->asyncCompute && c->attachEvents && c->streamMain == c->ownMain && c->streamRefit != nullptr && !c->timing
-         && !(c->mesh[0].deforming || c->mesh[1].deforming) && !c->lastTraceSmall && fp.rowBegin == 0u && fp.rowEnd == fp.H
-         && (uint64_t)fp.W * fp.H <= RT_TONE_ASIDE_PIXELS;
-}
 // The frames-in-flight fence (evSetRead[set]: the last reader of an input set has ended) rides on a kernel's completion signal, and a
 // kernel that carries an event leaves its queue idle for ~5 us behind it (profiles/r03_c_strip_chain.txt).  So it rides on the LAST
-// kernel the main stream gets for the frame: the tone map when it follows on the main stream (strips, small frames), else the temporal
-// pass, the shading kernel only when an aside tone map waits for it.  A frame that ends earlier -- the caller traces without
-// denoising -- gets the event recorded explicitly by the next frame (settleSetRead).
+// kernel the main stream gets for the frame: the fused temporal + tone-map kernel, or the tone map where that is a kernel of its own.
+// A frame that ends earlier -- the caller traces without denoising -- gets the event recorded explicitly by the next frame (settleSetRead).
 static void settleSetRead(rtggx_context* c) {
   if (c->setReadDeferred < 0) return;
   hipEventRecord(c->evSetRead[c->setReadDeferred], c->streamMain);
   c->setReadRecorded[c->setReadDeferred] = true; c->setReadDeferred = -1;
 }
 static hipError_t syncStreams(rtggx_context* c) {
-  flushToneMap(c);      // whoever waits for the streams wants the back buffer complete
   hipError_t e = c->ownVis ? hipStreamSynchronize(c->ownVis) : hipSuccess;
   if (e == hipSuccess && c->streamRefit) e = hipStreamSynchronize(c->streamRefit);
-  if (e == hipSuccess && c->streamExchange) e = hipStreamSynchronize(c->streamExchange);
   if (e == hipSuccess) e = hipStreamSynchronize(c->ownAS);
   if (e == hipSuccess) e = hipStreamSynchronize(c->streamMain);
   return e;
@@ -193,39 +170,28 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   rtggx_context* c = new rtggx_context();
   c->device = device; c->W = width; c->H = height; c->rowBegin = 0; c->rowEnd = height;
   const size_t n = (size_t)width * height;
-  // Stream B carries visibility -> ray generation -> traversal, the main stream shading and the denoiser of the frame
-  // before.  While the traversal kernel had a long tail, giving stream B the higher priority paid; since the launch
-  // starts with the expensive bins the two chains are equally long and each waits for the other (B may not overwrite an
-  // input set the main stream is still reading), and equal priorities are the better choice (measured: bunny 1080p
-  // 0.233 -> 0.229 ms, dragon 0.259 -> 0.258; RTGGX_PRIORITY_MODE=0 restores B high / main low, 2 is the reverse).
+  // Streams and priorities (measured in rounds 1-3, profiles/r02_c_ab_pipeline.txt; the switches that chose between them are gone):
+  //   main  high   hit shading, spatial filters, temporal pass + tone map: the longest chain of the three, and the one the others slow down most
+  //   B     low    the traversal (one resident workgroup per CU)
+  //   C     low    visibility pass + ray generation of the next frame
+  //   R     middle vertex upload + tree refit of a deforming mesh; the traversals of odd frames where launches are small
   int prioLeast = 0, prioGreatest = 0;
   RT_HIP(hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
-  // Round 2, three-stage pipeline: the main stream's chain of five kernels is the longest of the three and the one the others slow
-  // down most; with the main stream high and stream B low the frame gains 4.5 % over equal priorities (profiles/r02_c_ab_pipeline.txt).
-  const int prioMode = getenv("RTGGX_PRIORITY_MODE") ? atoi(getenv("RTGGX_PRIORITY_MODE")) : 2;      // 0: B high, main low; 1: equal; 2: main high, B low
   const int prioMid = (prioLeast + prioGreatest) / 2;
-  RT_HIP(hipStreamCreateWithPriority(&c->ownMain, hipStreamNonBlocking, prioMode == 0 ? prioLeast : prioMode == 2 ? prioGreatest : prioMid));
-  RT_HIP(hipStreamCreateWithPriority(&c->ownAS, hipStreamNonBlocking, prioMode == 0 ? prioGreatest : prioMode == 2 ? prioLeast : prioMid));
+  RT_HIP(hipStreamCreateWithPriority(&c->ownMain, hipStreamNonBlocking, prioGreatest));
+  RT_HIP(hipStreamCreateWithPriority(&c->ownAS, hipStreamNonBlocking, prioLeast));
   c->streamMain = c->ownMain; c->streamAS = c->ownAS;
-  c->attachEvents = !(getenv("RTGGX_ATTACH_EVENTS") && atoi(getenv("RTGGX_ATTACH_EVENTS")) == 0);
-  if (!(getenv("RTGGX_VIS_STREAM") && atoi(getenv("RTGGX_VIS_STREAM")) == 0))
-    { const int pc = getenv("RTGGX_PRIORITY_C") ? atoi(getenv("RTGGX_PRIORITY_C")) : 0;      // stream C: 0 low (default: 0.2113 ms against 0.2126 mid, 0.2218 high), 1 mid, 2 high
-      RT_HIP(hipStreamCreateWithPriority(&c->ownVis, hipStreamNonBlocking, pc == 0 ? prioLeast : pc == 2 ? prioGreatest : prioMid)); c->streamVis = c->ownVis; }
+  c->attachEvents = !(getenv("RTGGX_ATTACH_EVENTS") && atoi(getenv("RTGGX_ATTACH_EVENTS")) == 0);      // 0: marker packets (hipEventRecord) instead of events riding on kernels
+  RT_HIP(hipStreamCreateWithPriority(&c->ownVis, hipStreamNonBlocking, prioLeast)); c->streamVis = c->ownVis;
   RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRefit, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evGen, hipEventDisableTiming));
   for (auto& e : c->evTraceRing) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  { const int pr = getenv("RTGGX_PRIORITY_R") ? atoi(getenv("RTGGX_PRIORITY_R")) : 1;      // stream R: 0 low, 1 mid, 2 high
-    RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, pr == 0 ? prioLeast : pr == 2 ? prioGreatest : prioMid)); }
-  c->pipeline = getenv("RTGGX_PIPELINE") ? atoi(getenv("RTGGX_PIPELINE")) : 1;
-  c->toneAside = getenv("RTGGX_TONEMAP_ASIDE") && atoi(getenv("RTGGX_TONEMAP_ASIDE")) != 0;      // rtggx_tone_map; rtggx_debug_tone_map_aside
-  c->rebuildRatio = getenv("RTGGX_REBUILD_RATIO") ? (float)atof(getenv("RTGGX_REBUILD_RATIO")) : RT_REFIT_REBUILD_RATIO;
-  c->rebuildSteps = getenv("RTGGX_REBUILD_STEPS") ? (uint32_t)atoi(getenv("RTGGX_REBUILD_STEPS")) : RT_REBUILD_STEPS;
-  { const int lt = getenv("RTGGX_LEAF_TRIS") ? atoi(getenv("RTGGX_LEAF_TRIS")) : 1; c->leafTris = lt < 1 ? 1u : lt > 4 ? 4u : (uint32_t)lt; }
+  RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, prioMid));
+  c->rebuildRatio = RT_REFIT_REBUILD_RATIO; c->rebuildSteps = RT_REBUILD_STEPS;      // rtggx_set_refit_policy
   RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
   for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto& e : c->evTone) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
   for (int i = 0; i < RT_SETS; ++i) {
     RT_HIP(hipMalloc(&c->normalBuf[i], n * 4)); RT_HIP(hipMemset(c->normalBuf[i], 0, n * 4));
@@ -257,7 +223,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     const uint32_t tiles = ((width + 15) / 16) * ((height + 15) / 16);
     c->numBinsMax = tiles * 4u;
     if (c->numBinsMax < 64u) c->numBinsMax = 64u;            // room for rtggx_trace_rays batches on tiny frames
-    c->binSlots = getenv("RTGGX_BIN_SLOTS") && atoi(getenv("RTGGX_BIN_SLOTS")) == 128 ? RT_BIN : RT_BIN_MIN;      // (all-metal default materials: one ray per pixel)
+    c->binSlots = RT_BIN_MIN;      // (all-metal default materials: one ray per pixel; rtggx_update_frame grows the bins with the first metallic below 1)
     for (int i = 0; i < RT_SETS; ++i) {
       RT_HIP(hipMalloc(&c->rayQueueBuf[i], (size_t)c->numBinsMax * c->binSlots * sizeof(rt::RayRec)));
       RT_HIP(hipMalloc(&c->hitQueueBuf[i], (size_t)c->numBinsMax * c->binSlots * 8));
@@ -268,13 +234,13 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     c->binWork = c->binWorkBuf[0];
     for (int i = 0; i < RT_SETS; ++i) RT_HIP(hipMalloc(&c->splitListBuf[i], (size_t)RT_SPLIT_CAP * 4));
     c->selectSet(0);
-    c->splitWork = getenv("RTGGX_SPLIT_WORK") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_WORK")) : RT_SPLIT_WORK;
-    c->splitMaxShift = getenv("RTGGX_SPLIT_MAX_SHIFT") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_MAX_SHIFT")) : RT_SPLIT_MAX_SHIFT;
-    if (c->splitMaxShift > 3u) c->splitMaxShift = 3u;
+    c->splitWork = RT_SPLIT_WORK; c->splitMaxShift = RT_SPLIT_MAX_SHIFT;      // rtggx_debug_trace_split
     RT_HIP(hipMalloc(&c->dEnvMipOffset, 16 * 4)); RT_HIP(hipMemset(c->dEnvMipOffset, 0, 16 * 4));
     RT_HIP(hipMalloc(&c->dummyRecord, 128)); RT_HIP(hipMemset(c->dummyRecord, 0, 128));
   }
   RT_HIP(hipMalloc(&c->histReach, 4)); RT_HIP(hipMemset(c->histReach, 0, 4));
+  RT_HIP(hipMalloc(&c->exchangeTokens, 4 * 2 * RT_MAX_PEERS)); RT_HIP(hipMemset(c->exchangeTokens, 0, 4 * 2 * RT_MAX_PEERS));
+  RT_HIP(hipMalloc(&c->dPeerTable, sizeof(void*) * 2 * RT_MAX_PEERS + 4 * (RT_MAX_PEERS + 1))); RT_HIP(hipMemset(c->dPeerTable, 0, sizeof(void*) * 2 * RT_MAX_PEERS + 4 * (RT_MAX_PEERS + 1)));
   RT_HIP(hipMalloc(&c->sh, 27 * 4)); RT_HIP(hipMemset(c->sh, 0, 27 * 4));
   RT_HIP(hipMalloc(&c->cosSinTab, 512 * 4));
   RT_HIP(hipMalloc(&c->dParams, RT_SLOTS * sizeof(FrameParams)));
@@ -303,9 +269,10 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
 
 void rtggx_destroy(rtggx_context* c) {
   if (!c) return;
-  if (getenv("RTGGX_TRACE_LOG")) fprintf(stderr, "[rtggx] tone maps put aside: %u, launched beside the next frame: %u\n", c->toneAsideCount, c->toneBesideCount);
   hipSetDevice(c->device);
   hipDeviceSynchronize();
+  for (void* p : c->ipcMapped) hipIpcCloseMemHandle(p);
+  hipFree(c->dPeerTable); hipFree(c->exchangeTokens);
   for (auto& m : c->mesh) {
     freeMeshVerts(m); freeBuildProducts(m);
     hipFree(m.indices); hipFree(m.dCost); if (m.hCost) hipHostFree(m.hCost); if (m.evCost) hipEventDestroy(m.evCost);
@@ -322,18 +289,17 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->kevBegin) hipEventDestroy(e);
   for (auto& e : c->kevEnd) hipEventDestroy(e);
   for (auto& e : c->tev) hipEventDestroy(e);
-  hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e); for (auto e : c->evTone) hipEventDestroy(e);
+  hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->ownAS); if (c->ownVis) hipStreamDestroy(c->ownVis);
   hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit); hipEventDestroy(c->evGen); for (auto e : c->evTraceRing) hipEventDestroy(e);
   if (c->streamRefit) hipStreamDestroy(c->streamRefit);
-  if (c->streamExchange) { hipStreamDestroy(c->streamExchange); hipEventDestroy(c->evExchange); hipEventDestroy(c->evFrameEnd); }
   delete c;
 }
 
 int rtggx_set_strip(rtggx_context* c, uint32_t rowBegin, uint32_t rowEnd) {
   RT_CHECK_CTX(c);
   if (rowBegin > rowEnd || rowEnd > c->H) { setError("rtggx_set_strip: bad rows [%u,%u) for height %u", rowBegin, rowEnd, c->H); return -1; }
-  c->rowBegin = rowBegin; c->rowEnd = rowEnd;
+  c->rowBegin = rowBegin; c->rowEnd = rowEnd; c->toneMapDone = false;
   return 0;
 }
 
@@ -363,47 +329,65 @@ int rtggx_set_stream(rtggx_context* c, void* stream) {
   return 0;
 }
 
-// Multi-GPU strips: the exchange of history rows between two frames on a stream of its own.  Issued on the main stream (rtggx_get_stream)
-// the exchange -- an RCCL group of sends and receives, ~30 us on its stream -- sits in the main stream's chain between the tone map of
-// frame f and the SHADING of frame f + 1, although only the temporal pass of frame f + 1 needs what it delivers: the slowest of 8 strips of
-// the 1080p frame 0.077 -> 0.109 ms (profiles/r03_h_strip_projection.txt).  So the caller may put it on the context's exchange stream:
-//     rtggx_tone_map(f); rtggx_exchange_begin(ctx);  <sends / receives on the exchange stream>;  rtggx_exchange_end(ctx);
-// begin orders the exchange stream behind frame f's last kernel; end records where the exchange ends, and the temporal pass of frame f + 1
-// (nothing before it) waits for that.  The tone map of frame f + 1 -- which overwrites the back-buffer rows the exchange may still be
-// sending -- follows the temporal pass on the main stream; the H pass of frame f + 2, which reuses the history image as its scratch, too.
-int rtggx_get_exchange_stream(rtggx_context* c, void** stream) {
+// Multi-GPU strips: the history images of ALL ranks, mapped into this process, for the temporal pass's taps beyond the exchanged apron
+// ("N-strip output == 1-strip output on every buffer"; the reference samples its one history texture anywhere,
+// CSTemporalSS.hlsl:259-265).  Every rank allocates full-size targets, so rank r's TemporalSSOut[p] holds the rows r owns at the same
+// offsets as this rank's own image does; a tap at row y outside [b - apron, e + apron) is read from the image of the rank whose strip
+// holds y.  `bounds`: world + 1 ascending rows (rank r owns [bounds[r], bounds[r + 1])); tss0 / tss1: world device pointers each, valid in
+// THIS process -- another context's rtggx_buffer_ptr in the same process, or what rtggx_history_ipc_open returned for another process's
+// rtggx_history_ipc_export.  The entries of this rank itself may be its own pointers or null.
+// ORDERING is the caller's, and the per-frame exchange already provides it where it has a message in each direction between two ranks
+// (include/rtggx.h): rank A's temporal pass of frame f + 1 may read rank B's image once B's temporal pass of frame f has ended (A's
+// receive from B in the exchange of frame f), and B's H filter of frame f + 2, which reuses that image as scratch, waits for A's temporal
+// pass of frame f + 1 (B's receive from A in the exchange of frame f + 1) -- both on the main streams the exchange is issued on.
+int rtggx_set_history_peers(rtggx_context* c, uint32_t world, const uint32_t* bounds, void* const* tss0, void* const* tss1) {
   RT_CHECK_CTX(c);
-  if (!stream) { setError("rtggx_get_exchange_stream: null"); return -1; }
-  if (!c->streamExchange) {
-    int prioLeast = 0, prioGreatest = 0;
-    RT_HIP(hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
-    RT_HIP(hipStreamCreateWithPriority(&c->streamExchange, hipStreamNonBlocking, prioGreatest));      // on the history's critical cycle: temporal f -> exchange f -> temporal f + 1
-    RT_HIP(hipEventCreateWithFlags(&c->evExchange, hipEventDisableTiming)); RT_HIP(hipEventCreateWithFlags(&c->evFrameEnd, hipEventDisableTiming));
+  if (world == 0u) { RT_HIP(syncStreams(c)); c->peerWorld = 0u; return 0; }
+  if (world > RT_MAX_PEERS || !bounds || !tss0 || !tss1) { setError("rtggx_set_history_peers: 1 .. %d ranks, boundaries and two pointer lists", RT_MAX_PEERS); return -1; }
+  if (bounds[0] != 0u || bounds[world] != c->H) { setError("rtggx_set_history_peers: boundaries must run from 0 to the frame height %u", c->H); return -1; }
+  for (uint32_t r = 0; r < world; ++r) if (bounds[r] > bounds[r + 1]) { setError("rtggx_set_history_peers: boundaries must ascend"); return -1; }
+  RT_HIP(syncStreams(c));
+  struct { const void* tss[2][RT_MAX_PEERS]; uint32_t bounds[RT_MAX_PEERS + 1]; } table;
+  memset(&table, 0, sizeof table);
+  for (uint32_t r = 0; r < world; ++r) {
+    const bool own = bounds[r] <= c->rowBegin && c->rowEnd <= bounds[r + 1] && c->rowEnd > c->rowBegin;
+    table.tss[0][r] = tss0[r] ? tss0[r] : own ? (void*)c->tss[0] : nullptr; table.tss[1][r] = tss1[r] ? tss1[r] : own ? (void*)c->tss[1] : nullptr;
+    if (bounds[r + 1] > bounds[r] && (!table.tss[0][r] || !table.tss[1][r])) { setError("rtggx_set_history_peers: no history images for rank %u", r); return -1; }
   }
-  flushToneMap(c); c->callerOrdersOnMain = true;      // the caller consumes the frame outside the library: the tone map stays on the main stream (see rtggx_get_stream)
-  *stream = (void*)c->streamExchange;
+  for (uint32_t r = 0; r <= world; ++r) table.bounds[r] = bounds[r];
+  for (uint32_t r = world + 1; r <= RT_MAX_PEERS; ++r) table.bounds[r] = c->H;
+  static_assert(sizeof table == sizeof(void*) * 2 * RT_MAX_PEERS + 4 * (RT_MAX_PEERS + 1) + 4 || sizeof table == sizeof(void*) * 2 * RT_MAX_PEERS + 4 * (RT_MAX_PEERS + 1), "peer table layout");
+  RT_HIP(hipMemcpy(c->dPeerTable, &table, sizeof(void*) * 2 * RT_MAX_PEERS + 4 * (RT_MAX_PEERS + 1), hipMemcpyHostToDevice));
+  c->peerWorld = world;
   return 0;
 }
-int rtggx_exchange_begin(rtggx_context* c) {
+// One process per GPU: the two history images as inter-process handles (2 x 64 bytes: hipIpcMemHandle_t of TemporalSSOut[0], [1]) ...
+int rtggx_history_ipc_export(rtggx_context* c, void* handles, size_t bytes) {
   RT_CHECK_CTX(c);
-  if (!c->streamExchange) { setError("rtggx_exchange_begin: rtggx_get_exchange_stream has not been called"); return -1; }
-  flushToneMap(c);
-  if (c->lastFrameSet >= 0 && c->setReadRecorded[c->lastFrameSet]) RT_HIP(hipStreamWaitEvent(c->streamExchange, c->evSetRead[c->lastFrameSet], 0));      // rides on the frame's last kernel
-  else { RT_HIP(hipEventRecord(c->evFrameEnd, c->streamMain)); RT_HIP(hipStreamWaitEvent(c->streamExchange, c->evFrameEnd, 0)); }
+  static_assert(sizeof(hipIpcMemHandle_t) == RTGGX_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  if (!handles || bytes < 2 * sizeof(hipIpcMemHandle_t)) { setError("rtggx_history_ipc_export: room for two %zu-byte handles", sizeof(hipIpcMemHandle_t)); return -1; }
+  hipIpcMemHandle_t h[2];
+  for (int p = 0; p < 2; ++p) RT_HIP(hipIpcGetMemHandle(&h[p], c->tss[p]));
+  memcpy(handles, h, sizeof h);
   return 0;
 }
-int rtggx_exchange_end(rtggx_context* c) {
+// ... and another rank's handles opened in this process: two device pointers for rtggx_set_history_peers (unmapped by rtggx_destroy).
+int rtggx_history_ipc_open(rtggx_context* c, const void* handles, size_t bytes, void** tss0, void** tss1) {
   RT_CHECK_CTX(c);
-  if (!c->streamExchange) { setError("rtggx_exchange_end: rtggx_get_exchange_stream has not been called"); return -1; }
-  RT_HIP(hipEventRecord(c->evExchange, c->streamExchange));
-  c->exchangePending = true;
+  if (!handles || bytes < 2 * sizeof(hipIpcMemHandle_t) || !tss0 || !tss1) { setError("rtggx_history_ipc_open: bad arguments"); return -1; }
+  hipIpcMemHandle_t h[2]; memcpy(h, handles, sizeof h);
+  void* p[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; ++k) {
+    RT_HIP(hipIpcOpenMemHandle(&p[k], h[k], hipIpcMemLazyEnablePeerAccess));
+    c->ipcMapped.push_back(p[k]);
+  }
+  *tss0 = p[0]; *tss1 = p[1];
   return 0;
 }
 
 int rtggx_get_stream(rtggx_context* c, void** stream) {
   RT_CHECK_CTX(c);
   if (!stream) { setError("rtggx_get_stream: null"); return -1; }
-  flushToneMap(c); c->callerOrdersOnMain = true;      // the caller will order work of its own behind the frame on this stream: the tone map stays on it from now on
   *stream = (void*)c->streamMain;
   return 0;
 }
@@ -498,6 +482,7 @@ int rtggx_refit_as(rtggx_context* c, uint32_t slot, const float* verts, uint32_t
     }
     for (int i = 0; i < RT_SLOTS; ++i) m.stage[i] = st[i];
     { const int r = splitBvhPerSet(c, slot); if (r) return r; }
+    { const int r = prepareRebuild(c, slot); if (r) return r; }      // the second topology and the build's scratch memory: not in the frame loop
     // A device-to-device hipMemcpy does NOT wait on the host (only its issue is synchronous) and runs on the null stream, which the
     // non-blocking streams of this context are not ordered against: the next frame's refit on stream R wrote a set's nodes while the copy
     // of the OLD nodes into the same array was still on its way, and the copy landed last (found once GPU_MAX_HW_QUEUES=8 gave the null
@@ -553,25 +538,23 @@ static int splitBvhPerSet(rtggx_context* c, uint32_t slot) {
 }
 
 // Issued by rtggx_render_visibility once the new input set is selected and fenced: bring the set's vertex buffer up to date and
-// refit.  Everything on stream B; returns true in *touched when stream B was given work the visibility pass must follow.
+// refit -- everything on stream R; *touched: stream R was given work the visibility pass and the traversal must follow (evRefit, recorded
+// HERE, right behind the refit).  A rebuild beside the frames gets its next launches only after that: they read the snapshot and write
+// the job's own topology, nobody waits for them, and they must not sit between a frame's refit and the event its visibility pass and
+// traversal wait for (round 3 issued them in front: while a rebuild was in progress every frame stalled behind 16 build launches, the
+// single-workgroup plocFinal among them).
 static int issuePendingRefits(rtggx_context* c, bool* touched) {
   *touched = false;
   const hipStream_t s = c->asyncCompute ? c->streamRefit : c->streamMain;
-  const uint32_t stepsPerFrame = c->rebuildSteps;
+  bool swapped[RTGGX_NUM_MESH] = {};
   for (uint32_t slot = 0; slot < RTGGX_NUM_MESH; ++slot) {
     MeshDev& m = c->mesh[slot];
     if (!m.deforming) continue;
-    // a rebuild beside the frames: has it ended (then this frame's refit is the first on the new topology)?  otherwise its next launches
-    bool swapped = false;
-    { const int r = continueRebuild(c, slot, s, stepsPerFrame, &swapped); if (r) return r; }
+    // has a rebuild whose launches are all out ended?  then this frame's refit is the first on the new topology
+    { const int r = continueRebuild(c, slot, s, 0u, &swapped[slot]); if (r) return r; }
     const size_t bytes = sizeof(float) * 6 * (size_t)m.numVerts;
     const uint32_t set = c->setIndex;
     bool refit = true;
-    // MEASUREMENT (profiles/r03_i_deform_states.txt): hold this frame's refit until the previous frame's ray generation has ended (1) or its
-    // traversal has ended (2), instead of letting it start whenever the host gets to issue it
-    static const int refitPhase = getenv("RTGGX_REFIT_PHASE") ? atoi(getenv("RTGGX_REFIT_PHASE")) : 0;
-    if (refitPhase == 1 && c->asyncCompute && c->genStream && c->frameCounter > 1u) hipStreamWaitEvent(s, c->evGen, 0);
-    if (refitPhase == 2 && c->asyncCompute && c->traceRecorded[(c->frameCounter + 3u) & 3u]) hipStreamWaitEvent(s, c->evTraceRing[(c->frameCounter + 3u) & 3u], 0);
     if (m.pendingStage >= 0) {
       RT_HIP(hipMemcpyAsync(m.vertsBuf[set], m.stage[m.pendingStage], bytes, hipMemcpyHostToDevice, s));
       m.pendingStage = -1; ++m.version;
@@ -584,11 +567,18 @@ static int issuePendingRefits(rtggx_context* c, bool* touched) {
       if (r) return r;
       *touched = true;
     }
-    if (m.wantRebuild && !swapped) {      // (the cost that asked for it was the old topology's)
+  }
+  if (*touched && c->asyncCompute) RT_HIP(hipEventRecord(c->evRefit, s));
+  for (uint32_t slot = 0; slot < RTGGX_NUM_MESH; ++slot) {
+    MeshDev& m = c->mesh[slot];
+    if (!m.deforming) continue;
+    bool sw = false;
+    if (m.wantRebuild && !swapped[slot]) {      // (the cost that asked for it was the old topology's)
       const int r = startRebuild(c, slot, m.latestSet);
       if (r < 0) return r;
-      if (r == 1) { m.wantRebuild = false; bool sw; const int r2 = continueRebuild(c, slot, s, stepsPerFrame, &sw); if (r2) return r2; }      // its first launches: the copy of the vertices it starts from
-    } else if (swapped) m.wantRebuild = false;
+      if (r == 1) m.wantRebuild = false;
+    } else if (swapped[slot]) m.wantRebuild = false;
+    { const int r = continueRebuild(c, slot, s, c->rebuildSteps, &sw); if (r) return r; }      // the next launches of a build in progress (the first ones of one just started: the copy of the vertices it starts from)
   }
   return 0;
 }
@@ -659,83 +649,79 @@ int rtggx_transform_sh(rtggx_context* c) {
 // streams, each stage one frame behind the one before it:
 //     stream C   visibility pass (its first kernel carries the frame constants) -> ray generation        of frame f + 1
 //     stream B   traversal                                                                                of frame f
-//     main       hit / miss shading -> spatial filters -> temporal pass -> tone map                       of frame f - 1
+//     main       hit / miss shading -> spatial filters -> temporal pass + tone map                        of frame f - 1
 // plus stream R for the vertex upload and tree refit of a deforming mesh.  No stage fills the machine by itself (the traversal
-// is a latency-bound chain of dependent gathers with 2.5 waves per SIMD resident on average: profiles/r02_*_limiter.txt), so
-// the three overlap almost freely; what each stage hands to the next exists three times (the input sets), and the events are
-//     evVis / stream order   visibility -> ray generation (same stream)
+// is a latency-bound chain of dependent gathers: profiles/r02_*_limiter.txt), so the three overlap; what each stage hands to the next
+// exists four times (the input sets), and the events are
+//     stream order           visibility -> ray generation (same stream)
 //     evGen                  ray generation f    -> traversal f                (C -> B)
 //     evTraceRing[f & 3]     traversal f         -> shading f                  (B -> main)
 //                            traversal f - 2     -> ray generation f           (B -> C: the bins' cost record and the ray counters
 //                                                                               exist twice, by frame parity)
 //     evRefit                refit f             -> visibility f, traversal f  (R -> C, B)
-//     evSetRead[set]         last reader of a set -> the HOST, three frames later (the sample's frames-in-flight fence)
-// RTGGX_PIPELINE=0 restores the round-1 arrangement: ray generation and traversal both on stream B, the visibility pass on stream C
-// only where launches are small.  rtggx_set_async_compute(0) puts everything on the main stream.
+//     evSetRead[set]         last reader of a set -> the HOST, four frames later (the sample's frames-in-flight fence)
+// rtggx_set_async_compute(0) (the sample's [A] toggle) puts everything on the main stream.
+//
+// WHERE a frame's kernels go is decided in ONE place, placeFrame, from a key of five facts (round 4: rounds 2-3 had grown nine
+// interacting switches for it).  The table, each line measured in the round that introduced it (DESIGN.md sections 5, 7, 9):
+//     key                              ray generation   traversal            hit shading       frames in flight
+//     full-size launch                 C                B                    main              4
+//       + a mesh deforms / diffuse rays                                                        3   (the front stages otherwise run ahead into one of two states)
+//     small launch (< 200 000 rays)    C                B, odd frames on R   the traversal's   4   (two traversals in flight; the main stream's chain is a strip's longest)
+//       + a mesh deforms               C                B                    main              4   (R is the refit's)
+//     strip / caller-owned stream      no line of their own: rows and the main stream's identity do not move a kernel
+//     async compute off                main             main                 main              4
+struct Placement {
+  bool small, strip, deforming, diffuse, callerStream;      // the key
+  hipStream_t gen, trace, shade;
+  uint32_t framesInFlight;
+  bool alternate, shadeWithTrace;
+};
+static Placement placeFrame(const rtggx_context* c, const FrameParams& fp, uint32_t frame) {
+  Placement P;
+  P.small = c->lastTraceSmall;      // by the ray count of the most recent frame whose count has arrived (raytrace.hip launchRayTrace; rtggx_debug_placement)
+  P.strip = fp.rowBegin > 0u || fp.rowEnd < fp.H;
+  P.deforming = c->mesh[0].deforming || c->mesh[1].deforming;
+  P.diffuse = fp.mat.RoughMetals[0][1] < 1.0f || fp.mat.RoughMetals[1][1] < 1.0f;
+  P.callerStream = c->externalStream;
+  const bool async = c->asyncCompute && c->streamVis != nullptr;
+  P.gen = async ? c->streamVis : c->streamMain;
+  P.alternate = async && c->streamRefit != nullptr && P.small && !P.deforming && (frame & 1u) != 0u;
+  P.trace = !async ? c->streamMain : P.alternate ? c->streamRefit : c->streamAS;
+  P.shadeWithTrace = async && c->attachEvents && !c->timing && P.small && !P.deforming;
+  P.shade = P.shadeWithTrace ? P.trace : c->streamMain;
+  P.framesInFlight = async && !P.small && (P.deforming || P.diffuse) ? RT_SETS - 1u : RT_SETS;
+  return P;
+}
+
+static int waitForSet(rtggx_context* c, uint32_t set) {
+  if (c->setReadRecorded[set] && hipEventQuery(c->evSetRead[set]) != hipSuccess) {
+    const auto t0 = std::chrono::steady_clock::now();
+    RT_HIP(hipEventSynchronize(c->evSetRead[set]));
+    c->fenceWaitUs += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++c->fenceWaits;      // rtggx_debug_fence_wait
+  }
+  return 0;
+}
+
 int rtggx_render_visibility(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_render_visibility: no frame constants"); return -1; }
   if (!c->shDone && c->env.texels) { const int r = projectSH(c, c->streamAS); if (r) return r; }   // first frame only, RayTracer.cpp:345-350
   settleSetRead(c);      // (the previous frame ended without the kernel that would have carried its set's event)
   ++c->frameCounter;
-  c->denoiseIssued = false;
+  c->denoiseIssued = false; c->toneMapDone = false;
   c->selectSet((c->setIndex + 1u) % RT_SETS);
-  // the set was last read three frames ago: normally long done; a host that has run further ahead than that waits here (also what makes
+  // the set was last read four frames ago: normally long done; a host that has run further ahead than that waits here (also what makes
   // it safe for this frame's ray generation to clear the NEXT frame's visibility target: rtggx_context.h RT_VIS_RING)
-  if (c->setReadRecorded[c->setIndex] && hipEventQuery(c->evSetRead[c->setIndex]) != hipSuccess) {
-    const auto t0 = std::chrono::steady_clock::now();
-    RT_HIP(hipEventSynchronize(c->evSetRead[c->setIndex]));
-    c->fenceWaitUs += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++c->fenceWaits;      // rtggx_debug_fence_wait
-  }
-  // A mesh that deforms on a full-size frame: THREE frames in flight, not four -- the host also waits for the end of frame f - 3.  With four,
-  // the stages in front (refit, visibility, ray generation, traversal) run ahead of the main stream as far as the sets allow, and the
-  // pipeline settles, whenever it fills, into one of two states: the deforming bunny at 1080p 0.212-0.219 ms per frame or 0.26-0.30, in
-  // 50-frame windows -8 / +29 % around a mean of 0.231; the deforming dragon 0.25-0.34 at 1080p.  With three there is one state: bunny
-  // 0.220-0.238 (mean 0.228: the model breathes, the work changes with it), dragon 1080p 0.238-0.282 (mean 0.263 against 0.301), dragon
-  // 4K a smooth curve 0.72-1.07 along the animation (mean 0.87 against 0.89-0.91, no window above 1.07 where there were 1.24).  Small
-  // launches and static meshes keep four (static 1080p 0.184 -> 0.196 with three, the deforming bunny at 640x360 0.128 -> 0.137).
-  // profiles/r03_i_deform_states.txt; RTGGX_FENCE_FRAMES overrides (1 .. RT_SETS).
-  { static const int forced = getenv("RTGGX_FENCE_FRAMES") ? atoi(getenv("RTGGX_FENCE_FRAMES")) : 0;
-    const bool deformingNow = c->mesh[0].deforming || c->mesh[1].deforming;
-    // ... and the same for frames that trace DIFFUSE rays (a material with metallic below 1: two rays per covered pixel, the traversal
-    // is the frame's longest stage by far): the dragon with diffuse rays 0.375-0.459 ms in five runs with four frames in flight (the
-    // "size trial that settles in most runs, not all" of round 2), 0.381-0.387 with three; only the model diffuse 0.305-0.343 -> 0.305-0.306;
-    // the bunny 0.302-0.312 -> 0.301-0.304; at 4K 1.140-1.154 -> 1.139-1.140.
-    const FrameParams& cur = c->slots[c->slot];
-    const bool diffuseNow = cur.mat.RoughMetals[0][1] < 1.0f || cur.mat.RoughMetals[1][1] < 1.0f;
-    const uint32_t inFlight = forced >= 1 && forced <= RT_SETS ? (uint32_t)forced
-                            : ((deformingNow || diffuseNow) && !c->lastTraceSmall && c->pipeline != 0 && c->asyncCompute) ? RT_SETS - 1u : RT_SETS;
-    if (inFlight < RT_SETS) {
-      const uint32_t idx = (c->setIndex + RT_SETS - inFlight) % RT_SETS;      // the set of frame f - inFlight
-      if (c->setReadRecorded[idx] && hipEventQuery(c->evSetRead[idx]) != hipSuccess) {
-        const auto t0 = std::chrono::steady_clock::now();
-        RT_HIP(hipEventSynchronize(c->evSetRead[idx]));
-        c->fenceWaitUs += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++c->fenceWaits;
-      }
-    } }
+  { const int r = waitForSet(c, c->setIndex); if (r) return r; }
+  const Placement P = placeFrame(c, c->slots[c->slot], c->frameCounter);
+  // THREE frames in flight where the table says so: the host also waits for the end of frame f - 3 (profiles/r03_i_deform_states.txt:
+  // with four, the deforming bunny at 1080p ran at 0.212-0.219 or 0.26-0.30 ms per frame, a run fell into one state; with three 0.220-0.238)
+  if (P.framesInFlight < RT_SETS) { const int r = waitForSet(c, (c->setIndex + RT_SETS - P.framesInFlight) % RT_SETS); if (r) return r; }
   c->refitIssued = false;
   { const int r = issuePendingRefits(c, &c->refitIssued); if (r) return r; }
-  if (c->refitIssued && c->asyncCompute) RT_HIP(hipEventRecord(c->evRefit, c->streamRefit));
-  const bool pipelined = c->pipeline != 0 && c->streamVis != nullptr;
-  hipStream_t s;
-  bool small = false;
-  if (pipelined) s = c->streamVis;
-  else {
-    // Round-1 arrangement: on stream C when the launches are small (few enough rays that the machine is not saturated), on
-    // stream B otherwise; with diffuse rays the main stream is the longer chain and the extra stream costs 1-2 %, so beyond small
-    // launches it is used for all-metal frames only.
-    static const uint32_t visRays = getenv("RTGGX_VIS_STREAM_RAYS") ? (uint32_t)atoi(getenv("RTGGX_VIS_STREAM_RAYS")) : RT_VIS_STREAM_RAYS;
-    const FrameParams& cur = c->slots[c->slot];
-    const bool allMetal = !(cur.mat.RoughMetals[0][1] < 1.0f || cur.mat.RoughMetals[1][1] < 1.0f);
-    small = c->streamVis && (chooseSliceShift(c, true, c->numBinsMax) != 0u || (allMetal && c->lastFrameRays < visRays));
-    s = small ? c->streamVis : c->streamAS;
-  }
-  if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on the other stream
-  // MEASUREMENT (profiles/r03_b_sync_pipeline.txt): the three stages in lock step -- stage C of frame f does not start before the main
-  // stream's chain of frame f - 3 has ended, the traversal of frame f not before that of frame f - 2 (rtggx_ray_trace): what a frame
-  // submitted as ONE graph of three branches per iteration would do to the GPU side.
-  static const bool syncPipe = getenv("RTGGX_SYNC_PIPE") && atoi(getenv("RTGGX_SYNC_PIPE")) != 0;
-  if (syncPipe && pipelined && c->setReadRecorded[(c->setIndex + 1u) % RT_SETS]) RT_HIP(hipStreamWaitEvent(s, c->evSetRead[(c->setIndex + 1u) % RT_SETS], 0));
+  const hipStream_t s = P.gen;
+  if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on another stream
   // constants already on their way on stream B (timing mode uploads them in rtggx_update_as): a pass on stream C reads
   // dParams[slot] and has to be ordered behind that upload (evAS); on stream B it follows it anyway
   if (c->slotUploaded && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evAS, 0));
@@ -744,8 +730,7 @@ int rtggx_render_visibility(rtggx_context* c) {
   const int r = launchVisibility(c, c->slots[c->slot], s, c->streamVis ? c->evVis : nullptr);
   if (c->streamVis) c->evVisStream = s;
   if (c->timing) hipEventRecord(c->tev[13], s);
-  if (small) RT_HIP(hipStreamWaitEvent(c->streamAS, c->evVis, 0));
-  c->genStream = pipelined ? c->streamVis : c->streamAS;
+  c->genStream = s;
   return r;
 }
 
@@ -756,22 +741,20 @@ int rtggx_ray_trace(rtggx_context* c) {
   if (c->sceneDirty) { const int r = uploadScene(c, c->streamAS); if (r) return r; }
   { const int r = ensureParams(c); if (r) return r; }
   const uint32_t f = c->frameCounter;
-  const hipStream_t sGen = c->genStream ? c->genStream : c->streamAS;
-  // Launches with few rays (thin strips, small frames) last as long as their longest chain of dependent traversal steps and leave
-  // most of the chip idle meanwhile: the traversals of odd frames go to a second stream, so that two of them can be in flight
-  // (the slowest of the eight strips of the 1080p frame: 0.107 -> 0.081 ms; profiles/r02_l_strip_projection.txt).
-  // Everything a traversal shares with its neighbours in time is per input set, per frame parity or per frame & 3, and everybody
-  // who needs its results waits for its event, not for its stream; the stack spill area exists twice (launchTrace).
-  // The second stream is the refit stream, idle unless a mesh deforms: a FIFTH stream would share one of the four hardware queues
-  // with another one (measured: the deforming bunny went from 0.22 to 0.40 ms per frame when a fifth stream merely existed).
-  // (Round 3, with eight hardware queues configured: a THIRD traversal stream, so that three traversals are in flight, loses everywhere --
-  // 1920 x 171 0.053 -> 0.086 ms per frame, 1920 x 400 0.083 -> 0.112, the slowest of eight 1080p strips 0.083 -> 0.081 with every
-  // other strip slower: beyond four streams with work on them the queues take turns.  profiles/r03_c_strip_chain.txt)
-  static const bool twoTraceStreams = !(getenv("RTGGX_TRACE_STREAMS") && atoi(getenv("RTGGX_TRACE_STREAMS")) == 1);
-  const bool deforming = c->mesh[0].deforming || c->mesh[1].deforming;
-  const bool alternate = twoTraceStreams && c->pipeline != 0 && c->asyncCompute && sGen != c->streamAS && c->streamRefit != nullptr && !deforming && c->lastTraceSmall && (f & 1u) != 0u;
-  const hipStream_t sTrace = alternate ? c->streamRefit : c->streamAS;
-  c->traceSpillHalf = alternate ? 1u : 0u;
+  const FrameParams& fp = c->slots[c->slot];
+  const Placement P = placeFrame(c, fp, f);
+  c->lastPlacement[0] = P.small | (P.strip << 1) | (P.deforming << 2) | (P.diffuse << 3) | (P.callerStream << 4);
+  const auto streamId = [&](hipStream_t st) { return st == c->streamMain ? 0u : st == c->streamAS ? 1u : st == c->streamVis ? 2u : st == c->streamRefit ? 3u : 4u; };
+  c->lastPlacement[1] = streamId(P.gen) | (streamId(P.trace) << 4) | (streamId(P.shade) << 8) | (P.framesInFlight << 12);
+  // a caller that skipped the visibility pass traces on the placement's streams all the same
+  const hipStream_t sGen = c->genStream ? c->genStream : P.gen;
+  // Small launches last as long as their longest chain of dependent traversal steps and leave most of the chip idle meanwhile: the
+  // traversals of odd frames go to a second stream (R, idle unless a mesh deforms), so that two are in flight.  Everything a traversal
+  // shares with its neighbours in time is per input set, per frame parity or per frame & 3, and everybody who needs its results waits
+  // for its event, not for its stream; the stack spill area exists twice (launchTrace).  (A third traversal stream loses everywhere:
+  // beyond four streams with work on them the queues take turns; profiles/r03_c_strip_chain.txt.)
+  const hipStream_t sTrace = P.trace;
+  c->traceSpillHalf = P.alternate ? 1u : 0u;
   if (sGen != sTrace) {
     // ray generation reads the cost record of the traversal two frames back and resets that frame's ray counters (frame parity)
     if (c->traceRecorded[(f + 2u) & 3u]) RT_HIP(hipStreamWaitEvent(sGen, c->evTraceRing[(f + 2u) & 3u], 0));
@@ -779,70 +762,46 @@ int rtggx_ray_trace(rtggx_context* c) {
     if (c->slotUploaded) RT_HIP(hipStreamWaitEvent(sGen, c->evAS, 0));
   }
   if (c->refitIssued && c->asyncCompute) RT_HIP(hipStreamWaitEvent(sTrace, c->evRefit, 0));      // this set's tree
-  { static const bool syncPipe = getenv("RTGGX_SYNC_PIPE") && atoi(getenv("RTGGX_SYNC_PIPE")) != 0;      // see rtggx_render_visibility
-    if (syncPipe && c->pipeline != 0 && c->setReadRecorded[(c->setIndex + 2u) % RT_SETS]) RT_HIP(hipStreamWaitEvent(sTrace, c->evSetRead[(c->setIndex + 2u) % RT_SETS], 0)); }
   if (c->timing) hipEventRecord(c->tev[3], sGen);
   hipEvent_t evDone = c->evTraceRing[f & 3u];
-  // Small launches: the hit shading runs on the TRAVERSAL's stream, behind the trace kernel, not on the main stream.  The main stream's
-  // chain (shading, two filters, temporal pass, tone map) is the longest stage of a thin strip's frame, and the two traversal streams
-  // alternate, so theirs may be twice as long: 1920 x 171 0.060 -> 0.052 ms per frame (the stand-in model of
-  // tools/microbench/frame_graph.hip: 60.9 -> 49.1 us; profiles/r03_c_strip_chain.txt).  The event the main stream -- and ray generation
-  // two frames on -- waits for then rides on the shading kernel.  Full-size frames keep the shading on the main stream: there the
-  // traversal is the longest kernel of the frame and its stream has the low priority.
-  static const bool shadeBesideTrace = !(getenv("RTGGX_SHADE_WITH_TRACE") && atoi(getenv("RTGGX_SHADE_WITH_TRACE")) == 0);
-  static const uint32_t shadeRays = getenv("RTGGX_SHADE_WITH_TRACE_RAYS") ? (uint32_t)atoi(getenv("RTGGX_SHADE_WITH_TRACE_RAYS")) : RT_WIDE_RAYS;
-  const bool shadeWithTrace = shadeBesideTrace && c->pipeline != 0 && c->asyncCompute && c->attachEvents && !c->timing && sTrace != c->streamMain && sGen != sTrace && !deforming && c->lastTraceSmall
-                              && c->lastFrameRays < shadeRays;
-  // who carries RayTracingOut1 over from the previous set where this frame traces no diffuse ray (raytrace.hip launchShade)
-  static const bool genMayCarry = !(getenv("RTGGX_GEN_CARRIES_DIFF") && atoi(getenv("RTGGX_GEN_CARRIES_DIFF")) == 0);
-  { const FrameParams& fpNow = c->slots[c->slot];
-    const bool diffuseNow = fpNow.mat.RoughMetals[0][1] < 1.0f || fpNow.mat.RoughMetals[1][1] < 1.0f;
-    // back to ray generation after frames with diffuse rays: once, ray generation waits for the previous frame's shading kernel (one
-    // bubble in the pipeline), so that the previous set's image is final when it reads it
-    if (genMayCarry && c->shadeWroteDiff && !diffuseNow && !c->lastFrameDiffuse && c->shadeStream) {
-      if (c->shadeStream != sGen) { RT_HIP(hipEventRecord(c->evRT, c->shadeStream)); RT_HIP(hipStreamWaitEvent(sGen, c->evRT, 0)); }
-      c->shadeWroteDiff = false;
-    }
-    c->lastFrameDiffuse = diffuseNow; }
-  c->genCarriesDiff = genMayCarry && !c->shadeWroteDiff;
-  int r = launchRayTrace(c, c->slots[c->slot], sGen, sTrace, shadeWithTrace ? nullptr : evDone);
+  const bool shadeWithTrace = P.shadeWithTrace && sGen != sTrace && sTrace != c->streamMain;
+  // who carries RayTracingOut1 over from the previous set where this frame traces no diffuse ray (raytrace.hip launchShade): ray
+  // generation, unless the previous frame's shading kernel wrote into that set's image -- then, once, ray generation waits for it
+  // (one bubble in the pipeline), so that the previous set's image is final when it reads it
+  if (c->shadeWroteDiff && !P.diffuse && !c->lastFrameDiffuse && c->shadeStream) {
+    if (c->shadeStream != sGen) { RT_HIP(hipEventRecord(c->evRT, c->shadeStream)); RT_HIP(hipStreamWaitEvent(sGen, c->evRT, 0)); }
+    c->shadeWroteDiff = false;
+  }
+  c->lastFrameDiffuse = P.diffuse;
+  c->genCarriesDiff = !c->shadeWroteDiff;
+  int r = launchRayTrace(c, fp, sGen, sTrace, shadeWithTrace ? nullptr : evDone);
   c->traceRecorded[f & 3u] = true;
   c->lastRayCounter32 = c->rayCounter32;
-  { const FrameParams& fpNow = c->slots[c->slot];
-    c->shadeWroteDiff = !c->genCarriesDiff || fpNow.mat.RoughMetals[0][1] < 1.0f || fpNow.mat.RoughMetals[1][1] < 1.0f; }
+  c->shadeWroteDiff = !c->genCarriesDiff || P.diffuse;
   if (shadeWithTrace) {
-    flushToneMap(c);      // (a tone map put aside by a full-size frame before waits for a shading kernel on the MAIN stream: none comes)
-    // the shading of frame f copies what it does not trace from the image of frame f - 1 (launchShade: diffPrev), which the other
-    // traversal stream's shading kernel wrote, or the main stream's if this is the first frame shaded here
+    // Small launches: the hit shading follows the traversal on ITS stream (the main stream's chain -- shading, two filters, temporal pass +
+    // tone map -- is the longest stage of a thin strip's frame, and the two traversal streams alternate, so theirs may be twice as long:
+    // 1920 x 171 0.060 -> 0.052 ms per frame, profiles/r03_c_strip_chain.txt); the event the main stream -- and ray generation two frames
+    // on -- waits for then rides on the shading kernel.  The shading of frame f copies what it does not trace from the image of frame
+    // f - 1, which the other traversal stream's shading kernel wrote, or the main stream's if this is the first frame shaded here.
     if (!c->genCarriesDiff && c->shadeStream && c->shadeStream != sTrace) {
       if (c->shadeStream == c->streamMain) { RT_HIP(hipEventRecord(c->evRT, c->streamMain)); RT_HIP(hipStreamWaitEvent(sTrace, c->evRT, 0)); }
       else if (c->traceRecorded[(f + 3u) & 3u]) RT_HIP(hipStreamWaitEvent(sTrace, c->evTraceRing[(f + 3u) & 3u], 0));
     }
-    if (!r) r = launchShade(c, c->slots[c->slot], sTrace, evDone);
+    if (!r) r = launchShade(c, fp, sTrace, evDone);
     c->shadeStream = sTrace;
     RT_HIP(hipStreamWaitEvent(c->streamMain, evDone, 0));
-    c->setReadDeferred = (int)c->setIndex;      // the main stream's kernels of this frame read the set after the shading: the last of them carries the set's event
   } else {
-    // stream B runs ahead with the traversal; shading and the denoiser consume the bins, the G-buffer and the traced images on
-    // the main stream (the event completes with the trace kernel; a shading kernel of the frame before on a traversal stream has been
-    // waited for by the main stream in its own frame)
+    // stream B runs ahead with the traversal; shading and the denoiser consume the bins, the G-buffer and the traced images on the main
+    // stream (the event completes with the trace kernel; a shading kernel of the frame before on a traversal stream has been waited for
+    // by the main stream in its own frame)
     RT_HIP(hipStreamWaitEvent(c->streamMain, evDone, 0));
-    // the main stream has now been given work that reads the current input set: that set may not be overwritten (three frames
-    // from now) before evSetRead, which completes with the shading kernel (and again with the denoiser's last one)
-    const bool carry = c->tonePending || !c->attachEvents;      // an aside tone map (below) waits for this kernel
-    if (!r) r = launchShade(c, c->slots[c->slot], c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr);
+    if (!r) r = launchShade(c, fp, c->streamMain, c->attachEvents ? nullptr : c->evSetRead[c->setIndex]);
     c->shadeStream = c->streamMain;
-    if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex;
   }
-  if (c->tonePending) {      // the previous frame's tone map: beside this frame's filters (rtggx_tone_map)
-    if (c->attachEvents && c->streamRefit != nullptr && !(c->mesh[0].deforming || c->mesh[1].deforming) && !alternate && c->streamMain == c->ownMain) {
-      c->tonePending = false;
-      RT_HIP(hipStreamWaitEvent(c->streamRefit, c->evSetRead[c->setIndex], 0));      // completes with the shading kernel just launched
-      const int rt2 = launchPreparedToneMap(c, c->tonePrepared, c->streamRefit, c->evTone[c->toneParity]);
-      if (rt2) return rt2;
-      c->toneRecorded[c->toneParity] = true; ++c->toneBesideCount;
-    } else flushToneMap(c);
-  }
+  // the main stream has now been given work that reads the current input set: that set may not be overwritten (four frames from now)
+  // before evSetRead, which rides on the LAST kernel the main stream gets for this frame (settleSetRead)
+  if (c->attachEvents) c->setReadDeferred = (int)c->setIndex; else { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; }
   if (c->timing) hipEventRecord(c->tev[14], c->streamMain);
   return r;
 }
@@ -851,47 +810,26 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_denoise: no frame constants"); return -1; }
   if (c->timing) hipEventRecord(c->tev[9], c->streamMain);   // start of denoise
-  { const uint32_t p = (c->frameParity ^ 1u) & 1u;      // the image this frame's temporal pass writes: a tone map on the refit stream may still be reading it
-    if (c->tonePending && c->toneParity == p) flushToneMap(c);
-    if (c->toneRecorded[p]) { RT_HIP(hipStreamWaitEvent(c->streamMain, c->evTone[p], 0)); c->toneRecorded[p] = false; } }
-  c->denoiseIssued = true;
-  // the temporal pass is the last reader of the set; its event rides on the tone map instead when that follows on this stream (settleSetRead)
-  const bool carry = !c->attachEvents || toneAsideEligible(c, c->slots[c->slot]);
-  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr, c->exchangePending ? c->evExchange : nullptr);
-  c->exchangePending = false;
+  // Denoiser::Denoise and Denoiser::ToneMap follow each other in every frame of the sample (RayTracedGGX.cpp:341-350): the temporal pass
+  // also tone-maps its result (denoise.hip temporalToneKernel), and rtggx_tone_map finds its work done.  Not in the per-pass timing
+  // mode (the tone map keeps a duration of its own) and not after rtggx_debug_fuse_tone_map(ctx, 0).
+  const bool fuse = c->fuseToneMap && !c->timing;
+  const bool carry = fuse || !c->attachEvents;      // the frame's last kernel on this stream carries the set's event; else the tone map will
+  const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr, fuse);
   if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex;
+  c->denoiseIssued = true; c->toneMapDone = fuse && c->slots[c->slot].rowEnd > c->slots[c->slot].rowBegin;
   return r;
 }
 
 int rtggx_tone_map(rtggx_context* c) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_tone_map: no frame constants"); return -1; }
-  // OPT-IN since round 3 (rtggx_debug_tone_map_aside / RTGGX_TONEMAP_ASIDE=1; with the shorter shading kernel it measures neutral at best
-  // and widens the run-to-run spread: DESIGN.md section 5).  When on:
-  // the tone map of a full-size frame does not run at the end of the main stream's chain (shading, filters, temporal pass: the chain
-  // the frame waits for) but beside the NEXT frame's filters, on the refit stream: it needs the temporal pass's result only, moves
-  // many bytes with little arithmetic, and the horizontal filter it then overlaps does the opposite.  It is prepared here and
-  // launched by the next rtggx_ray_trace behind that frame's shading kernel (waitable: the kernel carries evSetRead); whoever
-  // synchronises first (rtggx_sync, a read-back, ...) gets it on the main stream at once (flushToneMap).  The temporal pass two
-  // frames on overwrites the image it reads: rtggx_denoise makes the main stream wait for evTone.  Strips, small launches, deforming
-  // meshes (the refit stream is busy), a caller-owned main stream and the timing modes keep the tone map where it was; so do frames
-  // where it does not pay: while the traversal, not the main stream, is the longest stage (its share of the period above 0.92 until it
-  // falls below 0.85: trace.hip steerTraceWaves), and at 4K, where every stage moves four times the bytes (bunny 1080p 0.197 -> 0.189
-  // or 0.196 ms -- two stable states, a run falls into one --, with diffuse rays 0.304 -> 0.296; dragon 0.222 -> 0.225, dragon with
-  // diffuse rays 0.357 -> 0.387 and bunny 4K 0.696 -> 0.702 if it were used there: profiles/r02_c_ab_pipeline.txt block 9).
-  flushToneMap(c);
-  const FrameParams& fp = c->slots[c->slot];
-  const bool aside = toneAsideEligible(c, fp) && c->denoiseIssued && c->setReadDeferred < 0;
-  if (aside && prepareToneMap(c, fp, &c->tonePrepared)) { c->tonePending = true; c->toneParity = c->frameParity & 1u; ++c->toneAsideCount; return 0; }
-  orderMainBehindTones(c);
-  // the frame's last kernel on this stream: it carries the set's event if the kernels before it left that to it
-  PreparedToneMap p;
   int r = 0;
-  if (prepareToneMap(c, fp, &p)) {
+  if (c->toneMapDone) c->toneMapDone = false;      // this frame's rtggx_denoise wrote the back buffer as well
+  else {
     const bool carry = c->setReadDeferred >= 0 && c->attachEvents;
-    r = launchPreparedToneMap(c, p, c->streamMain, carry ? c->evSetRead[c->setReadDeferred] : nullptr);
-    c->lastFrameSet = carry ? c->setReadDeferred : -1;      // its event completes with the frame's last kernel (rtggx_exchange_begin)
-    if (carry) { c->setReadRecorded[c->setReadDeferred] = true; c->setReadDeferred = -1; }
+    r = launchToneMap(c, c->slots[c->slot], c->streamMain, carry ? c->evSetRead[c->setReadDeferred] : nullptr);
+    if (carry && c->slots[c->slot].rowEnd > c->slots[c->slot].rowBegin) { c->setReadRecorded[c->setReadDeferred] = true; c->setReadDeferred = -1; }
   }
   settleSetRead(c);
   if (c->timing) { hipEventRecord(c->tev[10], c->streamMain); c->timingsPending = true; }
@@ -925,7 +863,6 @@ int rtggx_debug_counters(rtggx_context* c, uint32_t* out, uint32_t n, int reset)
   return 0;
 }
 
-// Triangles per leaf of the 4-wide trees built from now on (lbvh.hip emitNodes4 "multi-leaves"): 1 (every leaf one triangle), 2 or 4.
 int rtggx_debug_fence_wait(rtggx_context* c, double* usTotal, uint32_t* waits, int reset) {
   RT_CHECK_CTX(c);
   if (usTotal) *usTotal = c->fenceWaitUs;
@@ -933,16 +870,29 @@ int rtggx_debug_fence_wait(rtggx_context* c, double* usTotal, uint32_t* waits, i
   if (reset) { c->fenceWaitUs = 0.0; c->fenceWaits = 0u; }
   return 0;
 }
-int rtggx_debug_tone_map_aside(rtggx_context* c, int on) {
+int rtggx_debug_fuse_tone_map(rtggx_context* c, int on) {
   RT_CHECK_CTX(c);
-  flushToneMap(c);
-  c->toneAside = on != 0;
+  c->fuseToneMap = on != 0;      // from the next rtggx_denoise on
   return 0;
 }
-int rtggx_debug_leaf_tris(rtggx_context* c, uint32_t leafTris) {
+// force_small: -1 by the ray count, 0 / 1 the placement of a full-size / small launch whatever the count (from the next frame on).
+// key / where (either may be null): the most recent rtggx_ray_trace's key (bit 0 small, 1 strip, 2 deforming, 3 diffuse, 4 caller-owned
+// stream) and placement (bits 0-3 / 4-7 / 8-11: the streams of ray generation / traversal / hit shading -- 0 main, 1 B, 2 C, 3 R --,
+// bits 12-15 frames in flight).
+int rtggx_debug_placement(rtggx_context* c, int forceSmall, uint32_t* key, uint32_t* where) {
   RT_CHECK_CTX(c);
-  if (leafTris < 1u || leafTris > 4u) { setError("rtggx_debug_leaf_tris: 1 .. 4"); return -1; }
-  c->leafTris = leafTris;
+  if (forceSmall < -1 || forceSmall > 1) { setError("rtggx_debug_placement: force_small is -1, 0 or 1"); return -1; }
+  c->forcePlacement = forceSmall;
+  if (forceSmall >= 0) c->lastTraceSmall = forceSmall == 1;
+  if (key) *key = c->lastPlacement[0];
+  if (where) *where = c->lastPlacement[1];
+  return 0;
+}
+int rtggx_debug_collapse_weights(rtggx_context* c, const float* set, float* get) {
+  RT_CHECK_CTX(c);
+  if (set) { if (!(set[0] >= 0.0f) || !(set[1] >= 0.0f) || !(set[0] + set[1] > 0.0f)) { setError("rtggx_debug_collapse_weights: two non-negative weights, not both zero"); return -1; }
+             c->collapseWeights[0] = set[0]; c->collapseWeights[1] = set[1]; }
+  if (get) { get[0] = c->collapseWeights[0]; get[1] = c->collapseWeights[1]; }
   return 0;
 }
 int rtggx_debug_trace_residency(rtggx_context* c, uint32_t forceWaves, uint32_t* waves, float* share) {
@@ -1033,6 +983,7 @@ static int bufferInfo(rtggx_context* c, int id, void** ptr, size_t* bytes) {
     case RTGGX_BUF_BVH4_TOP0: case RTGGX_BUF_BVH4_TOP1: { const MeshDev& m = c->mesh[id == RTGGX_BUF_BVH4_TOP1]; *ptr = m.top; *bytes = m.top ? (size_t)m.topCount * sizeof(Bvh4Node) : 0; return 0; }
     case RTGGX_BUF_BIN_WORK: *ptr = c->binWork; *bytes = (size_t)(((c->W + 15) / 16) * ((c->H + 15) / 16)) * 4u * 4u; return 0;
     case RTGGX_BUF_ENV: *ptr = c->env.texels; *bytes = (size_t)c->env.totalTexels * 8; return 0;
+    case RTGGX_BUF_EXCHANGE_TOKENS: *ptr = c->exchangeTokens; *bytes = 4 * 2 * RT_MAX_PEERS; return 0;
     default: setError("unknown buffer id %d", id); return -1;
   }
 }
@@ -1046,7 +997,6 @@ int rtggx_buffer_ptr(rtggx_context* c, int id, void** dptr) {
   if (r) return r;
   if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) *dptr = c->visDepth;   // packed u64: (depth << 32) | visibility
   if (!*dptr) { setError("buffer %d has no device storage", id); return -1; }
-  if (id == RTGGX_BUF_BACKBUFFER || id == RTGGX_BUF_TSS0 || id == RTGGX_BUF_TSS1) { flushToneMap(c); c->callerOrdersOnMain = true; }      // a consumer outside the library: see rtggx_get_stream
   return 0;
 }
 
@@ -1079,6 +1029,7 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
   if (r) return r;
   if (bytes != need) { setError("rtggx_upload: buffer %d is %zu bytes, %zu given", id, need, bytes); return -1; }
   RT_HIP(syncStreams(c));
+  c->toneMapDone = false;      // (a tone map after an upload reads what was uploaded)
   if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) {
     // replace one half of the packed buffer
     uint32_t *dVis, *dDepth;

@@ -62,6 +62,11 @@ struct Targets {
   // Strips of a multi-GPU frame: rows [histLo, histHi) of `history` are valid on this rank (its own rows + the apron its
   // neighbours delivered).  A reprojection that reads beyond them records by how many rows (histReach; null on whole frames).
   int histLo, histHi; uint32_t* histReach;
+  // ... and beyond them the tap reads the OWNER's image directly (round 4): peerHist[r] = rank r's TemporalSSOut[!parity] as mapped into this
+  // process (rtggx_set_history_peers), peerBounds[r] .. peerBounds[r + 1] the rows rank r owns.  Null: no peers (the tap reads this rank's
+  // own buffer whatever it holds there -- rounds 2-3's "reported, not prevented").
+  const uint2* const* peerHist; const uint32_t* peerBounds; int peerWorld;
+  int outBegin, outEnd;      // rows of the back buffer (the strip itself): the fused temporal + tone-map kernel
 };
 
 #define RT_LOG2E 1.44269504088896341f
@@ -75,18 +80,21 @@ struct Targets {
 // 512th power overflows, 0 x inf = NaN, and the pixel (then its column) turns NaN -- in the reference, hence here:
 // reflection texels are staged as they are, with the flag in the sign bit of the roughness word.
 struct Centre { float nx, ny, nz, depth, rough, gaussK /* -0.5 log2(e) / sigma^2 */, depthK /* dc 4 log2(e) */; };
+// pow(x, 512) / pow(x, 32) of the normal weight.  HLSL's pow IS exp2(y log2 x) on the hardware's 1-ulp functions; rounds 1-3 squared x nine
+// (five) times, which carries 2^k - 1 roundings -- up to 423 ulps of the true power over the possible dot products, against 16 for
+// v_exp_f32(512 v_log_f32(x)) where the weight is above 1e-6 and 80 at worst (tools/microbench/pow512.hip, profiles/r04_a_pow512.txt) --
+// and the temporal pass turns a 1e-5 difference of the filtered image into 1e-3.  Two quarter-rate instructions
+// and a multiplication instead of nine (five) multiplications; x = 0 gives 0, x > 2^(1/4) gives +inf like the true power does (the
+// reference's 0 x inf = NaN for taps outside the frame, SpatialFilter.hlsli:60, stays where it was).
+RT_DEV float powByLog(float x, float n) { return __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x)); }
 template <bool DIFFUSE>
 RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, float depth, float rough) {
 #pragma clang fp contract(fast)
-  // N . Nc as one multiplication and two fused multiply-adds (what a dp3 is on the reference's hardware), written out so that the oracle
-  // can evaluate the same three operations: the 512th power multiplies an ulp of this dot product by 512, and the temporal pass
-  // multiplies what is left of it again (variance clamp, inverse tone map: profiles/r03_d_parity_1080p.txt).  The power itself --
-  // nine squarings -- is the numeric contract's on both sides.
-  float p = fmaxf(__builtin_fmaf(c.nz, nz, __builtin_fmaf(c.ny, ny, c.nx * nx)), 0.0f);
-  p *= p; p *= p; p *= p; p *= p; p *= p;                 // ^32
+  // N . Nc as one multiplication and two fused multiply-adds (what a dp3 is on the reference's hardware)
+  const float x = fmaxf(__builtin_fmaf(c.nz, nz, __builtin_fmaf(c.ny, ny, c.nx * nx)), 0.0f);
   const float dd = fabsf(c.depth - depth) * c.depthK;
-  if (DIFFUSE) return p * __builtin_amdgcn_exp2f(-dd);
-  p *= p; p *= p; p *= p; p *= p;                          // ^512
+  if (DIFFUSE) return powByLog(x, 32.0f) * __builtin_amdgcn_exp2f(-dd);
+  const float p = powByLog(x, 512.0f);
   const float e = __builtin_fmaf(c.gaussK, (float)(i * i), -dd);
   const float t = saturatef(fabsf(fabsf(rough) - c.rough) * 2.0f);
   const float flag = (__float_as_uint(rough) >> 31) ? 0.0f : 1.0f;          // sign bit set: norm.w <= 0
@@ -260,44 +268,21 @@ RT_DEV f4 loadRGBA16(const uint2* __restrict__ b, int x, int y, int W, int H) {
   return unpackRGBA16F(b[(size_t)y * W + x]);
 }
 
-// The 3x3 neighbourhood is read from an LDS tile that holds tssTM(FilteredOut1) (alpha kept) of the block's 64 x RT_TP_ROWS
-// pixels and a one-texel apron: each texel is unpacked and tone-mapped (three divisions) once instead of nine times.
-// RT_TP_ROWS / 4 pixels per thread.  One pixel per thread (64 x 4 blocks) stays: VERDICT r02 asked to finish the taller shape the tone map
-// and the clear have -- a tile of 8 or 16 rows loads 1.29x / 1.16x its pixels instead of 1.55x, and a half / a quarter of the waves are
-// launched -- and here it loses: bunny 1080p 0.1818 -> 0.1944 (8 rows) -> 0.1970 ms (16), 4K 0.689 -> 0.693 -> 0.740, a thin strip 0.0527 ->
-// 0.0536 -> 0.0564.  The pixels with a surface take the long path (four 8-byte history taps, the clamp window), and a thread that walks
-// several of them one after the other serialises their round trips.
-#ifndef RT_TP_ROWS
-#define RT_TP_ROWS 4
-#endif
-__global__ void __launch_bounds__(256) temporalKernel(Targets T) {
-  __shared__ float4 tile[RT_TP_ROWS + 2][66];
-  __shared__ uint32_t velRaw[RT_TP_ROWS + 2][66];      // the velocity texels of the same window (zero outside the frame) ...
-  __shared__ float velSq[RT_TP_ROWS + 2][66];          // ... and their squared lengths: VelocityMax compares five of them per pixel
+// The 3x3 neighbourhood is read from an LDS tile that holds tssTM(FilteredOut1) (alpha kept) of the workgroup's pixels and a one-texel
+// apron: each texel is unpacked and tone-mapped (three divisions) once instead of nine times.  ONE pixel per thread: round 3 built
+// workgroups of 64 x 8 and 64 x 16 pixels with two and four pixels per thread (1.29 x / 1.16 x the pixels loaded instead of 1.55 x) and
+// lost -- bunny 1080p 0.1818 -> 0.1944 -> 0.1970 ms -- because the pixels with a surface take the long path (four 8-byte history taps, the
+// clamp window), and a thread that walks several of them one after the other serialises their round trips.
+RT_DEV const uint2* peerHistoryRow(const Targets& T, int iy) {
+  int r = 0;
+  while (r + 1 < T.peerWorld && (int)T.peerBounds[r + 1] <= iy) ++r;
+  return T.peerHist[r] + (size_t)iy * T.W;
+}
+// One pixel of the temporal pass: (x, y) of the frame = (lx, ly) of the workgroup's LDS tiles (tone-mapped FilteredOut1 + alpha, the
+// velocity texels and their squared lengths; 66 texels per row, a one-texel apron all round).  Returns TemporalSSOut's packed texel.
+template <int ROWS>
+RT_DEV uint2 temporalPixel(const Targets& T, const float4 (&tile)[ROWS][66], const uint32_t (&velRaw)[ROWS][66], const float (&velSq)[ROWS][66], int x, int y, int lx, int ly) {
   const int W = T.W, H = T.H;
-  {
-    const int ox = blockIdx.x * 64 - 1, oy = T.rowBegin + blockIdx.y * RT_TP_ROWS - 1;
-    for (int t = threadIdx.x; t < (RT_TP_ROWS + 2) * 66; t += 256) {
-      const int tx = ox + t % 66, ty = oy + t / 66;
-      const bool inside = tx >= 0 && ty >= 0 && tx < W && ty < H;
-      const size_t ti = inside ? (size_t)ty * W + tx : 0;
-      const f4 raw = inside ? unpackRGBA16F(T.fltDff[ti]) : f4{0.0f, 0.0f, 0.0f, 0.0f};
-      const uint32_t vr = inside ? T.velocity[ti] : 0u;
-      const f3 tm = tssTM(mk3(raw.x, raw.y, raw.z));
-      tile[t / 66][t % 66] = make_float4(tm.x, tm.y, tm.z, raw.w);
-      const float vx = f16ToF32(vr & 0xFFFFu), vy = f16ToF32(vr >> 16);
-      velRaw[t / 66][t % 66] = vr;
-      velSq[t / 66][t % 66] = vx * vx + vy * vy;
-    }
-  }
-  __syncthreads();
-  const int lx = (threadIdx.x & 63) + 1;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  if (x >= T.W) return;
-  for (int row = 0; row < RT_TP_ROWS / 4; ++row) {
-  const int ly = (threadIdx.x >> 6) + 4 * row + 1;
-  const int y = T.rowBegin + blockIdx.y * RT_TP_ROWS + (threadIdx.x >> 6) + 4 * row;
-  if (y >= T.rowEnd) continue;
   const float Wf = (float)W, Hf = (float)H;
   const float uvx = ((float)x + 0.5f) * rcpFast(Wf), uvy = ((float)y + 0.5f) * rcpFast(Hf);
   const float4 cur = tile[ly][lx];
@@ -337,12 +322,23 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
     const int iy0 = y0 < 0.0f ? 0 : (y0 > (float)(H - 1) ? H - 1 : (int)y0);
     const int iy1 = y0 + 1.0f < 0.0f ? 0 : (y0 + 1.0f > (float)(H - 1) ? H - 1 : (int)(y0 + 1.0f));
     const float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-    if (T.histReach != nullptr) {      // history-apron guard (SURVEY 8e "clamp and report"): rows this rank does not hold
+    // Strips: rows [histLo, histHi) of `history` are this rank's own and the apron its neighbours delivered; a tap beyond them (a pixel
+    // that moved more than the apron's rows in one frame: one sliver triangle per few hundred frames of the turning bunny) is counted
+    // (histReach, SURVEY 8e "clamp and report") and read from the image of the rank that OWNS the row -- the reference samples its one
+    // history texture anywhere (CSTemporalSS.hlsl:259-265).
+    const uint2* row0 = T.history + (size_t)iy0 * W; const uint2* row1 = T.history + (size_t)iy1 * W;
+    if (T.histReach != nullptr) {
       const int over = max(T.histLo - iy0, iy1 - (T.histHi - 1));
-      if (over > 0) atomicMax(T.histReach, (uint32_t)over);
+      if (over > 0) {
+        atomicMax(T.histReach, (uint32_t)over);
+        if (T.peerHist != nullptr) {
+          if (iy0 < T.histLo || iy0 >= T.histHi) row0 = peerHistoryRow(T, iy0);
+          if (iy1 < T.histLo || iy1 >= T.histHi) row1 = peerHistoryRow(T, iy1);
+        }
+      }
     }
-    const uint2* h00 = T.history + (size_t)iy0 * W + ix0; const uint2* h10 = T.history + (size_t)iy0 * W + ix1;
-    const uint2* h01 = T.history + (size_t)iy1 * W + ix0; const uint2* h11 = T.history + (size_t)iy1 * W + ix1;
+    const uint2* h00 = row0 + ix0; const uint2* h10 = row0 + ix1;
+    const uint2* h01 = row1 + ix0; const uint2* h11 = row1 + ix1;
     if (plain) {      // only the alpha (history length) is needed
       history.x = history.y = history.z = 0.0f;
       history.w = ((f16ToF32(h00->y >> 16) * w00 + f16ToF32(h10->y >> 16) * w10) + f16ToF32(h01->y >> 16) * w01) + f16ToF32(h11->y >> 16) * w11;
@@ -436,8 +432,82 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   hw = fminf(history.w * (1.0f / 15.0f), 1.0f - curHistoryBlur);
   }
   }
-  T.scratch[(size_t)y * W + x] = packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
-  }   // row
+  return packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
+}
+// Stages the tiles of a (ROWS - 2) x 64 pixel block whose first pixel is (ox + 1, oy + 1).
+template <int ROWS, int THREADS>
+RT_DEV void stageTemporalTiles(const Targets& T, float4 (&tile)[ROWS][66], uint32_t (&velRaw)[ROWS][66], float (&velSq)[ROWS][66], int ox, int oy) {
+  const int W = T.W, H = T.H;
+  for (int t = threadIdx.x; t < ROWS * 66; t += THREADS) {
+    const int tx = ox + t % 66, ty = oy + t / 66;
+    const bool inside = tx >= 0 && ty >= 0 && tx < W && ty < H;
+    const size_t ti = inside ? (size_t)ty * W + tx : 0;
+    const f4 raw = inside ? unpackRGBA16F(T.fltDff[ti]) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t vr = inside ? T.velocity[ti] : 0u;
+    const f3 tm = tssTM(mk3(raw.x, raw.y, raw.z));
+    tile[t / 66][t % 66] = make_float4(tm.x, tm.y, tm.z, raw.w);
+    const float vx = f16ToF32(vr & 0xFFFFu), vy = f16ToF32(vr >> 16);
+    velRaw[t / 66][t % 66] = vr;
+    velSq[t / 66][t % 66] = vx * vx + vy * vy;
+  }
+}
+#define RT_TP_ROWS 4
+__global__ void __launch_bounds__(256) temporalKernel(Targets T) {
+  __shared__ float4 tile[RT_TP_ROWS + 2][66];
+  __shared__ uint32_t velRaw[RT_TP_ROWS + 2][66];      // the velocity texels of the same window (zero outside the frame) ...
+  __shared__ float velSq[RT_TP_ROWS + 2][66];          // ... and their squared lengths: VelocityMax compares five of them per pixel
+  stageTemporalTiles<RT_TP_ROWS + 2, 256>(T, tile, velRaw, velSq, (int)blockIdx.x * 64 - 1, T.rowBegin + (int)blockIdx.y * RT_TP_ROWS - 1);
+  __syncthreads();
+  const int lx = (threadIdx.x & 63) + 1, ly = (threadIdx.x >> 6) + 1;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = T.rowBegin + blockIdx.y * RT_TP_ROWS + (threadIdx.x >> 6);
+  if (x >= T.W || y >= T.rowEnd) return;
+  T.scratch[(size_t)y * T.W + x] = temporalPixel<RT_TP_ROWS + 2>(T, tile, velRaw, velSq, x, y, lx, ly);
+}
+
+// The temporal pass and the tone map in ONE kernel (round 4; CSTemporalSS.hlsl:254-336 + PSToneMap.hlsl:13-41; Denoiser.cpp:66-103 issues
+// them back to back).  The tone map reads TemporalSSOut at the pixel and its four neighbours -- what the temporal pass has just written:
+// as two kernels that is a launch, an event-carrying gap on the frame's longest stream and 8 bytes per pixel read again.  One workgroup
+// of 1024 threads computes the temporal result of 64 x 16 pixels, one per thread (a thread that walks several surface pixels serialises
+// their history taps: the 8- and 16-row shapes of round 3 lost), keeps c / (c + 0.5) of the ROUNDED result (the half-float texel the
+// two-kernel path reads back: the back buffer is bit-identical) in LDS and tone-maps the 62 x 14 pixels inside: 1.18 x the temporal work.
+// TemporalSSOut is written by the workgroup whose interior holds the pixel; of a strip's apron rows (b - 1 and e: what the two-kernel
+// path's temporal pass writes there) by the first and last row of workgroups.
+#define RT_TT_W 62
+#define RT_TT_H 14
+__global__ void __launch_bounds__(1024) temporalToneKernel(Targets T) {
+  __shared__ float4 tile[RT_TT_H + 4][66];
+  __shared__ uint32_t velRaw[RT_TT_H + 4][66];
+  __shared__ float velSq[RT_TT_H + 4][66];
+  __shared__ float4 tm[RT_TT_H + 2][64];      // c / (c + 0.5) and alpha of the temporal result; zero outside the frame (what D3D reads there)
+  const int x0 = (int)blockIdx.x * RT_TT_W - 1, y0 = T.outBegin + (int)blockIdx.y * RT_TT_H - 1;      // the pixel of thread (0, 0)
+  stageTemporalTiles<RT_TT_H + 4, 1024>(T, tile, velRaw, velSq, x0 - 1, y0 - 1);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int x = x0 + tx, y = y0 + ty;
+  float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (x >= 0 && x < T.W && y >= T.rowBegin && y < T.rowEnd) {      // (T.rowBegin .. T.rowEnd: the strip + one row either side, inside the frame)
+    const uint2 packed = temporalPixel<RT_TT_H + 4>(T, tile, velRaw, velSq, x, y, tx + 1, ty + 1);
+    const bool mine = tx >= 1 && tx <= RT_TT_W && (ty >= 1 && ty <= RT_TT_H ? true : ty == 0 ? blockIdx.y == 0 : blockIdx.y == gridDim.y - 1);
+    if (mine) T.scratch[(size_t)y * T.W + x] = packed;
+    {
+#pragma clang fp contract(fast)
+      const f4 v = unpackRGBA16F(packed);
+      c = make_float4(v.x * rcpFast(v.x + 0.5f), v.y * rcpFast(v.y + 0.5f), v.z * rcpFast(v.z + 0.5f), v.w);
+    }
+  }
+  tm[ty][tx] = c;
+  __syncthreads();
+  if (tx < 1 || tx > RT_TT_W || ty < 1 || ty > RT_TT_H || x >= T.W || y >= T.outEnd) return;
+  {
+#pragma clang fp contract(fast)
+    const float4 c0 = tm[ty][tx], c1 = tm[ty][tx - 1], c2 = tm[ty][tx + 1], c3 = tm[ty - 1][tx], c4 = tm[ty + 1][tx];
+    float lx_ = -4.0f * c0.x, ly_ = -4.0f * c0.y, lz_ = -4.0f * c0.z;
+    lx_ += c1.x; ly_ += c1.y; lz_ += c1.z;
+    lx_ += c2.x; ly_ += c2.y; lz_ += c2.z;
+    lx_ += c3.x; ly_ += c3.y; lz_ += c3.z;
+    lx_ += c4.x; ly_ += c4.y; lz_ += c4.z;
+    T.backbuffer[(size_t)y * T.W + x] = packRGBA8(c0.x - 0.2f * lx_, c0.y - 0.2f * ly_, c0.z - 0.2f * lz_, c0.w);
+  }
 }
 
 // PSToneMap.hlsl:13-41; source = TSS[parity] (passed as T.scratch)
@@ -491,14 +561,21 @@ static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass
   T.W = (int)fp.W; T.H = (int)fp.H;
   uint32_t rb, re; passRows(fp, pass, rb, re);
   T.rowBegin = (int)rb; T.rowEnd = (int)re;
+  passRows(fp, ROWS_FINAL, rb, re);
+  T.outBegin = (int)rb; T.outEnd = (int)re;
   const bool strip = fp.rowBegin > 0u || fp.rowEnd < fp.H;
   T.histLo = (int)(fp.rowBegin > c->historyApron ? fp.rowBegin - c->historyApron : 0u);
   T.histHi = (int)(fp.rowEnd + c->historyApron < fp.H ? fp.rowEnd + c->historyApron : fp.H);
   T.histReach = strip ? c->histReach : nullptr;
+  // the other ranks' history images (rtggx_set_history_peers): the table lives in device memory, [parity][rank]
+  const bool peers = strip && c->peerWorld > 1u && c->dPeerTable != nullptr;
+  T.peerHist = peers ? reinterpret_cast<const uint2* const*>(c->dPeerTable) + (c->frameParity ^ 1u) * RT_MAX_PEERS : nullptr;
+  T.peerBounds = peers ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint2* const*>(c->dPeerTable) + 2 * RT_MAX_PEERS) : nullptr;
+  T.peerWorld = peers ? (int)c->peerWorld : 0;
   return T;
 }
 
-int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done, hipEvent_t historyReady) {
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done, bool fuseToneMap) {
   c->frameParity ^= 1u;   // Denoiser.cpp:69
   if (fp.rowEnd <= fp.rowBegin) return 0;
   const Targets TH = makeTargets(c, fp, ROWS_GBUFFER), TV = makeTargets(c, fp, ROWS_VFILTER), TT = makeTargets(c, fp, ROWS_TEMPORAL);
@@ -507,9 +584,8 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
   auto mark = [&](int i) { if (c->timing) hipEventRecord(c->tev[i], s); };
   // The diffuse passes only touch pixels whose metallic is below 1, and metallic is a per-instance material constant
   // (Material.hlsli:20-30: no textures): with both instances fully metallic -- the sample's default -- they have nothing
-  // to do (the reflection V pass already wrote FilteredOut1) and are not launched.  RTGGX_KEEP_EMPTY_DIFFUSE=1 launches them.
-  static const bool keepEmpty = getenv("RTGGX_KEEP_EMPTY_DIFFUSE") && atoi(getenv("RTGGX_KEEP_EMPTY_DIFFUSE")) != 0;
-  const bool anyDiffuse = keepEmpty || fp.mat.RoughMetals[0][1] < 1.0f || fp.mat.RoughMetals[1][1] < 1.0f;
+  // to do (the reflection V pass already wrote FilteredOut1) and are not launched.
+  const bool anyDiffuse = fp.mat.RoughMetals[0][1] < 1.0f || fp.mat.RoughMetals[1][1] < 1.0f;
   // FilteredOut is read by the diffuse V pass only.  Without diffuse passes the reflection V pass writes FilteredOut1 alone (the two
   // images would be identical, 8 bytes per pixel each); rtggx_readback(RTGGX_BUF_FLT_RFL) then returns FilteredOut1 (capi.hip).
   c->fltRflIsFltDff = !anyDiffuse;
@@ -530,36 +606,27 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
     hipLaunchKernelGGL(spatialDirectKernel<2>, grid(TH, 64, 4), block, 0, s, TH); mark(6);
     hipLaunchKernelGGL(spatialDirectKernel<3>, grid(TV, 64, 4), block, 0, s, TV); mark(7);
   }
-  if (historyReady) RT_HIP(hipStreamWaitEvent(s, historyReady, 0));      // the caller's exchange of history rows, on its own stream (capi.hip rtggx_exchange_end): only the temporal pass needs them
-  if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalKernel, grid(TT, 64, RT_TP_ROWS), block, 0, s, nullptr, done, 0, TT);
+  if (fuseToneMap) {      // the temporal pass and the tone map of its result in one kernel: workgroups of 62 x 14 back-buffer pixels over the strip's own rows
+    const dim3 g((fp.W + RT_TT_W - 1) / RT_TT_W, (uint32_t)(TT.outEnd - TT.outBegin + RT_TT_H - 1) / RT_TT_H), b(1024);
+    if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalToneKernel, g, b, 0, s, nullptr, done, 0, TT);
+    else { hipLaunchKernelGGL(temporalToneKernel, g, b, 0, s, TT); if (done) hipEventRecord(done, s); }
+  } else if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalKernel, grid(TT, 64, RT_TP_ROWS), block, 0, s, nullptr, done, 0, TT);
   else { hipLaunchKernelGGL(temporalKernel, grid(TT, 64, RT_TP_ROWS), block, 0, s, TT); if (done) hipEventRecord(done, s); }
   mark(8);
   RT_HIP(hipGetLastError());
   return 0;
 }
 
-// The tone map of a frame, prepared (prepareToneMap: everything the kernel needs, by value) and launched (launchPreparedToneMap) in
-// two steps: capi.hip may launch it later and elsewhere than where rtggx_tone_map was called.
-bool prepareToneMap(rtggx_context* c, const FrameParams& fp, PreparedToneMap* out) {
-  if (fp.rowEnd <= fp.rowBegin) return false;
-  static_assert(sizeof(Targets) <= sizeof(out->targets), "PreparedToneMap::targets too small");
+// The tone map as a kernel of its own: a caller that tone-maps without having denoised in this frame, the per-pass timing mode, and
+// rtggx_debug_fuse_tone_map(ctx, 0) -- the two-kernel path of rounds 1-3, kept for comparison with the fused one.
+int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done) {
+  if (fp.rowEnd <= fp.rowBegin) return 0;
   const Targets T = makeTargets(c, fp, ROWS_FINAL);
-  std::memcpy(out->targets, &T, sizeof T);
-  out->gridX = (fp.W + 63) / 64; out->gridY = (uint32_t)(T.rowEnd - T.rowBegin + RT_TM_ROWS - 1) / RT_TM_ROWS;
-  return true;
-}
-int launchPreparedToneMap(rtggx_context* c, const PreparedToneMap& p, hipStream_t s, hipEvent_t done) {
-  Targets T; std::memcpy(&T, p.targets, sizeof T);
-  const dim3 grid(p.gridX, p.gridY), block(256);
+  const dim3 grid((fp.W + 63) / 64, (uint32_t)(T.rowEnd - T.rowBegin + RT_TM_ROWS - 1) / RT_TM_ROWS), block(256);
   if (done && c->attachEvents) hipExtLaunchKernelGGL(toneMapKernel, grid, block, 0, s, nullptr, done, 0, T);
   else { hipLaunchKernelGGL(toneMapKernel, grid, block, 0, s, T); if (done) RT_HIP(hipEventRecord(done, s)); }
   RT_HIP(hipGetLastError());
   return 0;
-}
-int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s) {
-  PreparedToneMap p;
-  if (!prepareToneMap(c, fp, &p)) return 0;
-  return launchPreparedToneMap(c, p, s, nullptr);
 }
 
 }  // namespace rt

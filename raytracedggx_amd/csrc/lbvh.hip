@@ -142,60 +142,6 @@ __global__ void __launch_bounds__(256) radixScatter(const uint32_t* __restrict__
   }
 }
 
-// ---- Karras hierarchy --------------------------------------------------------------------------------
-RT_DEV int deltaLcp(const uint32_t* __restrict__ codes, int n, int i, int j) {
-  if (j < 0 || j >= n) return -1;
-  const uint32_t a = codes[i], b = codes[j];
-  if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
-  return __clz(a ^ b);
-}
-__global__ void hierarchyKernel(const uint32_t* __restrict__ codes, int n, int32_t* __restrict__ left, int32_t* __restrict__ right,
-                                int32_t* __restrict__ nodeParent, int32_t* __restrict__ leafParent) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n - 1) return;
-  const int d = (deltaLcp(codes, n, i, i + 1) - deltaLcp(codes, n, i, i - 1)) >= 0 ? 1 : -1;
-  const int dmin = deltaLcp(codes, n, i, i - d);
-  int lmax = 2;
-  while (deltaLcp(codes, n, i, i + lmax * d) > dmin) lmax *= 2;
-  int l = 0;
-  for (int t = lmax / 2; t >= 1; t /= 2) if (deltaLcp(codes, n, i, i + (l + t) * d) > dmin) l += t;
-  const int j = i + l * d;
-  const int dnode = deltaLcp(codes, n, i, j);
-  int s = 0, t = l;
-  do { t = (t + 1) / 2; if (deltaLcp(codes, n, i, i + (s + t) * d) > dnode) s += t; } while (t > 1);
-  const int gamma = i + s * d + min(d, 0);
-  const int lo = min(i, j), hi = max(i, j);
-  if (lo == gamma) { left[i] = ~gamma; leafParent[gamma] = i; } else { left[i] = gamma; nodeParent[gamma] = i; }
-  if (hi == gamma + 1) { right[i] = ~(gamma + 1); leafParent[gamma + 1] = i; } else { right[i] = gamma + 1; nodeParent[gamma + 1] = i; }
-  if (i == 0) nodeParent[0] = -1;
-}
-
-RT_DEV float ldAgent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-RT_DEV void stAgent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// One lane per leaf climbs towards the root; the second arrival at a node merges the child boxes.
-__global__ void fitKernel(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
-                          const int32_t* __restrict__ right, const int32_t* __restrict__ nodeParent, const int32_t* __restrict__ leafParent,
-                          float* nodeBox, uint32_t* arrive) {
-  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
-  if (leaf >= n) return;
-  int cur = leafParent[leaf];
-  while (cur >= 0) {
-    __threadfence();
-    const uint32_t old = atomicAdd(&arrive[cur], 1u);
-    if (old == 0) return;
-    __threadfence();
-    float b[2][6];
-    const int32_t ch[2] = {left[cur], right[cur]};
-    for (int s = 0; s < 2; ++s) {
-      if (ch[s] < 0) { const uint32_t prim = order[~ch[s]]; for (int k = 0; k < 6; ++k) b[s][k] = triBox[6 * (size_t)prim + k]; }
-      else for (int k = 0; k < 6; ++k) b[s][k] = ldAgent(&nodeBox[6 * (size_t)ch[s] + k]);
-    }
-    for (int k = 0; k < 3; ++k) { stAgent(&nodeBox[6 * (size_t)cur + k], fminf(b[0][k], b[1][k])); stAgent(&nodeBox[6 * (size_t)cur + 3 + k], fmaxf(b[0][3 + k], b[1][3 + k])); }
-    cur = nodeParent[cur];
-  }
-}
-
 // ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) ------------------------------------
 // Agglomerative build over the Morton-ordered triangles: every cluster looks RT_PLOC_RADIUS positions to either side
 // for the partner that gives the smallest merged box; mutual choices merge into a new node; the survivors are
@@ -538,54 +484,145 @@ __global__ void emitNodes(int n, const uint32_t* __restrict__ order, const float
   nd.left = l; nd.right = r; nd.pad[0] = 0; nd.pad[1] = 0;
   nodes[i] = nd;
 }
-// 4-wide collapse: every internal node of even depth becomes a Bvh4Node whose entries are its grandchildren (or
-// its children where those are leaves).  Boxes are the binary tree's own child boxes, so the set of triangles a
-// ray reaches can only grow relative to the binary traversal (one box test per two levels is skipped).
-// Multi-leaves (round 3): a child or grandchild whose whole subtree holds at most `leafTris` triangles becomes ONE entry, a leaf of
-// several triangles -- reference ~(first slot | (count - 1) << 28), box = the subtree's -- and the nodes below it are never visited:
-// the bottom level or two of the tree, the ones that miss the LDS table and the L1, go away for one more triangle test or two per
-// leaf step (the leaf slots are in depth-first order, leafRankKernel, so a subtree's triangles are consecutive).  leafTris = 1: none.
-RT_DEV int32_t multiLeafRef(int32_t x, const int32_t* __restrict__ left, const uint32_t* __restrict__ cnt0) {
-  int32_t y = x;
-  while (y >= 0) y = left[y];      // the subtree's first slot: its leftmost leaf
-  return ~(int32_t)((uint32_t)~y | (cnt0[x] << 28));      // cnt0 = internal nodes of the subtree = triangles - 1
+// (a treelet of the refit schedule, see "the refit schedule" below: the collapse's dynamic programme runs in the same order)
+struct RefitTreelet { uint32_t itemBegin, roundBegin, numRounds, pad; };
+RT_DEV uint32_t treeletBase(const BuildResult* res, int level) { uint32_t b = 0; for (int l = 0; l < level; ++l) b += res->treelets[l]; return b; }
+// ---- the 4-wide collapse (round 4: by surface area) --------------------------------------------------------------------------------
+// The reference asks the driver for PREFER_FAST_TRACE (RayTracer.cpp:676-716); what this builder can do for the traversal's count of
+// dependent steps is choose WHICH binary nodes become 4-wide nodes.  Rounds 1-3 collapsed by depth parity -- every binary node of even
+// depth took its grandchildren: 3.0 entries per node on the bunny; opening the largest child first from the top down gives the same
+// (measured: 34 462 nodes against 34 764) -- the nodes are counted at the bottom of the tree, and a top-down rule leaves whatever
+// subtrees it ends on.  So the choice is made from the bottom up, by dynamic programming over the binary tree (the idea of Ylitie,
+// Karras, Laine 2017, section 3, for width 4): the expected number of node steps of a random ray is proportional to the summed surface
+// area of the 4-wide nodes, and
+//     F(n, i) = the least such sum with which the subtree of n can be covered by AT MOST i entries (i = 1, 2, 3)
+//     F(leaf, i) = 0
+//     F(n, 1) = A(n) + min over k = 1..3 of F(left, k) + F(right, 4 - k)          (n is a 4-wide node: its entries split k : 4 - k)
+//     F(n, i) = min(F(n, 1), min over k = 1..i-1 of F(left, k) + F(right, i - k))  (n stays one entry, or is opened)
+// with the choices recorded beside the sums.  Boxes are still the binary tree's own, so the triangles a ray reaches can only grow
+// relative to the binary traversal; a node step costs what it did (seven 16-byte loads), there are fewer of them.
+//   collapseCostTreelets   F and the choices for every node, children before parents: the refit schedule's order (one workgroup per
+//                          treelet, round by round with the treelet's sums in LDS, level after level)
+//   entries4Kernel         every binary node i: the entries E(i) it has IF it is a 4-wide node, by following the choices down
+//   roots4Kernel           which binary nodes ARE 4-wide nodes: the root, and every internal entry of one.  Thread i walks its ancestors from
+//                          the root down through the E() of the 4-wide nodes on the way: either it arrives at i, or i lies inside one of them.
+//                          On the way it adds up what a traversal's stack can hold there (entries - 1 per 4-wide ancestor): BuildResult::stack4.
+// All of it is part of the topology (BvhTopo::ent4, lvl4): a refit emits the same nodes with new boxes (emitNodes4).
+RT_DEV float halfAreaOf(const float* __restrict__ b) { const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2]; return (ex * ey + ey * ez) + ez * ex; }
+// choices word: bits 0-1 k of F(n, 1); bit 2: F(n, 2) opens n (1 : 1); bits 4-5: F(n, 3) keeps n (0) or opens it k : 3 - k (k = 1, 2)
+__global__ void __launch_bounds__(256) collapseCostTreelets(int level, const RefitTreelet* __restrict__ treelets, const int4* __restrict__ items, const uint32_t* __restrict__ roundOfs,
+                                                            const float* __restrict__ nodeBox, const uint32_t* __restrict__ cnt0, int32_t root, float areaWeight, float trisWeight,
+                                                            float4* __restrict__ cost4, const BuildResult* __restrict__ res) {
+  __shared__ float sF[RT_TREELET_NODES][3];
+  const uint32_t base = treeletBase(res, level), K = res->treelets[level];
+  // a node's cost: areaWeight x A(n) / A(root) + trisWeight x triangles(n) / triangles(root) -- the chance that a random ray enters it, and
+  // the chance that a ray STARTING on the surface starts inside it (rtggx_debug_collapse_weights)
+  const float ka = areaWeight / halfAreaOf(nodeBox + 6 * (size_t)root), kt = trisWeight / (float)(cnt0[root] + 1u);
+  for (uint32_t tk = blockIdx.x; tk < K; tk += gridDim.x) {
+    const RefitTreelet tl = treelets[base + tk];
+    for (uint32_t r = 0; r < tl.numRounds; ++r) {
+      const uint32_t b = roundOfs[tl.roundBegin + r], e = roundOfs[tl.roundBegin + r + 1u];
+      for (uint32_t k = b + threadIdx.x; k < e; k += 256u) {
+        const int4 it = items[tl.itemBegin + k];
+        float c[2][3];
+        const int32_t ref[2] = {it.y, it.z};
+        for (int s = 0; s < 2; ++s) {
+          if (ref[s] >= 0) { for (int q = 0; q < 3; ++q) c[s][q] = sF[ref[s]][q]; }
+          else if ((uint32_t)ref[s] & 0x40000000u) { c[s][0] = c[s][1] = c[s][2] = 0.0f; }      // a leaf
+          else { const float4 f = cost4[(uint32_t)ref[s] & 0x3FFFFFFFu]; c[s][0] = f.x; c[s][1] = f.y; c[s][2] = f.z; }      // a node of a lower treelet level
+        }
+        const float A = halfAreaOf(nodeBox + 6 * (size_t)it.x) * ka + (float)(cnt0[it.x] + 1u) * kt;
+        float best = c[0][0] + c[1][2]; uint32_t k1 = 1u;
+        { const float v = c[0][1] + c[1][1]; if (v < best) { best = v; k1 = 2u; } }
+        { const float v = c[0][2] + c[1][0]; if (v < best) { best = v; k1 = 3u; } }
+        const float F1 = A + best;
+        float F2 = F1; uint32_t d2 = 0u;
+        { const float v = c[0][0] + c[1][0]; if (v < F2) { F2 = v; d2 = 1u; } }
+        float F3 = F1; uint32_t d3 = 0u;
+        { const float v = c[0][0] + c[1][1]; if (v < F3) { F3 = v; d3 = 1u; } }
+        { const float v = c[0][1] + c[1][0]; if (v < F3) { F3 = v; d3 = 2u; } }
+        sF[k][0] = F1; sF[k][1] = F2; sF[k][2] = F3;
+        cost4[it.x] = make_float4(F1, F2, F3, __uint_as_float(k1 | (d2 << 2) | (d3 << 4)));
+      }
+      __syncthreads();
+    }
+  }
 }
-__global__ void emitNodes4(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const int32_t* __restrict__ left,
-                           const int32_t* __restrict__ right, const int32_t* __restrict__ nodeParent, const float* __restrict__ nodeBox,
-                           const uint32_t* __restrict__ cnt0, uint32_t leafTris, Bvh4Node* __restrict__ nodes4) {
+__global__ void entries4Kernel(int numNodes, const int32_t* __restrict__ left, const int32_t* __restrict__ right, const float4* __restrict__ cost4, int4* __restrict__ ent4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numNodes) return;
+  int32_t e[4] = {RT_BVH4_EMPTY, RT_BVH4_EMPTY, RT_BVH4_EMPTY, RT_BVH4_EMPTY};
+  int cnt = 0;
+  // (subtree, entries it may become) pairs still to settle, left to right; a pair with one entry, or a leaf, is an entry
+  int32_t stN[4]; int stI[4]; int sp = 0;
+  { const uint32_t k1 = __float_as_uint(cost4[i].w) & 3u; stN[0] = right[i]; stI[0] = 4 - (int)k1; stN[1] = left[i]; stI[1] = (int)k1; sp = 2; }
+  while (sp > 0) {
+    const int32_t n = stN[--sp]; const int allowed = stI[sp];
+    if (n < 0 || allowed == 1) { e[cnt++] = n; continue; }
+    const uint32_t w = __float_as_uint(cost4[n].w);
+    const int k = allowed == 2 ? (int)((w >> 2) & 1u) : (int)((w >> 4) & 3u);      // 0: n stays one entry; else n is opened k : allowed - k
+    if (k == 0) { e[cnt++] = n; continue; }
+    stN[sp] = right[n]; stI[sp] = allowed - k; ++sp;
+    stN[sp] = left[n]; stI[sp] = k; ++sp;
+  }
+  ent4[i] = make_int4(e[0], e[1], e[2], e[3]);
+}
+#define RT_MAX_TREE_DEPTH 128      // ancestors of a node roots4Kernel can hold (PLOC trees of 100 000 triangles: ~25; deeper: BuildResult::error bit 2)
+RT_DEV int entryCount(const int4 e) { return 2 + (e.z != RT_BVH4_EMPTY ? 1 : 0) + (e.w != RT_BVH4_EMPTY ? 1 : 0); }
+__global__ void __launch_bounds__(256) roots4Kernel(int numNodes, const int32_t* __restrict__ nodeParent, const int4* __restrict__ ent4, uint32_t* __restrict__ lvl4, BuildResult* res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t myStack = 0, isRoot = 0, level = 0;
+  if (i < numNodes) {
+    int32_t path[RT_MAX_TREE_DEPTH];      // path[0] = i ... path[d - 1] = the root
+    int d = 0;
+    for (int32_t p = i; p >= 0; p = nodeParent[p]) { if (d < RT_MAX_TREE_DEPTH) path[d] = p; ++d; }
+    if (d > RT_MAX_TREE_DEPTH) atomicOr(&res->error, 4u);
+    else {
+      uint32_t bound = 0;
+      int j = d - 1;
+      for (;;) {
+        if (j == 0) { isRoot = 1u; break; }
+        const int4 e = ent4[path[j]];
+        int nj = -1;      // the next 4-wide node on the way down: the ancestor of i (or i) among this node's entries, at most three levels below
+        for (int s = 1; s <= 3 && j - s >= 0; ++s) { const int32_t x = path[j - s]; if (x == e.x || x == e.y || x == e.z || x == e.w) { nj = j - s; break; } }
+        if (nj < 0) break;      // i was opened: it lies inside this 4-wide node
+        bound += (uint32_t)entryCount(e) - 1u; ++level; j = nj;
+      }
+      if (isRoot) myStack = bound + (uint32_t)entryCount(ent4[i]) - 1u;
+    }
+    lvl4[i] = isRoot ? level : 0xFFFFFFFFu;
+  }
+  // one atomic per workgroup and result (thousands of atomics on one word would take longer than the kernel)
+  __shared__ uint32_t sStack, sCount, sLevel;
+  if (threadIdx.x == 0) { sStack = 0u; sCount = 0u; sLevel = 0u; }
+  __syncthreads();
+  const unsigned long long rootMask = __ballot(isRoot != 0u);
+  for (int o = 32; o > 0; o >>= 1) { myStack = max(myStack, (uint32_t)__shfl_down((int)myStack, o)); level = max(level, (uint32_t)__shfl_down((int)level, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(&sStack, myStack); atomicMax(&sLevel, level); atomicAdd(&sCount, (uint32_t)__popcll(rootMask)); }
+  __syncthreads();
+  if (threadIdx.x == 0 && sCount) { atomicMax(&res->stack4, sStack); atomicMax(&res->depth4, sLevel + 1u); atomicAdd(&res->nodes4, sCount); }
+}
+// The 4-wide node of binary node i, if it is one: its entries' boxes from the binary tree's (triBox / nodeBox of the latest refit).
+__global__ void emitNodes4(int n, const uint32_t* __restrict__ order, const float* __restrict__ triBox, const float* __restrict__ nodeBox,
+                           const int4* __restrict__ ent4, const uint32_t* __restrict__ lvl4, Bvh4Node* __restrict__ nodes4) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n - 1) return;
-  const auto small = [&](int32_t x) { return cnt0 != nullptr && cnt0[x] + 1u <= leafTris; };
-  int depth = 0;
-  for (int p = nodeParent[i]; p >= 0; p = nodeParent[p]) ++depth;
-  if (depth & 1) return;
-  if (depth != 0 && small(i)) return;      // inside a multi-leaf: nobody refers to it (the root is always a node)
-  int32_t refs[4], boxOf[4]; int cnt = 0;      // boxOf: the leaf slot (< 0: ~slot) or node whose box the entry carries
-  const int32_t ch[2] = {left[i], right[i]};
-  for (int s = 0; s < 2; ++s) {
-    if (ch[s] < 0) { refs[cnt] = ch[s]; boxOf[cnt++] = ch[s]; }
-    else if (small(ch[s])) { refs[cnt] = multiLeafRef(ch[s], left, cnt0); boxOf[cnt++] = ch[s]; }
-    else {
-      const int32_t g[2] = {left[ch[s]], right[ch[s]]};
-      for (int q = 0; q < 2; ++q) {
-        if (g[q] >= 0 && small(g[q])) { refs[cnt] = multiLeafRef(g[q], left, cnt0); boxOf[cnt++] = g[q]; }
-        else { refs[cnt] = g[q]; boxOf[cnt++] = g[q]; }
-      }
-    }
-  }
+  const uint32_t level = lvl4[i];
+  if (level == 0xFFFFFFFFu) return;
+  const int4 e4 = ent4[i];
+  const int32_t refs[4] = {e4.x, e4.y, e4.z, e4.w};
   Bvh4Node nd;
   for (int k = 0; k < 4; ++k) {
-    if (k < cnt) {
-      const float* b = boxOf[k] < 0 ? &triBox[6 * (size_t)order[~boxOf[k]]] : &nodeBox[6 * (size_t)boxOf[k]];
+    if (refs[k] != RT_BVH4_EMPTY) {
+      const float* b = refs[k] < 0 ? &triBox[6 * (size_t)order[~refs[k]]] : &nodeBox[6 * (size_t)refs[k]];
       nd.minx[k] = b[0]; nd.miny[k] = b[1]; nd.minz[k] = b[2]; nd.maxx[k] = b[3]; nd.maxy[k] = b[4]; nd.maxz[k] = b[5];
-      nd.ref[k] = refs[k];
     } else {
       nd.minx[k] = nd.miny[k] = nd.minz[k] = __builtin_inff(); nd.maxx[k] = nd.maxy[k] = nd.maxz[k] = -__builtin_inff();
-      nd.ref[k] = RT_BVH4_EMPTY;
     }
+    nd.ref[k] = refs[k];
     nd.pad[k] = 0;
   }
-  nd.pad[0] = depth >> 1;      // level in the 4-wide tree (read by -DRT_TRACE_STATS builds only)
+  nd.pad[0] = (int32_t)level;      // level in the 4-wide tree (read by -DRT_TRACE_STATS builds and tools/probes only)
   nodes4[i] = nd;
 }
 // Leaf slots in depth-first order of the finished tree.  PLOC starts from the Morton order, and the clusters it merges are neighbours
@@ -645,12 +682,11 @@ __global__ void emitTop(int count, const int32_t* __restrict__ topList, const in
 }
 
 // ---- the list of nodes at the tree's top (for the trace kernel's LDS table), on the device -----------------------------------------
-// The first `capacity` 4-wide nodes in breadth-first order (4-wide nodes = the binary nodes of even depth, rtggx_device.h): their list
-// and every node's rank in it (topRank: -1 elsewhere, cleared by the caller).  One workgroup walks the tree level by level; the order
-// is the one a queue would give: a node's internal grandchildren left to right, nodes in list order.
-__global__ void __launch_bounds__(128) planTopKernel(uint32_t capacity, int32_t root, uint32_t numNodes, const int32_t* __restrict__ left, const int32_t* __restrict__ right,
-                                                     const uint32_t* __restrict__ cnt0, uint32_t leafTris, int32_t* __restrict__ topList, int32_t* __restrict__ topRank, BuildResult* res) {
-  const auto small = [&](int32_t x) { return cnt0 != nullptr && cnt0[x] + 1u <= leafTris; };      // a multi-leaf of the 4-wide tree (emitNodes4), not a node
+// The first `capacity` 4-wide nodes in breadth-first order: their list and every node's rank in it (topRank: -1 elsewhere, cleared by
+// the caller).  One workgroup walks the tree level by level through the 4-wide entries (ent4); the order is the one a queue would give:
+// a node's internal entries in entry order, nodes in list order.
+__global__ void __launch_bounds__(128) planTopKernel(uint32_t capacity, int32_t root, uint32_t numNodes, const int4* __restrict__ ent4,
+                                                     int32_t* __restrict__ topList, int32_t* __restrict__ topRank, BuildResult* res) {
   __shared__ int32_t list[128]; __shared__ uint32_t offs[128]; __shared__ uint32_t sCount, sHead;
   if (capacity > 128u) capacity = 128u;
   if (threadIdx.x == 0) { sCount = 0u; sHead = 0u; if (root >= 0 && numNodes > 0u && capacity > 0u) { list[0] = root; sCount = 1u; } }
@@ -658,25 +694,21 @@ __global__ void __launch_bounds__(128) planTopKernel(uint32_t capacity, int32_t 
   for (;;) {
     const uint32_t head = sHead, count = sCount;
     if (head >= count || count >= capacity) break;
-    // the (at most four) grandchildren of my node that are 4-wide nodes themselves, in entry order; -1: none
-    int32_t g0 = -1, g1 = -1, g2 = -1, g3 = -1;
+    // the (at most four) entries of my node that are 4-wide nodes themselves, in entry order; -1: none
+    int32_t g[4] = {-1, -1, -1, -1};
     if (head + threadIdx.x < count) {
-      const int32_t v = list[head + threadIdx.x];
-      const int32_t c0 = left[v], c1 = right[v];
-      if (c0 >= 0 && !small(c0)) { const int32_t a = left[c0], b = right[c0]; if (a >= 0 && !small(a)) g0 = a; if (b >= 0 && !small(b)) g1 = b; }
-      if (c1 >= 0 && !small(c1)) { const int32_t a = left[c1], b = right[c1]; if (a >= 0 && !small(a)) g2 = a; if (b >= 0 && !small(b)) g3 = b; }
+      const int4 e = ent4[list[head + threadIdx.x]];
+      const int32_t r[4] = {e.x, e.y, e.z, e.w};
+      for (int k = 0; k < 4; ++k) if (r[k] >= 0 && r[k] != RT_BVH4_EMPTY) g[k] = r[k];
     }
-    const uint32_t k = (g0 >= 0 ? 1u : 0u) + (g1 >= 0 ? 1u : 0u) + (g2 >= 0 ? 1u : 0u) + (g3 >= 0 ? 1u : 0u);
+    const uint32_t k = (g[0] >= 0 ? 1u : 0u) + (g[1] >= 0 ? 1u : 0u) + (g[2] >= 0 ? 1u : 0u) + (g[3] >= 0 ? 1u : 0u);
     offs[threadIdx.x] = k;
     __syncthreads();
     if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < count - head; ++t) { const uint32_t v = offs[t]; offs[t] = run; run += v; } sHead = count; sCount = min(capacity, count + run); }
     __syncthreads();
     {
       uint32_t pos = count + offs[threadIdx.x];
-      if (g0 >= 0) { if (pos < capacity) list[pos] = g0; ++pos; }
-      if (g1 >= 0) { if (pos < capacity) list[pos] = g1; ++pos; }
-      if (g2 >= 0) { if (pos < capacity) list[pos] = g2; ++pos; }
-      if (g3 >= 0) { if (pos < capacity) list[pos] = g3; ++pos; }
+      for (int q = 0; q < 4; ++q) if (g[q] >= 0) { if (pos < capacity) list[pos] = g[q]; ++pos; }
     }
     __syncthreads();
   }
@@ -695,8 +727,6 @@ __global__ void __launch_bounds__(128) planTopKernel(uint32_t capacity, int32_t 
 // treelet of level l if it is pending, its count fits, and its parent's does not.  The treelet is the pending part of its subtree.
 // An item of a treelet: (node, left ref, right ref); a ref is >= 0: position of another item of the same treelet (its box is in LDS);
 // 0xC0000000 | s: leaf slot s (the primitive's box); 0x80000000 | n: node n placed by a lower level (its box is final in nodeBox).
-struct RefitTreelet { uint32_t itemBegin, roundBegin, numRounds, pad; };
-RT_DEV uint32_t treeletBase(const BuildResult* res, int level) { uint32_t b = 0; for (int l = 0; l < level; ++l) b += res->treelets[l]; return b; }
 __global__ void treeletRootsKernel(int numNodes, int level, const uint32_t* __restrict__ cntPrev, const uint32_t* __restrict__ cntCur, const int32_t* __restrict__ nodeParent,
                                    int32_t* __restrict__ roots, BuildResult* res) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -842,14 +872,14 @@ template <typename T> static void freeAliased(T* (&buf)[RT_SETS]) {
 static void freeTopo(BvhTopo& t) {
   hipFree(t.order); hipFree(t.left); hipFree(t.right); hipFree(t.nodeParent); hipFree(t.leafParent); hipFree(t.nodeBox); hipFree(t.triBox);
   for (auto& c : t.cnt) { hipFree(c); c = nullptr; }
-  hipFree(t.roundBase); hipFree(t.dTreelets); hipFree(t.dRefitItems); hipFree(t.dRefitRounds); hipFree(t.treeletRoots); hipFree(t.topList); hipFree(t.topRank); hipFree(t.dResult);
+  hipFree(t.roundBase); hipFree(t.dTreelets); hipFree(t.dRefitItems); hipFree(t.dRefitRounds); hipFree(t.treeletRoots); hipFree(t.topList); hipFree(t.topRank); hipFree(t.ent4); hipFree(t.lvl4); hipFree(t.cost4); hipFree(t.dResult);
   if (t.hResult) hipHostFree(t.hResult);
   t = BvhTopo{};
 }
 
 // ---- a build as a list of launches ------------------------------------------------------------------------------------------------
 struct BuildScratch {
-  uint32_t *codes[2] = {}, *order2 = nullptr, *hist = nullptr, *chunkSums = nullptr, *bounds = nullptr, *arrive = nullptr;
+  uint32_t *codes[2] = {}, *order2 = nullptr, *hist = nullptr, *chunkSums = nullptr, *bounds = nullptr;
   int32_t *clRef[2] = {}, *nn = nullptr; float* clBox[2] = {}; uint2* blockCounts = nullptr; PlocState* state = nullptr;
   float* vertsSnapshot = nullptr;      // a rebuild beside the frames works on a copy of the vertices it started from
 };
@@ -863,7 +893,7 @@ struct BuildJob {
   uint32_t numTris = 0, numVerts = 0;
 };
 static void freeScratch(BuildScratch& s) {
-  hipFree(s.codes[0]); hipFree(s.codes[1]); hipFree(s.order2); hipFree(s.hist); hipFree(s.chunkSums); hipFree(s.bounds); hipFree(s.arrive);
+  hipFree(s.codes[0]); hipFree(s.codes[1]); hipFree(s.order2); hipFree(s.hist); hipFree(s.chunkSums); hipFree(s.bounds);
   hipFree(s.clRef[0]); hipFree(s.clRef[1]); hipFree(s.nn); hipFree(s.clBox[0]); hipFree(s.clBox[1]); hipFree(s.blockCounts); hipFree(s.state); hipFree(s.vertsSnapshot);
   s = BuildScratch{};
 }
@@ -885,6 +915,7 @@ static int allocTopo(BvhTopo& t, uint32_t n) {
   RT_HIP(hipMalloc(&t.dTreelets, sizeof(RefitTreelet) * nn)); RT_HIP(hipMalloc(&t.dRefitItems, sizeof(int4) * nn)); RT_HIP(hipMalloc(&t.dRefitRounds, 4 * (2 * nn + 64)));
   RT_HIP(hipMalloc(&t.treeletRoots, 4 * nn));
   RT_HIP(hipMalloc(&t.topList, 4 * 128)); RT_HIP(hipMalloc(&t.topRank, 4 * nn));
+  RT_HIP(hipMalloc(&t.ent4, sizeof(int4) * nn)); RT_HIP(hipMalloc(&t.lvl4, 4 * nn)); RT_HIP(hipMalloc(&t.cost4, sizeof(float4) * nn));
   RT_HIP(hipMalloc(&t.dResult, sizeof(BuildResult))); RT_HIP(hipHostMalloc(&t.hResult, sizeof(BuildResult)));
   memset(t.hResult, 0, sizeof(BuildResult));
   return 0;
@@ -892,7 +923,7 @@ static int allocTopo(BvhTopo& t, uint32_t n) {
 static int allocScratch(BuildScratch& s, uint32_t n, uint32_t nv, bool snapshot) {
   const size_t nn = n > 1 ? n : 2, nb = (n + 255) / 256;
   RT_HIP(hipMalloc(&s.codes[0], 4 * nn)); RT_HIP(hipMalloc(&s.codes[1], 4 * nn)); RT_HIP(hipMalloc(&s.order2, 4 * nn));
-  RT_HIP(hipMalloc(&s.hist, 4 * 256 * nb)); RT_HIP(hipMalloc(&s.chunkSums, 4 * ((256 * nb + 1023) / 1024 + 1))); RT_HIP(hipMalloc(&s.bounds, 4 * 8)); RT_HIP(hipMalloc(&s.arrive, 4 * (nn + 1)));
+  RT_HIP(hipMalloc(&s.hist, 4 * 256 * nb)); RT_HIP(hipMalloc(&s.chunkSums, 4 * ((256 * nb + 1023) / 1024 + 1))); RT_HIP(hipMalloc(&s.bounds, 4 * 8));
   RT_HIP(hipMalloc(&s.clRef[0], 4 * nn)); RT_HIP(hipMalloc(&s.clRef[1], 4 * nn)); RT_HIP(hipMalloc(&s.nn, 4 * nn));
   RT_HIP(hipMalloc(&s.clBox[0], 24 * nn)); RT_HIP(hipMalloc(&s.clBox[1], 24 * nn));
   RT_HIP(hipMalloc(&s.blockCounts, sizeof(uint2) * nb)); RT_HIP(hipMalloc(&s.state, 2 * sizeof(PlocState)));
@@ -934,15 +965,8 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
   }
   t.root = n == 1 ? ~0 : -1; t.refittable = false;
   if (n > 1) {
-    static const bool radixTree = getenv("RTGGX_BVH_RADIX_TREE") != nullptr;     // A/B switch: the Karras tree this build started with (cannot be refitted)
-    const int radius = getenv("RTGGX_PLOC_RADIUS") ? atoi(getenv("RTGGX_PLOC_RADIUS")) : RT_PLOC_RADIUS;
-    if (radixTree) {
-      t.root = 0;
-      steps.push_back([=](hipStream_t st) { hipMemsetAsync(s.arrive, 0, 4 * ((size_t)n + 1), st); });
-      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(hierarchyKernel, dim3(nb), dim3(256), 0, st, (const uint32_t*)s.codes[0], (int)n, t.left, t.right, t.nodeParent, t.leafParent); });
-      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(fitKernel, dim3(nb), dim3(256), 0, st, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right,
-                                                               (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent, t.nodeBox, s.arrive); });
-    } else {
+    const int radius = RT_PLOC_RADIUS;
+    {
       t.root = (int32_t)n - 2; t.refittable = true;      // the last node created
       PlocArrays A;
       A.clRef[0] = s.clRef[0]; A.clRef[1] = s.clRef[1]; A.clBox[0] = s.clBox[0]; A.clBox[1] = s.clBox[1]; A.nn = s.nn;
@@ -956,7 +980,7 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
         steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocScatter, dim3(nb), dim3(256), 0, st, s.state, r, (const uint2*)s.blockCounts, A); });
       }
       steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(plocFinal, dim3(1), dim3(1024), 0, st, (const PlocState*)s.state, rounds, radius, n, A); });
-      // leaf slots in depth-first order (multi-leaves: emitNodes4); scratch: codes[1] = ranks, order2 / clRef[0] = the moved arrays
+      // leaf slots in depth-first order (a subtree's triangles are consecutive); scratch: codes[1] = ranks, order2 / clRef[0] = the moved arrays
       steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(leafRankKernel, dim3(nb), dim3(256), 0, st, (int)n, (const int32_t*)t.left, (const int32_t*)t.right, (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent,
                                                                (const uint32_t*)t.cnt[0], s.codes[1]); });
       steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(leafPermuteKernel, dim3(nb), dim3(256), 0, st, (int)n, (const uint32_t*)s.codes[1], (const uint32_t*)t.order, (const int32_t*)t.leafParent,
@@ -975,9 +999,14 @@ static void planBuildSteps(rtggx_context* c, uint32_t slot, BuildJob& job, const
     const uint32_t topCap = slot == 0 ? RT_TOP_SLOT0 : RT_TOP_SLOT1;
     const int32_t root = t.root;
     steps.push_back([=](hipStream_t st) { hipMemsetAsync(t.topRank, 0xFF, 4 * (size_t)(n - 1), st); });
-    const uint32_t* cnt0 = t.refittable ? t.cnt[0] : nullptr; const uint32_t leafTris = t.refittable ? c->leafTris : 1u;
-    t.leafTris = leafTris;
-    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(planTopKernel, dim3(1), dim3(128), 0, st, topCap, root, n - 1, (const int32_t*)t.left, (const int32_t*)t.right, cnt0, leafTris, t.topList, t.topRank, t.dResult); });
+    // the 4-wide collapse (by surface area), then the table of its top
+    const float wArea = c->collapseWeights[0], wTris = c->collapseWeights[1];
+    for (int l = 0; l < RT_TREELET_LEVELS; ++l)
+      steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(collapseCostTreelets, dim3(l ? 64u : std::min<uint32_t>(std::max<uint32_t>((n + RT_TREELET_NODES / 4 - 1) / (RT_TREELET_NODES / 4), 1u), 2048u)), dim3(256), 0, st, l,
+                                                               (const RefitTreelet*)t.dTreelets, (const int4*)t.dRefitItems, (const uint32_t*)t.dRefitRounds, (const float*)t.nodeBox, (const uint32_t*)t.cnt[0], root, wArea, wTris, t.cost4, (const BuildResult*)t.dResult); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(entries4Kernel, dim3(nb), dim3(256), 0, st, (int)n - 1, (const int32_t*)t.left, (const int32_t*)t.right, (const float4*)t.cost4, t.ent4); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(roots4Kernel, dim3(nb), dim3(256), 0, st, (int)n - 1, (const int32_t*)t.nodeParent, (const int4*)t.ent4, t.lvl4, t.dResult); });
+    steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(planTopKernel, dim3(1), dim3(128), 0, st, topCap, root, n - 1, (const int4*)t.ent4, t.topList, t.topRank, t.dResult); });
     steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(depthKernel, dim3(nb), dim3(256), 0, st, (int)n, (const int32_t*)t.nodeParent, (const int32_t*)t.leafParent, &t.dResult->depth); });
     steps.push_back([=](hipStream_t st) { hipLaunchKernelGGL(treeCostKernel, dim3(std::min<uint32_t>((n - 1 + 255) / 256, 48u)), dim3(256), 0, st, (int)n - 1, (const float*)t.nodeBox, &t.dResult->cost); });
   }
@@ -992,8 +1021,7 @@ static void emitTree(MeshDev& m, const BvhTopo& t, uint32_t set, bool full, hipS
   if (n > 1) {
     if (full) hipMemsetAsync(m.nodes4Buf[set], 0, sizeof(Bvh4Node) * (size_t)(n - 1), s);
     hipLaunchKernelGGL(emitNodes, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right, (const float*)t.nodeBox, m.nodesBuf[set]);
-    hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const int32_t*)t.left, (const int32_t*)t.right,
-                       (const int32_t*)t.nodeParent, (const float*)t.nodeBox, t.refittable ? (const uint32_t*)t.cnt[0] : (const uint32_t*)nullptr, t.leafTris, m.nodes4Buf[set]);
+    hipLaunchKernelGGL(emitNodes4, dim3(nb), dim3(256), 0, s, (int)n, (const uint32_t*)t.order, (const float*)t.triBox, (const float*)t.nodeBox, (const int4*)t.ent4, (const uint32_t*)t.lvl4, m.nodes4Buf[set]);
     if (t.result.topCount) hipLaunchKernelGGL(emitTop, dim3((t.result.topCount + 63) / 64), dim3(64), 0, s, (int)t.result.topCount, (const int32_t*)t.topList, (const int32_t*)t.topRank, (const Bvh4Node*)m.nodes4Buf[set], m.topBuf[set]);
   }
   m.topCountBuf[set] = n > 1 ? t.result.topCount : 0u;
@@ -1002,18 +1030,21 @@ static void emitTree(MeshDev& m, const BvhTopo& t, uint32_t set, bool full, hipS
 static int harvest(MeshDev& m, BvhTopo& t, uint32_t slot) {
   t.result = *t.hResult;
   if (t.result.error & 1u) { setError("BVH build of mesh %u: more than %u clustering rounds", slot, (unsigned)RT_MAX_ROUNDS); return -3; }
+  if (t.result.error & 4u) { setError("BVH build of mesh %u: the tree is deeper than %d levels", slot, RT_MAX_TREE_DEPTH); return -3; }
   if (t.result.error & 2u) { setError("BVH build of mesh %u: the refit schedule would need more than %d treelet levels", slot, RT_TREELET_LEVELS); return -3; }
   if (t.result.depth > m.depth) m.depth = t.result.depth;
+  m.stack4 = t.result.stack4;
   static const bool log = getenv("RTGGX_BUILD_LOG") != nullptr;
-  if (log) fprintf(stderr, "[rtggx] build of mesh %u: %u triangles, %u rounds (%u clusters handed to the last workgroup, %u at the start of its LDS rounds), treelets %u / %u / %u, table %u, depth %u, cost %.1f\n",
-                   slot, t.numTris, t.result.numRounds, t.result.finalEntry, t.result.finalLds, t.result.treelets[0], t.result.treelets[1], t.result.treelets[2], t.result.topCount, t.result.depth, t.result.cost);
+  if (log) fprintf(stderr, "[rtggx] build of mesh %u: %u triangles, %u rounds (%u clusters handed to the last workgroup, %u at the start of its LDS rounds), treelets %u / %u / %u, table %u, depth %u, %u 4-wide nodes in %u levels (deepest traversal stack %u), cost %.1f\n",
+                   slot, t.numTris, t.result.numRounds, t.result.finalEntry, t.result.finalLds, t.result.treelets[0], t.result.treelets[1], t.result.treelets[2], t.result.topCount, t.result.depth,
+                   t.result.nodes4, t.result.depth4, t.result.stack4, t.result.cost);
   if (log && t.numTris > 1 && t.numTris <= 64) {      // small trees: the arrays themselves
     const uint32_t nn = t.numTris - 1;
     std::vector<int32_t> l(nn), r(nn), tl(128), tr(nn); std::vector<uint32_t> c0(nn);
     hipMemcpy(l.data(), t.left, 4 * nn, hipMemcpyDeviceToHost); hipMemcpy(r.data(), t.right, 4 * nn, hipMemcpyDeviceToHost); hipMemcpy(c0.data(), t.cnt[0], 4 * nn, hipMemcpyDeviceToHost);
     hipMemcpy(tl.data(), t.topList, 4 * 128, hipMemcpyDeviceToHost); hipMemcpy(tr.data(), t.topRank, 4 * nn, hipMemcpyDeviceToHost);
     for (uint32_t i = 0; i < nn; ++i) fprintf(stderr, "   node %u: left %d right %d cnt0 %u topRank %d\n", i, l[i], r[i], c0[i], tr[i]);
-    fprintf(stderr, "   topList:"); for (uint32_t k = 0; k < t.result.topCount; ++k) fprintf(stderr, " %d", tl[k]); fprintf(stderr, "  (root %d, leafTris %u)\n", t.root, t.leafTris);
+    fprintf(stderr, "   topList:"); for (uint32_t k = 0; k < t.result.topCount; ++k) fprintf(stderr, " %d", tl[k]); fprintf(stderr, "  (root %d)\n", t.root);
   }
   return 0;
 }
@@ -1022,7 +1053,7 @@ static int harvest(MeshDev& m, BvhTopo& t, uint32_t slot) {
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
   MeshDev& m = c->mesh[slot];
   const uint32_t n = m.numTris;
-  m.root = -1; m.depth = 0;
+  m.root = -1; m.depth = 0; m.stack4 = 0;
   freeBuildProducts(m);       // also the nodes / leaf triangles of every input set, and a rebuild in progress (the caller has synchronised)
   if (n == 0) return 0;
   // a mesh that deforms is built from its newest shape
@@ -1069,16 +1100,25 @@ int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s) {
 // refits run on, behind the frame's refit.  When the last launch has ended (the host polls an event at the start of a frame) the new
 // topology replaces the old one: the frame's refit, a moment later on the same stream, is the first to use it.  The buffers of the two
 // topologies and the build's scratch memory are allocated once per mesh and swapped; nothing is freed, nothing waits.
+// The second topology, the build's scratch memory and the event, allocated ONCE, when the mesh begins to deform (rtggx_refit_as's first
+// call for it, which synchronises anyway): ~30 allocations that may serialise with work in flight have no place in the frame loop.  A
+// failure leaves no half-made job behind (a later startRebuild would plan kernels over null pointers).
+int prepareRebuild(rtggx_context* c, uint32_t slot) {
+  MeshDev& m = c->mesh[slot];
+  if (m.job || !m.topo.refittable || m.numTris < 2) return 0;
+  BuildJob* job = new BuildJob();
+  job->numTris = m.numTris; job->numVerts = m.numVerts;
+  int r = allocTopo(job->topo, m.numTris);
+  if (!r) r = allocScratch(job->s, m.numTris, m.numVerts, true);
+  if (!r && hipEventCreateWithFlags(&job->done, hipEventDisableTiming) != hipSuccess) { setError("prepareRebuild: hipEventCreate failed"); r = -2; }
+  if (r) { if (job->done) hipEventDestroy(job->done); freeTopo(job->topo); freeScratch(job->s); delete job; return r; }
+  m.job = job;
+  return 0;
+}
 int startRebuild(rtggx_context* c, uint32_t slot, uint32_t set) {
   MeshDev& m = c->mesh[slot];
   if (!m.deforming || !m.topo.refittable || m.numTris < 2) return 0;
-  if (!m.job) {
-    m.job = new BuildJob();
-    m.job->numTris = m.numTris; m.job->numVerts = m.numVerts;
-    { const int r = allocTopo(m.job->topo, m.numTris); if (r) return r; }
-    { const int r = allocScratch(m.job->s, m.numTris, m.numVerts, true); if (r) return r; }
-    RT_HIP(hipEventCreateWithFlags(&m.job->done, hipEventDisableTiming));
-  }
+  if (!m.job) { const int r = prepareRebuild(c, slot); if (r) return r; }      // (a mesh that was built again since it began to deform: buildLbvh frees the job)
   BuildJob& job = *m.job;
   if (job.active) return 0;
   planBuildSteps(c, slot, job, nullptr, m.vertsBuf[set]);
@@ -1091,7 +1131,7 @@ int continueRebuild(rtggx_context* c, uint32_t slot, hipStream_t s, uint32_t max
   if (!m.job || !m.job->active) return 0;
   BuildJob& job = *m.job;
   if (job.allIssued) {
-    if (hipEventQuery(job.done) != hipSuccess) return 0;      // still running
+    if (maxSteps != 0u || hipEventQuery(job.done) != hipSuccess) return 0;      // (asked to issue: nothing left to) / still running
     job.active = false;
     { const int r = harvest(m, job.topo, slot); if (r) return r; }
     std::swap(m.topo, job.topo);
@@ -1100,6 +1140,7 @@ int continueRebuild(rtggx_context* c, uint32_t slot, hipStream_t s, uint32_t max
     *swapped = true;
     return 0;
   }
+  if (maxSteps == 0u) return 0;
   for (uint32_t k = 0; k < maxSteps && job.next < job.steps.size(); ++k) job.steps[job.next++](s);
   RT_HIP(hipGetLastError());
   if (job.next == job.steps.size()) { RT_HIP(hipEventRecord(job.done, s)); job.allIssued = true; }
@@ -1143,8 +1184,7 @@ int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s) {
   }
   emitTree(m, t, set, m.topoVersionOfSet[set] != m.topoVersion, s);
   m.topoVersionOfSet[set] = m.topoVersion;
-  static const bool noCost = getenv("RTGGX_NO_COST_SAMPLE") != nullptr;      // measurement
-  if (n > 1 && !m.costInFlight && (m.refits & 3u) == 0u && !noCost) {
+  if (n > 1 && !m.costInFlight && (m.refits & 3u) == 0u) {
     { const int r = launchTreeCost(m, s); if (r) return r; }
     RT_HIP(hipMemcpyAsync(m.hCost, m.dCost, 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipEventRecord(m.evCost, s));

@@ -368,8 +368,11 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
   RayRec* dst = A.rays + (size_t)bin * A.binSlots;
   HitKey* keys = A.hits + (size_t)bin * A.binSlots;      // every ray starts as a miss at TMax
   if (wantRefl) { const uint32_t k = (uint32_t)__popcll(maskR & below); dst[k] = rr; keys[k] = hitKey(RT_RAY_TMAX, 0xFFFFFFFFu); }
-  if (wantDiff) { const uint32_t k = nR + (uint32_t)__popcll(maskD & below); dst[k] = rd; keys[k] = hitKey(RT_RAY_TMAX, 0xFFFFFFFFu); }
-  const uint32_t nRaysInBin = nR + (uint32_t)__popcll(maskD);
+  // (a diffuse ray needs bins of two rays per pixel: rtggx_update_frame grows them with the first metallic below 1, and launchRayTrace
+  // refuses a frame whose materials and bins disagree.  The bound here is the last line: a record is never written beyond its bin.)
+  const uint32_t kD = nR + (uint32_t)__popcll(maskD & below);
+  if (wantDiff && kD < A.binSlots) { dst[kD] = rd; keys[kD] = hitKey(RT_RAY_TMAX, 0xFFFFFFFFu); }
+  const uint32_t nRaysInBin = min(nR + (uint32_t)__popcll(maskD), A.binSlots);
   if (A.binWork == nullptr) {
     if (lane == 0) A.binCount[bin] = nRaysInBin;
     return;
@@ -504,11 +507,13 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   passRows(fp, ROWS_GBUFFER, rb, re);
   if (re <= rb) return 0;
   const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
+  if ((fp.mat.RoughMetals[0][1] < 1.0f || fp.mat.RoughMetals[1][1] < 1.0f) && c->binSlots < RT_BIN) {
+    setError("rtggx_ray_trace: a material with metallic below 1 (a diffuse ray per pixel as well) but ray bins of %u slots: rtggx_update_frame sizes them", c->binSlots); return -1;
+  }
   GenArgs G;
   // ray generation starts the next frame's visibility pass (GenArgs)
   { const uint32_t nextFrame = c->frameCounter + 1u, nextSet = (c->setIndex + 1u) % RT_SETS;
-    static const bool clearNext = !(getenv("RTGGX_CLEAR_NEXT") && atoi(getenv("RTGGX_CLEAR_NEXT")) == 0);      // measurement: 0 = every frame clears its own target (the kernel of rounds 1 and 2)
-    G.visNext = clearNext ? c->visDepthBuf[nextFrame % RT_VIS_RING] : nullptr; G.zeroNext0 = c->largeCountBase + (nextFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
+    G.visNext = c->visDepthBuf[nextFrame % RT_VIS_RING]; G.zeroNext0 = c->largeCountBase + (nextFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
     c->visClearedFor = G.visNext; c->visClearedRows[0] = rb; c->visClearedRows[1] = re; }
   G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
@@ -520,16 +525,14 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   const uint32_t splitWork = c->splitWork, splitMaxShift = c->splitMaxShift;
   const uint32_t sliceShift = chooseSliceShift(c, true, G.numTiles * 4u);
   // "wide" launches: few enough rays that the traversal does not fill the chip for long (trace.hip launchTrace, capi.hip rtggx_ray_trace)
-  static const uint32_t wideRays = getenv("RTGGX_WIDE_RAYS") ? (uint32_t)atoi(getenv("RTGGX_WIDE_RAYS")) : RT_WIDE_RAYS;
-  c->lastTraceSmall = sliceShift > 0u || c->lastFrameRays < wideRays;
+  c->lastTraceSmall = c->forcePlacement >= 0 ? c->forcePlacement == 1 : (sliceShift > 0u || c->lastFrameRays < RT_WIDE_RAYS);
   const bool adaptive = splitWork != 0u && sliceShift == 0u;
   c->lastTraceAdaptive = adaptive;
   // the split list is sized from the demand of an earlier frame (copied back asynchronously, like the ray counters)
   const uint32_t splitCap = !adaptive ? 0u : c->splitCapForced != 0xFFFFFFFFu ? c->splitCapForced
                           : c->splitDemand == 0u ? 0u : ((c->splitDemand + c->splitDemand / 8u + 64u + 31u) / 32u) * 32u;
   G.binWork = adaptive ? c->binWork : nullptr; G.splitList = c->splitList; G.splitCount = c->splitCount;
-  static const uint32_t frontWork = getenv("RTGGX_SPLIT_FRONT") ? (uint32_t)atoi(getenv("RTGGX_SPLIT_FRONT")) : RT_SPLIT_FRONT;
-  G.frontWork = frontWork < splitWork ? frontWork : splitWork;
+  G.frontWork = RT_SPLIT_FRONT < splitWork ? RT_SPLIT_FRONT : splitWork;
   G.splitWork = splitWork; G.splitMaxShift = splitMaxShift < 3u ? splitMaxShift : 3u; G.splitCap = splitCap < RT_SPLIT_CAP ? splitCap : RT_SPLIT_CAP;
   if (sGen != s && c->attachEvents) hipExtLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, sGen, nullptr, c->evGen, 0, (const FrameParams*)(c->dParams + c->slot), G);
   else hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, sGen, c->dParams + c->slot, G);

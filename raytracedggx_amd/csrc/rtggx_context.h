@@ -46,7 +46,8 @@ struct BuildResult {
   uint32_t numRounds;                        // PLOC rounds (= entries of roundBase - 1)
   uint32_t treelets[RT_TREELET_LEVELS];      // refit treelets per level (lbvh.hip "treelets")
   uint32_t topCount;                         // entries of the LDS table of the tree's top
-  uint32_t depth;                            // deepest leaf (number of ancestors): bounds the traversal stack
+  uint32_t depth;                            // deepest leaf (number of ancestors)
+  uint32_t stack4, depth4, nodes4;           // the 4-wide collapse (lbvh.hip roots4Kernel): the most entries a traversal's stack can hold, its levels, its nodes
   uint32_t error;                            // bit 0: more than RT_MAX_ROUNDS rounds; bit 1: a treelet level beyond RT_TREELET_LEVELS would be needed
   uint32_t itemCursor, roundCursor;
   uint32_t finalEntry, finalLds;             // statistics of plocFinal: clusters handed to it, clusters when its LDS rounds began
@@ -65,10 +66,11 @@ struct BvhTopo {
   uint32_t* roundBase = nullptr;             // device: first node of PLOC round k
   void *dTreelets = nullptr, *dRefitItems = nullptr; uint32_t* dRefitRounds = nullptr; int32_t* treeletRoots = nullptr;
   int32_t *topList = nullptr, *topRank = nullptr;
+  float4* cost4 = nullptr;       // the collapse's dynamic programme per binary node: F(n, 1..3) and the choices (lbvh.hip collapseCostTreelets)
+  int4* ent4 = nullptr; uint32_t* lvl4 = nullptr;      // the 4-wide collapse: per binary node the entries it has as a 4-wide node, and its level there (~0: it is not one)
   BuildResult* dResult = nullptr; BuildResult* hResult = nullptr;      // device record, pinned copy
   BuildResult result{};                      // the host's copy, valid once the build has ended
   uint32_t numTris = 0; int32_t root = -1;
-  uint32_t leafTris = 1;                     // triangles a leaf of the 4-wide tree may hold (emitNodes4); fixed when the build is planned
   bool refittable = false;                   // a PLOC build (the Karras radix tree of RTGGX_BVH_RADIX_TREE has no rounds)
 };
 
@@ -110,7 +112,8 @@ struct MeshDev {
   uint32_t topCount = 0; uint32_t topCountBuf[RT_SETS] = {};
   Bvh4Node* top = nullptr; Bvh4Node* topBuf[RT_SETS] = {};
   int32_t root = -1;             // 0, or ~0 for a single-triangle mesh
-  uint32_t depth = 0;            // deepest leaf (number of ancestors): bounds the traversal stack
+  uint32_t depth = 0;            // deepest leaf (number of ancestors)
+  uint32_t stack4 = 0;           // the most entries a traversal of the 4-wide tree can have on its stack (BuildResult::stack4 of the latest topology)
   float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};   // vertex bounds (Morton normalisation box)
 };
 
@@ -144,7 +147,12 @@ struct Scene {
 
 }  // namespace rt
 
-namespace rt { struct PreparedToneMap { alignas(16) unsigned char targets[192]; uint32_t gridX, gridY; }; }      // a tone map ready to launch (denoise.hip)
+// The 4-wide collapse's objective (lbvh.hip): cost of a 4-wide node = AREA x half-area / the root's + TRIS x triangles / all triangles.
+#ifndef RT_COLLAPSE_AREA_WEIGHT
+#define RT_COLLAPSE_AREA_WEIGHT 1.0f
+#define RT_COLLAPSE_TRIS_WEIGHT 0.0f
+#endif
+#define RT_MAX_PEERS 16      // ranks whose history images a context can map (rtggx_set_history_peers): one node has eight GPUs
 
 struct rtggx_context {
   int device = 0;
@@ -176,20 +184,23 @@ struct rtggx_context {
   hipEvent_t evRefit = nullptr;   // vertices of the current set uploaded and the tree refitted (stream B -> stream C)
   hipEvent_t evRT = nullptr, evSetRead[RT_SETS] = {};   // ray trace done (stream B -> main); last reader of input set i done (the HOST waits for it before stream B is given work that overwrites the set)
   bool setReadRecorded[RT_SETS] = {};
-  // the caller's exchange between frames on a stream of its own (rtggx_get_exchange_stream / rtggx_exchange_begin / _end): multi-GPU strips
-  hipStream_t streamExchange = nullptr; hipEvent_t evExchange = nullptr, evFrameEnd = nullptr; bool exchangePending = false; int lastFrameSet = -1;
   int setReadDeferred = -1;      // the set whose event is still to ride on a later kernel of this frame (capi.hip settleSetRead)
-  // a tone map that waits to be launched beside the NEXT frame's filters (capi.hip rtggx_tone_map), and the events of those launched that way
   double fenceWaitUs = 0.0; uint32_t fenceWaits = 0;      // host time spent waiting at the frames-in-flight fence (rtggx_render_visibility; rtggx_debug_fence_wait)
-  bool toneAside = false;        // off by default since round 3 (rtggx_debug_tone_map_aside, RTGGX_TONEMAP_ASIDE=1)
-  bool tonePending = false, denoiseIssued = false, callerOrdersOnMain = false, toneAsideAllowed = true; rt::PreparedToneMap tonePrepared; uint32_t toneParity = 0;
-  hipEvent_t evTone[2] = {}; bool toneRecorded[2] = {}; uint32_t toneAsideCount = 0, toneBesideCount = 0;
+  // The temporal pass and the tone map as one kernel (denoise.hip temporalToneKernel): rtggx_denoise then writes the back buffer as well and
+  // the rtggx_tone_map that follows it in the same frame has nothing left to launch.  rtggx_debug_fuse_tone_map(ctx, 0): two kernels, as in rounds 1-3.
+  bool fuseToneMap = true, toneMapDone = false, denoiseIssued = false;
+  // Multi-GPU strips: every rank's two history images as mapped into THIS process (rtggx_set_history_peers) -- device table
+  // [2][RT_MAX_PEERS] pointers + [RT_MAX_PEERS + 1] row boundaries; a history tap beyond the exchanged apron reads the owner's image.
+  uint32_t* exchangeTokens = nullptr;      // RTGGX_BUF_EXCHANGE_TOKENS
+  float collapseWeights[2] = {RT_COLLAPSE_AREA_WEIGHT, RT_COLLAPSE_TRIS_WEIGHT};      // rtggx_debug_collapse_weights
+  uint32_t peerWorld = 0; void* dPeerTable = nullptr; std::vector<void*> ipcMapped;      // (what rtggx_history_ipc_open mapped: unmapped by rtggx_destroy)
+  uint32_t lastPlacement[2] = {0, 0};      // key and placement of the most recent rtggx_ray_trace (rtggx_debug_placement)
+  int forcePlacement = -1;       // rtggx_debug_placement: -1 by the ray count; 0 / 1: the placement of a full-size / a small launch whatever the count
   bool fltRflIsFltDff = false;          // the last denoise ran without diffuse passes: FilteredOut == FilteredOut1 and only the latter was written
   bool externalStream = false;
 
   bool vndf = false;             // rtggx_set_sampler
   float rebuildRatio = 1.2f; uint32_t rebuildSteps = 16;      // rtggx_set_refit_policy
-  uint32_t leafTris = 1;         // triangles per leaf of the 4-wide trees built from now on (RTGGX_LEAF_TRIS, rtggx_debug_leaf_tris; 2-4: "multi-leaves", lbvh.hip emitNodes4)
   rt::MeshDev mesh[2];
   rt::EnvDev env;
   float* sh = nullptr;           // 27 floats
@@ -301,11 +312,7 @@ namespace rt {
 // instead of exchanging it.
 enum RowPass { ROWS_GBUFFER /* visibility, ray trace, H filters: +-18 */, ROWS_VFILTER /* +-2 */, ROWS_TEMPORAL /* +-1 */, ROWS_FINAL };
 inline void passRows(const FrameParams& fp, RowPass pass, uint32_t& b, uint32_t& e) {
-  // MEASUREMENT switch (tools/probes/strip_halo_projection.py): RTGGX_GBUFFER_APRON=0 makes the G-buffer passes and H filters cover
-  // the strip's own rows only, as they would if the +-18 halo rows were RECEIVED from the neighbours (the north-star design) instead
-  // of recomputed.  Rows near the strip edges are then wrong: for timing a strip's compute, never for rendering.
-  static const uint32_t gApron = getenv("RTGGX_GBUFFER_APRON") ? (uint32_t)atoi(getenv("RTGGX_GBUFFER_APRON")) : 18u;
-  const uint32_t apron = pass == ROWS_GBUFFER ? gApron : pass == ROWS_VFILTER ? 2u : pass == ROWS_TEMPORAL ? 1u : 0u;
+  const uint32_t apron = pass == ROWS_GBUFFER ? 18u : pass == ROWS_VFILTER ? 2u : pass == ROWS_TEMPORAL ? 1u : 0u;
   b = fp.rowBegin > apron ? fp.rowBegin - apron : 0u;
   e = fp.rowEnd + apron < fp.H ? fp.rowEnd + apron : fp.H;
   if (fp.rowEnd <= fp.rowBegin) { b = e = 0; }
@@ -324,7 +331,8 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
 //                      polls) the new topology replaces the old one between two frames.  Nothing waits.
 int buildLbvh(rtggx_context* c, uint32_t slot, hipStream_t s);
 int startRebuild(rtggx_context* c, uint32_t slot, uint32_t set);      // 1: started, 0: not (one is in progress, or the mesh cannot be refitted), < 0: error
-int continueRebuild(rtggx_context* c, uint32_t slot, hipStream_t s, uint32_t maxSteps, bool* swapped);
+int continueRebuild(rtggx_context* c, uint32_t slot, hipStream_t s, uint32_t maxSteps, bool* swapped);      // maxSteps 0: only ask whether a build whose launches are all out has ended (then the swap); > 0: only issue launches
+int prepareRebuild(rtggx_context* c, uint32_t slot);      // the second topology and the build's scratch memory, once, when a mesh begins to deform
 void abandonRebuild(rtggx_context* c, uint32_t slot);      // (synchronises; before the mesh's buffers are freed)
 int refitLbvh(rtggx_context* c, uint32_t slot, uint32_t set, hipStream_t s);      // boxes of the existing tree from the vertices of input set `set`, into that set's BVH arrays: no host round trip
 void freeBuildProducts(MeshDev& m);
@@ -335,10 +343,8 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
 // 5-7 us, and the frame's two chains had four of them (rocprofv3 kernel trace, profiles/).
 int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);      // hit / miss shading of the traced bins
 int launchTraceRays(rtggx_context* c, const FrameParams& fp, const float* dRays, uint32_t n, float* dOut, hipStream_t s);
-int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done = nullptr, hipEvent_t historyReady = nullptr);      // historyReady: waited for in front of the temporal pass
-int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s);
-bool prepareToneMap(rtggx_context* c, const FrameParams& fp, PreparedToneMap* out);      // false: nothing to do (empty strip)
-int launchPreparedToneMap(rtggx_context* c, const PreparedToneMap& p, hipStream_t s, hipEvent_t done);
+int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream_t s, hipEvent_t done = nullptr, bool fuseToneMap = false);      // fuseToneMap: the last kernel also writes the back buffer
+int launchToneMap(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent_t done = nullptr);
 int decodeEnv(rtggx_context* c, int format, uint32_t size, uint32_t mips, const void* hostData, size_t bytes, hipStream_t s);
 int projectSH(rtggx_context* c, hipStream_t s);
 int unpackVisDepth(rtggx_context* c, uint32_t* dVis, uint32_t* dDepth, hipStream_t s);

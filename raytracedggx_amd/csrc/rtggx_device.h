@@ -75,8 +75,8 @@ RT_DEV float sqrtRN(float x) {              // v_sqrt_f32 (1 ulp), then pick amo
 RT_MATH float exp2Contract(float x) {
   if (!(x > -126.0f)) return x != x ? x : 0.0f;      // (results below the normal range: zero -- the shading path asks for 2^(-9.28 NoV))
   if (!(x < 128.0f)) return x != x ? x : __builtin_inff();
-  const float n = __builtin_rintf(x);
-  const float t = (x - n) * 0.693147180559945f;      // e^t, |t| <= 0.347: Taylor to t^8 (next term 2e-10)
+  const float n = __builtin_fminf(__builtin_rintf(x), 127.0f);      // (x in (127.5, 128): 2^127 x e^t with t up to 0.693 -- finite, as the true value is; 2^128 does not exist)
+  const float t = (x - n) * 0.693147180559945f;      // e^t, |t| <= 0.347 (0.693 in that last half-octave): Taylor to t^8 (next term 2e-10; 1e-7 there)
   float p = 1.0f / 40320.0f;
   p = p * t + 1.0f / 5040.0f; p = p * t + 1.0f / 720.0f; p = p * t + 1.0f / 120.0f; p = p * t + 1.0f / 24.0f;
   p = p * t + 1.0f / 6.0f; p = p * t + 0.5f; p = p * t + 1.0f; p = p * t + 1.0f;
@@ -221,9 +221,9 @@ struct BvhNode {           // 64 B, internal nodes only; node 0 is the root
   int32_t left, right;     // >= 0 internal node, < 0 leaf: ~ref = slot in the triangle array
   int32_t pad[2];
 };
-// The 4-wide node the trace kernel walks: binary node i of even depth with its internal children folded in (their
-// children become its own).  128 B = one L2/L1 cache line per traversal step.  Stored at index i of a sparse array
-// (odd-depth slots unused).
+// The 4-wide node the trace kernel walks: binary node i with the internal children of largest surface area folded in (their children
+// become its own; lbvh.hip "the 4-wide collapse").  128 B = one L2/L1 cache line per traversal step.  Stored at index i of a sparse
+// array (the slots of binary nodes that were folded into another stay unused).
 #define RT_BVH4_EMPTY 0x7FFFFFFF
 struct Bvh4Node {
   float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];

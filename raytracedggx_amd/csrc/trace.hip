@@ -310,35 +310,24 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
         ++stLeafPhase;
 #endif
         if (atLeaf) {
-          // a leaf holds 1-4 consecutive triangles (lbvh.hip emitNodes4): reference ~(first slot | (count - 1) << 28)
-          const uint32_t lr = (uint32_t)~cur, nTri = (lr >> 28) + 1u;
-          const float4* rec = tris + (size_t)(lr & 0x0FFFFFFFu) * 4;
-          // two triangles per round trip: the second one's three words are fetched with the first one's (a leaf of one triangle fetches one)
-          for (uint32_t k = 0; k < nTri; k += 2u, rec += 8) {
-            const bool two = k + 1u < nTri;
-            float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            float4 p0 = q0, p1 = q1, p2 = q2;
-            if (two) { p0 = rec[4]; p1 = rec[5]; p2 = rec[6]; }
-            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
-            asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(p2.x), "+v"(p2.y));
-            asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z), "+v"(p0.w), "+v"(p1.x), "+v"(p1.y), "+v"(p1.z), "+v"(p1.w));
-            // q0 = v0.xyz v1.x | q1 = v1.yz v2.xy | q2 = v2.z prim pad pad
-            const auto test = [&](const float4& t0, const float4& t1, const float4& t2) {
-              const uint32_t id = (INST << 24) | __float_as_uint(t2.y);
-              if (id == skip) return;
-              float t, b1, b2;
-              if (woopTest(r, t0, t1, t2, t, b1, b2) && t > tmin) {
-                const bool closer = t < myT;
-                const bool tie = myId != 0xFFFFFFFFu && t == myT && id < myId;
-                if (closer || tie) { myT = t; myId = id; }
-              }
-            };
-            test(q0, q1, q2);
-            if (two) test(p0, p1, p2);
-#ifdef RT_TRACE_STATS
-            stLeaf += two ? 2u : 1u;
-#endif
+          // a leaf is one triangle: three 16-byte words of its 64-byte record (the primitive id sits in the third as well)
+          const float4* rec = tris + (size_t)(uint32_t)~cur * 4;
+          float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+          asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+          asm volatile("" : "+v"(q2.x), "+v"(q2.y));
+          // q0 = v0.xyz v1.x | q1 = v1.yz v2.xy | q2 = v2.z prim pad pad
+          const uint32_t id = (INST << 24) | __float_as_uint(q2.y);
+          if (id != skip) {
+            float t, b1, b2;
+            if (woopTest(r, q0, q1, q2, t, b1, b2) && t > tmin) {
+              const bool closer = t < myT;
+              const bool tie = myId != 0xFFFFFFFFu && t == myT && id < myId;
+              if (closer || tie) { myT = t; myId = id; }
+            }
           }
+#ifdef RT_TRACE_STATS
+          ++stLeaf;
+#endif
           popOrFinish();
         }
       }
@@ -348,7 +337,7 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
     //    behind that iteration's ballots, work sharing and LDS traffic; asking for the line now turns that fetch's L2 round trip
     //    (500-900 cycles under load) into an L1 hit.  One 4-byte load per lane, its value unused.
     if (job) {
-      const float* line = cur >= 0 ? reinterpret_cast<const float*>(nodes + (size_t)cur * 8) : reinterpret_cast<const float*>(tris + (size_t)((uint32_t)~cur & 0x0FFFFFFFu) * 4);
+      const float* line = cur >= 0 ? reinterpret_cast<const float*>(nodes + (size_t)cur * 8) : reinterpret_cast<const float*>(tris + (size_t)(uint32_t)~cur * 4);
       pf = __builtin_nontemporal_load(line);
     }
 #endif
@@ -454,8 +443,6 @@ static void steerTraceWaves(rtggx_context* c, const unsigned long long* stamps, 
   if (!usable) { c->traceTrial = 0u; return; }
   const float period = (float)dStart / (float)launches;
   c->traceShare = (float)dSum / (float)dStart;
-  // the tone map beside the next frame's filters (capi.hip rtggx_tone_map) pays while the main stream is the longest stage, not the traversal
-  if (c->traceShare > 0.92f) c->toneAsideAllowed = false; else if (c->traceShare < 0.85f) c->toneAsideAllowed = true;
   static const bool log = getenv("RTGGX_TRACE_LOG") != nullptr;
   if (log) fprintf(stderr, "[rtggx] trace sample at launch %u: %u launches, period %.1f us, share %.3f, waves %u, trial %u (base %.1f us), cooldown %u\n", launch, launches, period * 0.01f, c->traceShare, c->traceWaves, c->traceTrial, c->traceTrialBase * 0.01f, c->traceCooldown);
   if (c->traceWavesForced || c->lastTraceSmall) { c->traceTrial = 0u; return; }      // (two launches in flight: their stamps overlap)
@@ -478,9 +465,8 @@ uint32_t chooseSliceShift(rtggx_context* c, bool countRays, uint32_t numBins) {
     c->lastFrameRays = sum; c->splitDemand = c->hostRayCounters[256]; c->rayCountersInFlight = false;
     steerTraceWaves(c, reinterpret_cast<const unsigned long long*>(c->hostRayCounters + 258), c->traceSampleLaunch);
   }
-  static const int forcedShift = getenv("RTGGX_SLICE_SHIFT") ? atoi(getenv("RTGGX_SLICE_SHIFT")) : -1;
   const uint32_t raysGuess = countRays ? c->lastFrameRays : numBins * 40u;
-  return forcedShift >= 0 ? (uint32_t)forcedShift : (raysGuess < 25000u ? 3u : raysGuess < 60000u ? 2u : raysGuess < 110000u ? 1u : 0u);
+  return raysGuess < 25000u ? 3u : raysGuess < 60000u ? 2u : raysGuess < 110000u ? 1u : 0u;
 }
 
 int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t numBins, bool countRays, uint32_t tilesX, uint32_t tilesY, uint32_t sliceShift, int splitCap,
@@ -497,12 +483,12 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.root0 = c->mesh[0].root; T.root1 = c->mesh[1].root; T.haveMesh0 = have0; T.haveMesh1 = have1;
   T.rays = (const RayRec*)c->rayQueue; T.hits = (HitKey*)c->hitQueue; T.tRange = (const float2*)c->traceRayRange;
   T.binCount = c->binCount; T.numBins = numBins; T.binSlots = c->binSlots;
-  // Stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get (a 4-wide node leaves at most 3
-  // entries behind, and there is one per two levels of the binary tree).  The spill area belongs to the launch's WAVES, not to the bins
+  // Stacks deeper than the LDS part spill to global memory; the built trees say how deep they can get (a 4-wide node leaves its other
+  // entries behind: the build adds them up along every path, BuildResult::stack4).  The spill area belongs to the launch's WAVES, not to the bins
   // (round 3; per bin it was 2 x 20 entries x 32 640 bins x 2 KB = 2.7 GB for the bunny at 1080p, 4.3 GB for the dragon, four times
   // that at 4K -- for an area the bunny and dragon frames touch a handful of times): at most RT_SPILL_WAVES waves per launch, which is
   // what caps the grid of the single-wave variant below.
-  const uint32_t deepest = 3u * ((c->mesh[0].depth > c->mesh[1].depth ? c->mesh[0].depth : c->mesh[1].depth) / 2u + 1u);
+  const uint32_t deepest = (c->mesh[0].stack4 > c->mesh[1].stack4 ? c->mesh[0].stack4 : c->mesh[1].stack4) + 1u;      // what the builds found (lbvh.hip roots4Kernel)
   if (deepest > RT_STACK + c->spillEntries) {
     RT_HIP(hipDeviceSynchronize());
     if (c->stackOverflow) { RT_HIP(hipFree(c->stackOverflow)); c->stackOverflow = nullptr; }
@@ -525,8 +511,6 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   T.totalItems = grid * 4u;      // one item per (bin, slice), in the order single-wave workgroups would have been dispatched in
   T.top0 = (const float4*)c->mesh[0].top; T.topCount0 = have0 && c->mesh[0].top ? c->mesh[0].topCount : 0u;
   T.top1 = (const float4*)c->mesh[1].top; T.topCount1 = have1 && c->mesh[1].top ? c->mesh[1].topCount : 0u;
-  static const bool noTop = getenv("RTGGX_TRACE_NO_TOP") && atoi(getenv("RTGGX_TRACE_NO_TOP")) != 0;      // measurement: every node from global memory
-  if (noTop) T.topCount0 = T.topCount1 = 0u;
   if (T.topCount0 > RT_TOP_SLOT0 || T.topCount1 > RT_TOP_SLOT1) { setError("launchTrace: tree tables of %u / %u nodes exceed the LDS slots", T.topCount0, T.topCount1); return -1; }
   // Which variant.  A launch of a frame gets ONE workgroup of traceWaves (12, see steerTraceWaves) waves per CU: see the kernel.
   // Below RT_WIDE_RAYS rays two such launches are in flight (capi.hip rtggx_ray_trace).  A launch with fewer than RT_TINY_RAYS rays
@@ -535,8 +519,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
   // 0.071; from 40 000 rays on the resident workgroups are as fast or faster -- a strip of the 1080p frame with 70 000-150 000 rays:
   // 0.076 / 0.087 ms for the slowest of 8 / 4 strips against 0.082 / 0.092; profiles/r02_j_resident_trace.txt section 5).
   static const int forced = getenv("RTGGX_TRACE_WAVES") ? atoi(getenv("RTGGX_TRACE_WAVES")) : 0;      // measurement: 1, 10, 12, 14, 16
-  static const uint32_t tinyRays = getenv("RTGGX_TINY_RAYS") ? (uint32_t)atoi(getenv("RTGGX_TINY_RAYS")) : RT_TINY_RAYS;
-  const uint32_t waves = forced ? (uint32_t)forced : (!countRays || c->lastFrameRays < tinyRays) ? 1u : c->traceWaves;
+  const uint32_t waves = forced ? (uint32_t)forced : (!countRays || c->lastFrameRays < RT_TINY_RAYS) ? 1u : c->traceWaves;
   const uint32_t perCu = waves == 1u ? RT_SPILL_WAVES / 256u : 1u;      // single-wave workgroups: one per item, the dispatcher deals them -- up to RT_SPILL_WAVES of them (three times the
                                                                          // wave slots the chip offers this kernel); beyond that they take a second item, a third, ... (the loop in the kernel)
   if (waves == 1u) T.topCount0 = T.topCount1 = 0u;
@@ -558,7 +541,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
     default: setError("launchTrace: no kernel variant with %u waves", waves); return -1;
   }
 #undef RT_LAUNCH_TRACE
-  static const uint32_t counterMask = getenv("RTGGX_COUNTER_PERIOD") ? (uint32_t)atoi(getenv("RTGGX_COUNTER_PERIOD")) - 1u : 15u;      // measurement: a power of two
+  const uint32_t counterMask = 15u;
   if (countRays && !c->rayCountersInFlight && (c->traceLaunches < 8u || (c->traceLaunches & counterMask) == 0u)) {     // the first frames, then every 16th: ray counters and split demand, for later launches
     RT_HIP(hipMemcpyAsync(c->hostRayCounters, c->rayCounter32, 256 * 4, hipMemcpyDeviceToHost, s));
     RT_HIP(hipMemcpyAsync(c->hostRayCounters + 256, c->splitCount, 4, hipMemcpyDeviceToHost, s));

@@ -83,9 +83,21 @@ __global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begi
 
 // Small triangles (bounding box <= RT_SMALL_BOX pixels), balanced over the lanes of a wave.  Phase 1: one lane per
 // triangle does the set-up (transform, snap, cull, box) and parks it in LDS.  Phase 2: the candidate pixels of the
-// wave's 64 triangles form one list (prefix sum of the box sizes); lane l takes candidates l, l + 64, ...: finds the
+// wave's triangles form one list (prefix sum of the box sizes); lane l takes candidates l, l + 64, ...: finds the
 // triangle by binary search in the prefix sums and the pixel inside the box with a multiply-shift division.  The
 // per-thread box loop this replaces ran as long as the largest box in the wave (42 us on the 1080p bunny frame).
+// Round 4: a wave takes RT_RASTER_TPW = 16 triangles, not 64 -- the kernel is a chain of dependent steps (indices -> vertices -> set-up ->
+// ~30 candidate pixels per triangle), 1 092 waves of it were four per CU with nothing to hide a round trip behind, and in the frame,
+// beside the other stages on a low-priority stream, its 21 us became 40-80 (profiles/r03_n_timeline.txt): four times the waves, a
+// quarter of the candidate rounds each.  And a fragment goes to the target with ONE fire-and-forget atomicMin; rounds 1-3 read the
+// pixel first and skipped the atomic where the fragment was hidden, which saved a third of the atomics and put a load's round trip
+// into every round of the loop.
+#ifndef RT_RASTER_TPW
+#define RT_RASTER_TPW 16
+#endif
+#ifndef RT_RASTER_PREREAD
+#define RT_RASTER_PREREAD 0
+#endif
 #define RT_SMALL_BOX 1024
 struct __attribute__((aligned(16))) TriSetup {
   int32_t X[3], Y[3]; float z[3]; uint32_t word;
@@ -98,18 +110,19 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
                                                    const float* __restrict__ v1, const uint32_t* __restrict__ i1, uint32_t nt1,
                                                    unsigned long long* __restrict__ vd, LargeTri* __restrict__ large,
                                                    uint32_t* __restrict__ largeCount, uint32_t largeCap) {
-  __shared__ TriSetup setupMem[256];
-  __shared__ uint32_t prefixMem[256];
+  constexpr uint32_t TPW = RT_RASTER_TPW;      // triangles per wave: a power of two, 1 .. 64
+  __shared__ TriSetup setupMem[4 * TPW];
+  __shared__ uint32_t prefixMem[4 * TPW];
   if (blockIdx.x == 0 && dst) {
     const uint32_t* s = reinterpret_cast<const uint32_t*>(&fp);
     uint32_t* d = reinterpret_cast<uint32_t*>(dst);
     for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4; i += blockDim.x) d[i] = s[i];
   }
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  TriSetup* const setup = setupMem + wave * 64; uint32_t* const prefix = prefixMem + wave * 64;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  TriSetup* const setup = setupMem + wave * TPW; uint32_t* const prefix = prefixMem + wave * TPW;
+  const uint32_t t = (blockIdx.x * 4u + wave) * TPW + lane;
   uint32_t cnt = 0;
-  if (t < nt0 + nt1) {
+  if (lane < TPW && t < nt0 + nt1) {
     const uint32_t inst = t < nt0 ? 0u : 1u;
     const uint32_t prim = inst ? t - nt0 : t;
     const float* verts = inst ? v1 : v0;
@@ -183,12 +196,12 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
   // exclusive prefix sum of the candidate counts over the wave
   uint32_t inc = cnt;
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if ((int)lane >= o) inc += v; }
-  prefix[lane] = inc - cnt;
+  if (lane < TPW) prefix[lane] = inc - cnt;
   const uint32_t total = (uint32_t)__shfl((int)inc, 63);
   for (uint32_t w = lane; w < total; w += 64u) {
     uint32_t lo = 0;                       // last triangle whose candidates start at or before w (its count is > 0)
 #pragma unroll
-    for (uint32_t step = 32u; step > 0u; step >>= 1) if (prefix[lo + step] <= w) lo += step;
+    for (uint32_t step = TPW / 2u; step > 0u; step >>= 1) if (prefix[lo + step] <= w) lo += step;
     const TriSetup& S = setup[lo];
     const uint32_t q = w - prefix[lo], bw = S.bwTl & 0xFFFFu;
     const uint32_t ry = (q * S.magic) >> 24, rx = q - ry * bw;       // q / bw exactly: q < 1024, bw <= 1024
@@ -199,7 +212,11 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
                                                S.invA, z0, dz1, dz2, S.word);
     if (key == ~0ull) continue;
     unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
+#if RT_RASTER_PREREAD
     if (key < *dst) atomicMin(dst, key);
+#else
+    atomicMin(dst, key);      // (no result used: the compiler emits the no-return form, nothing waits for it)
+#endif
   }
 }
 
@@ -264,7 +281,7 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   FrameParams* const dst = c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot;
   c->slotUploaded = true;
   // (with no triangles at all the kernel still runs, for the constants)
-  const dim3 grid(nt ? (nt + 255) / 256 : 1u);
+  const dim3 grid(nt ? (nt + 4u * RT_RASTER_TPW - 1u) / (4u * RT_RASTER_TPW) : 1u);
   hipLaunchKernelGGL(rasterSmall, grid, dim3(256), 0, s, fp, dst, rb, re, (const float*)c->mesh[0].verts, (const uint32_t*)c->mesh[0].indices, c->mesh[0].numTris,
                      (const float*)c->mesh[1].verts, (const uint32_t*)c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
   if (nt) {

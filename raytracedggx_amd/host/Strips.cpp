@@ -43,20 +43,28 @@ std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int wor
   return bounds;
 }
 
-std::vector<Op> ExchangePlan(uint32_t height, int rank, int world, uint32_t apron, const std::vector<uint32_t>* bounds) {
+std::vector<Op> ExchangePlan(uint32_t height, int rank, int world, uint32_t apron, const std::vector<uint32_t>* bounds, bool tokens) {
   const auto [b, e] = StripRows(height, rank, world, bounds);
   std::vector<Op> ops;
   if (rank > 0) {                      // the upper neighbour owns [.., b)
-    ops.push_back({true, true, b, std::min(b + apron, e), rank - 1});
-    ops.push_back({false, true, b > apron ? b - apron : 0u, b, rank - 1});
+    ops.push_back({true, Buffer::History, b, std::min(b + apron, e), rank - 1});
+    ops.push_back({false, Buffer::History, b > apron ? b - apron : 0u, b, rank - 1});
   }
   if (rank < world - 1) {              // the lower neighbour owns [e, ..)
-    ops.push_back({true, true, std::max(e > apron ? e - apron : 0u, b), e, rank + 1});
-    ops.push_back({false, true, e, std::min(e + apron, height), rank + 1});
+    ops.push_back({true, Buffer::History, std::max(e > apron ? e - apron : 0u, b), e, rank + 1});
+    ops.push_back({false, Buffer::History, e, std::min(e + apron, height), rank + 1});
   }
   if (rank == 0) {                     // frame assembly on rank 0
-    for (int r = 1; r < world; ++r) { const auto [rb, re] = StripRows(height, r, world, bounds); ops.push_back({false, false, rb, re, r}); }
-  } else ops.push_back({true, false, b, e, 0});
+    for (int r = 1; r < world; ++r) { const auto [rb, re] = StripRows(height, r, world, bounds); ops.push_back({false, Buffer::BackBuffer, rb, re, r}); }
+  } else ops.push_back({true, Buffer::BackBuffer, b, e, 0});
+  if (tokens) {
+    if (world > RTGGX_MAX_PEERS) throw std::runtime_error("at most " + std::to_string(RTGGX_MAX_PEERS) + " ranks can map each other's history images");
+    for (int p = 0; p < world; ++p) {
+      if (std::abs(p - rank) < 2) continue;      // myself, or a neighbour: the history rows go both ways
+      if (p != 0) ops.push_back({true, Buffer::Token, (uint32_t)rank, (uint32_t)rank + 1u, p});                                    // (to rank 0 goes my back-buffer strip)
+      if (rank != 0) ops.push_back({false, Buffer::Token, (uint32_t)(RTGGX_MAX_PEERS + p), (uint32_t)(RTGGX_MAX_PEERS + p) + 1u, p});      // (rank 0 receives p's strip)
+    }
+  }
   return ops;
 }
 
@@ -88,31 +96,35 @@ Rccl::~Rccl() {
 static void check(void* const* fn, int rc, const char* what) {
   if (rc != 0) throw std::runtime_error(std::string(what) + " failed: " + reinterpret_cast<FnErrorString>(fn[kErrorString])(rc));
 }
+// Small files that carry a few bytes from one rank to the others (the ncclUniqueId, the hipIpc handles of the history images): written
+// beside and renamed -- a reader never sees half a file --, awaited by polling.
+static void writeFileAtomically(const std::string& path, const void* data, size_t bytes) {
+  const std::string tmp = path + ".tmp";
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f || std::fwrite(data, bytes, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+  std::fclose(f);
+  if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+}
+static void waitForFile(const std::string& path, void* data, size_t bytes, int rank) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == bytes) {
+      FILE* f = std::fopen(path.c_str(), "rb");
+      if (f && std::fread(data, bytes, 1, f) == 1) { std::fclose(f); return; }
+      if (f) std::fclose(f);
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) throw std::runtime_error("rank " + std::to_string(rank) + ": no " + path + " after 120 s");
+    std::this_thread::sleep_for(std::chrono::milliseconds(10));
+  }
+}
 void Rccl::InitRank(int rank, int world, const std::string& idFile) {
   UniqueId id;
   std::memset(&id, 0, sizeof id);
   if (rank == 0) {
     check(m_fn, reinterpret_cast<FnGetUniqueId>(m_fn[kGetUniqueId])(&id), "ncclGetUniqueId");
-    if (world > 1) {      // hand it to the other ranks: write beside, then rename (a reader never sees half a file)
-      const std::string tmp = idFile + ".tmp";
-      FILE* f = std::fopen(tmp.c_str(), "wb");
-      if (!f || std::fwrite(&id, sizeof id, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
-      std::fclose(f);
-      if (std::rename(tmp.c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
-    }
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      struct stat st;
-      if (stat(idFile.c_str(), &st) == 0 && (size_t)st.st_size == sizeof id) {
-        FILE* f = std::fopen(idFile.c_str(), "rb");
-        if (f && std::fread(&id, sizeof id, 1, f) == 1) { std::fclose(f); break; }
-        if (f) std::fclose(f);
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) throw std::runtime_error("rank " + std::to_string(rank) + ": no ncclUniqueId in " + idFile + " after 120 s");
-      std::this_thread::sleep_for(std::chrono::milliseconds(10));
-    }
-  }
+    if (world > 1) writeFileAtomically(idFile, &id, sizeof id);      // hand it to the other ranks
+  } else waitForFile(idFile, &id, sizeof id, rank);
   check(m_fn, reinterpret_cast<FnCommInitRank>(m_fn[kCommInitRank])(&m_comm, world, id, rank), "ncclCommInitRank");
 }
 void Rccl::Exchange(const std::vector<RawOp>& ops, void* stream) {
@@ -132,8 +144,9 @@ static RawOp rawOp(const Op& o, RayTracedGGX& app, bool send, int peer) {
   rtggx_context* ctx = app.GetContext();
   uint32_t parity = 0; abi(rtggx_frame_parity(ctx, &parity), "rtggx_frame_parity");
   void* base = nullptr;
-  abi(rtggx_buffer_ptr(ctx, o.history ? (parity ? RTGGX_BUF_TSS1 : RTGGX_BUF_TSS0) : RTGGX_BUF_BACKBUFFER, &base), "rtggx_buffer_ptr");
-  const size_t rowBytes = (size_t)app.GetWidth() * (o.history ? 8u : 4u);
+  const int id = o.buffer == Buffer::History ? (parity ? RTGGX_BUF_TSS1 : RTGGX_BUF_TSS0) : o.buffer == Buffer::BackBuffer ? RTGGX_BUF_BACKBUFFER : RTGGX_BUF_EXCHANGE_TOKENS;
+  abi(rtggx_buffer_ptr(ctx, id, &base), "rtggx_buffer_ptr");
+  const size_t rowBytes = o.buffer == Buffer::Token ? 4u : (size_t)app.GetWidth() * (o.buffer == Buffer::History ? 8u : 4u);
   return {send, static_cast<char*>(base) + (size_t)o.rowBegin * rowBytes, (size_t)(o.rowEnd - o.rowBegin) * rowBytes, peer};
 }
 std::vector<RawOp> PlanToRaw(const std::vector<Op>& plan, RayTracedGGX& app) {
@@ -278,12 +291,24 @@ int RunRank(RayTracedGGX& app, int rank, int world, const std::string& idFile, b
   const auto rows = takeStrip(app, rank, world, bounds, HistoryApron);
   Rccl rccl;
   rccl.InitRank(rank, world, idFile);
-  // the exchange on the main stream, behind the frame -- or, RTGGX_EXCHANGE_BESIDE=1, on the context's exchange stream: beside the next frame's
-  // shading and filters, only its temporal pass waits (rtggx.h; off by default: slower in the one-GPU emulation, profiles/r03_h_strip_projection.txt)
-  const char* be = std::getenv("RTGGX_EXCHANGE_BESIDE");
-  const bool beside = be && std::atoi(be) == 1;
+  // every rank's history images mapped into this one: handles through files beside the ncclUniqueId's
+  {
+    unsigned char mine[2 * RTGGX_IPC_HANDLE_BYTES];
+    abi(rtggx_history_ipc_export(ctx, mine, sizeof mine), "rtggx_history_ipc_export");
+    writeFileAtomically(idFile + ".hist." + std::to_string(rank), mine, sizeof mine);
+    std::vector<void*> t0(world, nullptr), t1(world, nullptr);
+    for (int r = 0; r < world; ++r) {
+      if (r == rank) continue;
+      unsigned char theirs[2 * RTGGX_IPC_HANDLE_BYTES];
+      waitForFile(idFile + ".hist." + std::to_string(r), theirs, sizeof theirs, rank);
+      abi(rtggx_history_ipc_open(ctx, theirs, sizeof theirs, &t0[r], &t1[r]), "rtggx_history_ipc_open");
+    }
+    std::vector<uint32_t> all(world + 1);
+    for (int r = 0; r <= world; ++r) all[r] = r < world ? StripRows(app.GetHeight(), r, world, &bounds).first : app.GetHeight();
+    abi(rtggx_set_history_peers(ctx, (uint32_t)world, all.data(), t0.data(), t1.data()), "rtggx_set_history_peers");
+  }
   void* stream = nullptr;
-  if (beside) abi(rtggx_get_exchange_stream(ctx, &stream), "rtggx_get_exchange_stream"); else abi(rtggx_get_stream(ctx, &stream), "rtggx_get_stream");
+  abi(rtggx_get_stream(ctx, &stream), "rtggx_get_stream");      // the exchange on the main stream, behind the frame
   const std::vector<Op> plan = ExchangePlan(app.GetHeight(), rank, world, HistoryApron, &bounds);
   std::vector<RawOp> raw[2]; bool have[2] = {false, false};      // the pointers depend on the history target only: built once per parity
   const auto t0 = std::chrono::steady_clock::now();
@@ -291,9 +316,7 @@ int RunRank(RayTracedGGX& app, int rank, int world, const std::string& idFile, b
     app.OnUpdate(); app.OnRender();
     uint32_t parity = 0; abi(rtggx_frame_parity(ctx, &parity), "rtggx_frame_parity");
     if (!have[parity]) { raw[parity] = PlanToRaw(plan, app); have[parity] = true; }
-    if (beside) abi(rtggx_exchange_begin(ctx), "rtggx_exchange_begin");
     rccl.Exchange(raw[parity], stream);
-    if (beside) abi(rtggx_exchange_end(ctx), "rtggx_exchange_end");
   }
   uint64_t rays = 0; abi(rtggx_ray_count(ctx, &rays), "rtggx_ray_count");      // synchronises
   abi(rtggx_sync(ctx), "rtggx_sync");
@@ -301,7 +324,8 @@ int RunRank(RayTracedGGX& app, int rank, int world, const std::string& idFile, b
   uint32_t over = 0; abi(rtggx_history_overreach(ctx, &over, 1), "rtggx_history_overreach");
   std::printf("rank %d of %d: rows [%u, %u), %u frames %ux%u: %.3f ms/frame, last frame %llu rays in its rows%s\n", rank, world, rows.first, rows.second, app.GetNumFrames(),
               app.GetWidth(), app.GetHeight(), ms / app.GetNumFrames(), (unsigned long long)rays,
-              over ? (", history read " + std::to_string(over) + " rows beyond the exchanged apron: the strips differ from the single-GPU frame").c_str() : "");
+              over ? (", history taps up to " + std::to_string(over) + " rows beyond the exchanged apron read the owner's image").c_str() : "");
+  std::remove((idFile + ".hist." + std::to_string(rank)).c_str());
   if (rank == 0) dumpIfAsked(app);      // rank 0 holds the assembled frame
   app.OnDestroy();
   return 0;
@@ -320,6 +344,13 @@ int RunStripsInOneProcess(RayTracedGGX& first, int world, bool balance, int argc
   if (balance) for (RayTracedGGX* a : apps) bounds = ProfileBounds(*a, world);      // every strip renders the profile frames as whole frames, like every rank would
   std::vector<std::vector<Op>> plans;
   for (int r = 0; r < world; ++r) { takeStrip(*apps[r], r, world, bounds, HistoryApron); plans.push_back(ExchangePlan(first.GetHeight(), r, world, HistoryApron, &bounds)); }
+  {      // every strip reads every strip's history images: plain pointers in one process
+    std::vector<void*> t0(world), t1(world);
+    for (int r = 0; r < world; ++r) { abi(rtggx_buffer_ptr(apps[r]->GetContext(), RTGGX_BUF_TSS0, &t0[r]), "rtggx_buffer_ptr"); abi(rtggx_buffer_ptr(apps[r]->GetContext(), RTGGX_BUF_TSS1, &t1[r]), "rtggx_buffer_ptr"); }
+    std::vector<uint32_t> all(world + 1);
+    for (int r = 0; r <= world; ++r) all[r] = r < world ? StripRows(first.GetHeight(), r, world, &bounds).first : first.GetHeight();
+    for (int r = 0; r < world; ++r) abi(rtggx_set_history_peers(apps[r]->GetContext(), (uint32_t)world, all.data(), t0.data(), t1.data()), "rtggx_set_history_peers");
+  }
   Rccl rccl;
   rccl.InitRank(0, 1, "");
   const auto syncAll = [&]() { for (RayTracedGGX* a : apps) abi(rtggx_sync(a->GetContext()), "rtggx_sync"); };

@@ -5,6 +5,8 @@
 // each side of a strip boundary go to the neighbour -- plus the gather of the tone-mapped strips on rank 0 (the reference presents
 // one back buffer, RayTracedGGX.cpp:341-353).  Point-to-point ncclSend / ncclRecv in one group per frame on the context's main
 // stream (rtggx_get_stream): ordered behind the frame's tone map, needed by the next frame's temporal pass only.  No collective.
+// Every rank also maps every other rank's two history images (hipIpc through files beside the ncclUniqueId; plain pointers in the
+// single-process mode): a history tap beyond the exchanged apron reads the owner's image, so N strips equal the single-GPU frame at any velocity.
 // This is the C++ twin of raytracedggx_amd/strips.py (what bench.py drives); the plan functions give the same answers
 // (tests/test_gpu_parity.py runs the executable's single-process mode against the single-context frame).
 #pragma once
@@ -27,10 +29,15 @@ std::pair<uint32_t, uint32_t> StripRows(uint32_t height, int rank, int world, co
 // Boundaries that even out sum(rowCost) per strip; every strip at least minRows rows.  Deterministic: every rank computes the same.
 std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int world, uint32_t minRows = HistoryApron);
 
-struct Op { bool send; bool history; uint32_t rowBegin, rowEnd; int peer; };      // history: TemporalSSOut[parity] (8 B/px); else the back buffer (4 B/px)
+enum class Buffer { History /* TemporalSSOut[parity], 8 B/px */, BackBuffer /* 4 B/px */, Token /* words of RTGGX_BUF_EXCHANGE_TOKENS */ };
+struct Op { bool send; Buffer buffer; uint32_t rowBegin, rowEnd; int peer; };      // rows of the frame; for a token: words of the token buffer
 // The transfers of one frame for `rank`.  Ops between a pair of ranks appear in the same order on both sides (history first,
-// then the back-buffer strip): that is what tag-less send / recv matching needs.
-std::vector<Op> ExchangePlan(uint32_t height, int rank, int world, uint32_t apron = HistoryApron, const std::vector<uint32_t>* bounds = nullptr);
+// then the back-buffer strip, then the token): that is what tag-less send / recv matching needs.
+// tokens (round 4): every rank maps every rank's history images (rtggx_set_history_peers: a history tap beyond the apron reads the
+// owner's image), which needs an order between ANY two ranks, in both directions, every frame; a message each way in this exchange gives
+// it.  Neighbours have their history rows, everybody has a back-buffer strip for rank 0; the pairs and directions that have nothing get
+// a 4-byte token (word [rank] of the token buffer to send from, [RTGGX_MAX_PEERS + peer] to receive into).
+std::vector<Op> ExchangePlan(uint32_t height, int rank, int world, uint32_t apron = HistoryApron, const std::vector<uint32_t>* bounds = nullptr, bool tokens = true);
 
 struct RawOp { bool send; void* ptr; size_t bytes; int peer; };
 // librccl.so, loaded at run time (the single-GPU executable does not need it).

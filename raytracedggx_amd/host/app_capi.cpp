@@ -92,14 +92,14 @@ extern "C" void rtggx_host_frame_constants(uint32_t width, uint32_t height, cons
 }
 
 // The multi-GPU host's plan functions (host/Strips.cpp), for the tests that compare them with raytracedggx_amd/strips.py.
-// bounds: nullptr / 0 for equal strips, else world + 1 row numbers.  ops: 5 int32 per transfer (send, history, rowBegin, rowEnd, peer);
+// bounds: nullptr / 0 for equal strips, else world + 1 row numbers.  ops: 5 int32 per transfer (send, buffer: 1 history / 0 back buffer / 2 token, rowBegin, rowEnd, peer);
 // returns the number of transfers, or -1 with rtggx_app_last_error set.
 extern "C" int rtggx_host_exchange_plan(uint32_t height, int rank, int world, uint32_t apron, const uint32_t* bounds, int32_t* ops, int capacity) {
   try {
     const std::vector<uint32_t> b(bounds, bounds + (bounds ? world + 1 : 0));
     const std::vector<strips::Op> plan = strips::ExchangePlan(height, rank, world, apron, &b);
     if ((int)plan.size() > capacity) { g_appError = "rtggx_host_exchange_plan: capacity"; return -1; }
-    for (size_t i = 0; i < plan.size(); ++i) { int32_t* o = ops + 5 * i; o[0] = plan[i].send; o[1] = plan[i].history; o[2] = (int32_t)plan[i].rowBegin; o[3] = (int32_t)plan[i].rowEnd; o[4] = plan[i].peer; }
+    for (size_t i = 0; i < plan.size(); ++i) { int32_t* o = ops + 5 * i; o[0] = plan[i].send; o[1] = plan[i].buffer == strips::Buffer::History ? 1 : plan[i].buffer == strips::Buffer::BackBuffer ? 0 : 2; o[2] = (int32_t)plan[i].rowBegin; o[3] = (int32_t)plan[i].rowEnd; o[4] = plan[i].peer; }
     return (int)plan.size();
   } catch (const std::exception& e) { g_appError = e.what(); return -1; }
 }

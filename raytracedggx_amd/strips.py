@@ -58,11 +58,17 @@ def balanced_bounds(row_cost, world, min_rows=HISTORY_APRON):
     return bounds
 
 
-def exchange_plan(height, rank, world, apron=HISTORY_APRON, bounds=None):
+def exchange_plan(height, rank, world, apron=HISTORY_APRON, bounds=None, tokens=True):
     """The point-to-point transfers of one frame for `rank`: a list of (op, buffer, row_begin, row_end, peer) with op in
-    {"send", "recv"} and buffer in {"history", "backbuffer"}.  Rows are frame rows: every rank allocates full-size
+    {"send", "recv"} and buffer in {"history", "backbuffer", "token"}.  Rows are frame rows: every rank allocates full-size
     targets, so a transfer reads and writes the same rows on both sides.  Ops between a pair of ranks appear in the same
-    order on both (history first, then the back-buffer strip), which is what tag-less send/recv matching needs."""
+    order on both (history first, then the back-buffer strip, then the token), which is what tag-less send/recv matching needs.
+    tokens (round 4): with every rank's history image mapped into every rank (rtggx_set_history_peers) a history tap beyond the apron
+    reads the owner's image, and that needs an order between ANY two ranks, in both directions, every frame: the reader's temporal pass
+    behind the owner's previous one, the owner's next-but-one H filter (which reuses the image as scratch) behind the reader's.  A
+    message each way in this exchange gives exactly that (it is issued on the main streams between the two).  Neighbours have their
+    history rows, everybody has a back-buffer strip for rank 0; the pairs and directions that have nothing get a 4-byte token
+    ("token" rows are WORDS of the context's token buffer: [rank] to send from, [MAX_PEERS + peer] to receive into)."""
     b, e = strip_rows(height, rank, world, bounds)
     ops = []
     if rank > 0:                       # upper neighbour owns [.., b)
@@ -77,14 +83,24 @@ def exchange_plan(height, rank, world, apron=HISTORY_APRON, bounds=None):
             ops.append(("recv", "backbuffer", rb, re, r))
     else:
         ops.append(("send", "backbuffer", b, e, 0))
+    if tokens:
+        if world > capi.MAX_PEERS:
+            raise ValueError("at most %d ranks can map each other's history images" % capi.MAX_PEERS)
+        for p in range(world):
+            if abs(p - rank) < 2:
+                continue               # myself, or a neighbour: the history rows go both ways
+            if p != 0:                 # (to rank 0 goes my back-buffer strip)
+                ops.append(("send", "token", rank, rank + 1, p))
+            if rank != 0:              # (rank 0 receives p's strip)
+                ops.append(("recv", "token", capi.MAX_PEERS + p, capi.MAX_PEERS + p + 1, p))
     return ops
 
 
-def plan_to_raw(plan, history_ptr, backbuffer_ptr, width):
+def plan_to_raw(plan, history_ptr, backbuffer_ptr, width, token_ptr=0):
     """`plan` as the argument lists of ncclSend / ncclRecv: (is_send, device pointer, bytes, peer).  Rows [r0, r1) of
     TemporalSSOut[parity] (8 B/px) or of the back buffer (4 B/px); every rank holds full-size targets, so both sides
-    address the same rows."""
-    base = {"history": (history_ptr, 8 * width), "backbuffer": (backbuffer_ptr, 4 * width)}
+    address the same rows.  Tokens: words [r0, r1) of the context's token buffer."""
+    base = {"history": (history_ptr, 8 * width), "backbuffer": (backbuffer_ptr, 4 * width), "token": (token_ptr, 4)}
     return [(op == "send", base[name][0] + r0 * base[name][1], (r1 - r0) * base[name][1], peer) for op, name, r0, r1, peer in plan]
 
 
@@ -108,7 +124,7 @@ class StripRenderer:
     SKY_ROW_WEIGHT = float(os.environ.get("RTGGX_SKY_ROW_WEIGHT", 0.5))
 
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
-                 transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON, overlap_exchange=None):
+                 transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON, peers=True):
         """dist: torch.distributed (one process per GPU).  transport: instead of dist, a callable
         transport(renderer, plan) that carries out the plan some other way (tests drive several strips from one process).
         torch_buffers: wrap the exchanged targets as torch tensors and render on torch's current stream (default: only
@@ -116,16 +132,16 @@ class StripRenderer:
         balance: False = equal strips; a list of world + 1 row numbers = these boundaries; True = every rank first renders
         PROFILE_FRAMES full frames and cuts the frame where the covered pixels (= rays, the expensive rows) balance --
         rendering is deterministic, so all ranks arrive at the same boundaries without talking to each other.
-        overlap_exchange: issue the exchange on the context's exchange stream (rtggx_get_exchange_stream), beside the next frame's shading
-        and spatial filters, instead of on the main stream in front of them (a transport that wants it issues its transfers on
-        renderer.xstream).  Default: off, or RTGGX_EXCHANGE_BESIDE=1 -- on the one GPU available to the builder the RCCL group of a one-rank
-        communicator takes 0.27 ms per frame there against 0.03 on the main stream (its send and receive workgroups wait for each other
-        while the frame's kernels hold the CUs; profiles/r03_h_strip_projection.txt): whether it pays across real links is the driver's to see.
+        peers: map every rank's history images into every rank (rtggx_set_history_peers) so that a history tap beyond the exchanged apron
+        reads the owner's image -- N strips then equal the single-GPU frame at any velocity -- and add the ordering tokens to the exchange
+        (exchange_plan).  With dist the handles travel through an all_gather (hipIpc); several strips in ONE process (a transport) are
+        connected by connect_peers(all_of_them) once they exist.
         apron: history rows exchanged beyond each strip edge (HISTORY_APRON = 18 covers 16 px of vertical reprojection per
         frame).  A faster motion -- an orbit drag of a -track script -- makes the strips differ from the single-GPU frame:
         the temporal pass detects that (history_overreach() > 0), and a wider apron, the same on every rank, is the remedy."""
         self.W, self.H, self.rank, self.world, self.dist, self.transport = width, height, rank, world, dist, transport
         self.apron = int(apron)
+        self.peers = bool(peers) and world > 1
         args = ["-mesh", mesh_path] + ([str(x) for x in pos_scale] if pos_scale else []) + \
                ["-env", env_path, "-width", width, "-height", height, "-device", device] + list(extra_args)
         self.app = app.RayTracedGGX(args)
@@ -150,8 +166,7 @@ class StripRenderer:
                 # torch stream against 0.076 on the library's own; profiles/r03_h_strip_projection.txt).  Asking for the stream also tells
                 # the library that the caller orders work of its own behind the frame (the tone map stays on this stream).
                 self.stream = torch.cuda.ExternalStream(self.context.stream(), device=device)
-                self.overlap = bool(overlap_exchange) if overlap_exchange is not None else os.environ.get("RTGGX_EXCHANGE_BESIDE", "0") == "1"
-                self.xstream = torch.cuda.ExternalStream(self.context.exchange_stream(), device=device) if self.overlap else self.stream
+                self.xstream = self.stream      # (rounds 2-3 had an exchange stream of its own here: measured slower, removed in round 4)
                 self._tss = [self._wrap(capi.BUF_TSS0, "<u8"), self._wrap(capi.BUF_TSS1, "<u8")]
                 self._backbuffer = self._wrap(capi.BUF_BACKBUFFER, "<u4")
         self._last = None
@@ -166,6 +181,39 @@ class StripRenderer:
                     import sys
                     print("strips: %s -- using torch.distributed's P2P batch instead" % e, file=sys.stderr, flush=True)
                 self._comm = None
+        if self.peers and dist is not None and transport is None:
+            self._connect_peers_over(dist)
+
+    def plan(self):
+        return exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds, tokens=self.peers)
+
+    def all_bounds(self):
+        return self.bounds if self.bounds is not None else [strip_rows(self.H, r, self.world)[0] for r in range(self.world)] + [self.H]
+
+    def connect_peers(self, renderers):
+        """Several strips in one process: every strip gets the history images of all of them as plain device pointers."""
+        if not self.peers:
+            return
+        self.context.set_history_peers(self.all_bounds(), [r.context.buffer_ptr(capi.BUF_TSS0) for r in renderers], [r.context.buffer_ptr(capi.BUF_TSS1) for r in renderers])
+
+    def _connect_peers_over(self, dist):
+        """One process per GPU: the handles of every rank's two history images, all-gathered, opened here (hipIpcOpenMemHandle)."""
+        import torch
+        mine = torch.frombuffer(bytearray(self.context.history_ipc_export()), dtype=torch.uint8)
+        on_gpu = dist.get_backend() != "gloo"
+        if on_gpu:
+            mine = mine.cuda()
+        every = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine)
+        p0, p1 = [], []
+        for r in range(self.world):
+            if r == self.rank:
+                p0.append(0); p1.append(0)
+            else:
+                a, b = self.context.history_ipc_open(every[r].cpu().numpy().tobytes())
+                p0.append(a); p1.append(b)
+        self.context.set_history_peers(self.all_bounds(), p0, p1)
+        dist.barrier()      # nobody renders into an image another rank has not finished mapping
 
     def _wrap(self, bid, typestr):
         t = self.torch.as_tensor(_DeviceArray(self.context.buffer_ptr(bid), (self.H, self.W), typestr), device="cuda")
@@ -191,36 +239,31 @@ class StripRenderer:
     def exchange(self):
         if self.world == 1:
             return
-        overlap = getattr(self, "overlap", False)
-        if overlap:
-            self.context.exchange_begin()      # the exchange stream behind this frame's last kernel
-        try:
-            self._exchange_on(self.xstream if overlap else getattr(self, "stream", None))
-        finally:
-            if overlap:
-                self.context.exchange_end()    # the next frame's temporal pass waits for what has been issued
-    def _exchange_on(self, stream):
+        stream = getattr(self, "stream", None)
         if self.transport is not None:
-            self.transport(self, exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds))
+            self.transport(self, self.plan())
             return
         parity = self.context.frame_parity()
         if self._comm is not None:
             if self._ops[parity] is None:      # (is_send, pointer, bytes, peer), built once per history target
-                self._ops[parity] = self.raw_ops(exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds), parity)
+                self._ops[parity] = self.raw_ops(self.plan(), parity)
             self._comm.exchange(self._ops[parity], stream.cuda_stream)
             return
         if self._ops[parity] is None:          # built once per history target: the per-frame host cost is the batch call alone
-            self._ops[parity] = make_ops(self.dist, exchange_plan(self.H, self.rank, self.world, apron=self.apron, bounds=self.bounds), self.exchange_buffers())
+            self._ops[parity] = make_ops(self.dist, self.plan(), self.exchange_buffers())
         with self.torch.cuda.stream(stream):
             run_exchange(self.dist, None, None, ops=self._ops[parity])
 
     def raw_ops(self, plan, parity):
         """`plan` for rccl.Communicator.exchange, over this renderer's TemporalSSOut[parity] and back buffer."""
-        return plan_to_raw(plan, self.context.buffer_ptr(capi.BUF_TSS1 if parity else capi.BUF_TSS0), self.context.buffer_ptr(capi.BUF_BACKBUFFER), self.W)
+        return plan_to_raw(plan, self.context.buffer_ptr(capi.BUF_TSS1 if parity else capi.BUF_TSS0), self.context.buffer_ptr(capi.BUF_BACKBUFFER), self.W,
+                           self.context.buffer_ptr(capi.BUF_EXCHANGE_TOKENS))
 
     def exchange_buffers(self):
         """The torch views of the two exchanged targets (this frame's temporal result, the back buffer)."""
-        return {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer}
+        if not hasattr(self, "_tokens"):
+            self._tokens = self.torch.as_tensor(_DeviceArray(self.context.buffer_ptr(capi.BUF_EXCHANGE_TOKENS), (2 * capi.MAX_PEERS,), "<u4"), device="cuda").view(self.torch.int32)
+        return {"history": self._tss[self.context.frame_parity()], "backbuffer": self._backbuffer, "token": self._tokens}
 
     def history_overreach(self, reset=True):
         """Rows by which this rank's temporal pass read history beyond the exchanged apron since the last reset (synchronises).

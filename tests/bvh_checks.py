@@ -54,14 +54,16 @@ def bvh_check(nodes_u32, tris_u32, root, num_tris):
     return len(levels) + 1
 
 
-def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None):
+def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None, built_shape=True):
     """The 4-wide nodes the trace kernel walks (RTGGX_BUF_BVH4_NODES*: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4]) against
-    the binary tree: a 4-wide node is an even-depth binary node whose entries are its grandchildren (or its children where those are
-    leaves).  Since round 3 an entry may also be a MULTI-LEAF: a whole binary subtree of at most four triangles, referenced as
-    ~(first slot | (count - 1) << 28) -- possible because the leaf slots are in depth-first order of the tree, so that every subtree's
-    triangles are consecutive.  Checked: walking the 4-wide nodes from the root reaches every leaf slot exactly once; every entry's
-    box is, bit for bit, the binary tree's box of the subtree (or leaf) it stands for; slots nobody references stay zero.
-    Returns the number of 4-wide nodes in use."""
+    the binary tree.  Round 4: WHICH binary nodes are 4-wide nodes, and with which entries, is chosen by dynamic programming over the
+    binary tree so that the summed half-area of the 4-wide nodes -- the expected node steps of a random ray -- is least (lbvh.hip "the
+    4-wide collapse"):  F(leaf, i) = 0;  F(n, 1) = A(n) + min_k F(left, k) + F(right, 4 - k);  F(n, i) = min(F(n, 1), min_k F(left, k) +
+    F(right, i - k)) for i = 2, 3; ties go to the first candidate.  Checked: the choice itself, re-derived here in the same fp32 arithmetic
+    from the binary nodes' boxes for every 4-wide node (built_shape=False skips this for a REFITTED tree: it keeps the choice its build
+    made for another shape; every entry must then still be a descendant at most three levels down); walking the 4-wide nodes from the
+    root reaches every leaf slot exactly once; every entry's box is, bit for bit, the binary tree's box of the subtree (or leaf) it
+    stands for; slots nobody references stay zero; the level recorded in pad[0].  Returns the number of 4-wide nodes in use."""
     if root < 0:
         assert nodes4_u32.size == 0 or not nodes4_u32.any()
         return 0
@@ -70,67 +72,108 @@ def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None):
     child = nodes[:, 12:14].view(np.int32)
     n = len(nodes)
     u4, r4 = nodes4[:, :24], nodes4[:, 24:28].view(np.int32)
-    # per binary node: depth, parent side (where its box is stored), leaf range [first, first + count) of its subtree
-    depth = np.full(n, -1); parent = np.full(n, -1); side = np.zeros(n, np.int64)
-    levels, frontier, d = [], np.array([root], np.int64), 0
+    # per binary node: parent and side (where its box is stored), number of leaves below it
+    parent = np.full(n, -1); side = np.zeros(n, np.int64)
+    levels, frontier = [], np.array([root], np.int64)
     while frontier.size:
-        depth[frontier] = d; levels.append(frontier)
+        levels.append(frontier)
         for sd in (0, 1):
             c = child[frontier, sd]
             inner = c >= 0
             parent[c[inner]] = frontier[inner]; side[c[inner]] = sd
         c = child[frontier].reshape(-1)
-        frontier, d = c[c >= 0].astype(np.int64), d + 1
-    assert (depth >= 0).all()
-    first = np.zeros(n, np.int64); count = np.zeros(n, np.int64); contiguous = np.ones(n, bool)
+        frontier = c[c >= 0].astype(np.int64)
+    count = np.zeros(n, np.int64)
     for nodes_l in reversed(levels):
         c0, c1 = child[nodes_l, 0].astype(np.int64), child[nodes_l, 1].astype(np.int64)
-        f0 = np.where(c0 < 0, ~c0, first[np.where(c0 < 0, 0, c0)]); n0 = np.where(c0 < 0, 1, count[np.where(c0 < 0, 0, c0)])
-        f1 = np.where(c1 < 0, ~c1, first[np.where(c1 < 0, 0, c1)]); n1 = np.where(c1 < 0, 1, count[np.where(c1 < 0, 0, c1)])
-        ok0 = np.where(c0 < 0, True, contiguous[np.where(c0 < 0, 0, c0)]); ok1 = np.where(c1 < 0, True, contiguous[np.where(c1 < 0, 0, c1)])
-        first[nodes_l] = np.minimum(f0, f1); count[nodes_l] = n0 + n1
-        contiguous[nodes_l] = ok0 & ok1 & ((f0 + n0 == f1) | (f1 + n1 == f0))
-    # the box the binary tree stores for a node: in its parent's child fields (the root has none)
+        count[nodes_l] = np.where(c0 < 0, 1, count[np.where(c0 < 0, 0, c0)]) + np.where(c1 < 0, 1, count[np.where(c1 < 0, 0, c1)])
+    # the box the binary tree stores for a node: in its parent's child fields (the root has none); its half-area as the builder adds it up
     pr = np.where(parent >= 0, parent, 0)
-    nbox = np.where((side == 0)[:, None], f[pr, 0:6], f[pr, 6:12]).view(np.uint32)
+    nboxf = np.where((side == 0)[:, None], f[pr, 0:6], f[pr, 6:12]).astype(np.float32)
+    nbox = nboxf.view(np.uint32)
+    ex, ey, ez = nboxf[:, 3] - nboxf[:, 0], nboxf[:, 4] - nboxf[:, 1], nboxf[:, 5] - nboxf[:, 2]
+    area = ((ex * ey + ey * ez) + ez * ex).astype(np.float32)
     leaf_box = {}            # leaf slot -> box (from the parent's child fields)
     for sd, off in ((0, 0), (1, 6)):
         c = child[:, sd]
         for i in np.nonzero(c < 0)[0]:
             leaf_box[int(~c[i])] = nodes[i, off:off + 6]
-    by_range = {(int(first[i]), int(count[i])): i for i in range(n) if contiguous[i] and i != root}
     EMPTY = 0x7FFFFFFF
+
+    # the dynamic programme, level by level from the bottom (fp32, the builder's order of operations)
+    F = np.zeros((n, 3), np.float32); K1 = np.zeros(n, np.int64); D2 = np.zeros(n, np.int64); D3 = np.zeros(n, np.int64)
+    if built_shape:
+        zero = np.zeros(3, np.float32)
+        for nodes_l in reversed(levels):
+            c0, c1 = child[nodes_l, 0].astype(np.int64), child[nodes_l, 1].astype(np.int64)
+            f0 = np.where((c0 < 0)[:, None], zero, F[np.where(c0 < 0, 0, c0)]).astype(np.float32)
+            f1 = np.where((c1 < 0)[:, None], zero, F[np.where(c1 < 0, 0, c1)]).astype(np.float32)
+            best, k1 = f0[:, 0] + f1[:, 2], np.ones(len(nodes_l), np.int64)
+            for k, v in ((2, f0[:, 1] + f1[:, 1]), (3, f0[:, 2] + f1[:, 0])):
+                take = v < best
+                best, k1 = np.where(take, v, best), np.where(take, k, k1)
+            f1_ = (area[nodes_l] + best).astype(np.float32)
+            if nodes_l.size == 1 and nodes_l[0] == root:      # the root has no box in the binary tree's records: its area is the union of its children's
+                lo = np.minimum(f[root, 0:3], f[root, 6:9]); hi = np.maximum(f[root, 3:6], f[root, 9:12])
+                e_ = (hi - lo).astype(np.float32)
+                f1_ = (np.float32((e_[0] * e_[1] + e_[1] * e_[2]) + e_[2] * e_[0]) + best).astype(np.float32)
+            v = f0[:, 0] + f1[:, 0]
+            d2 = (v < f1_).astype(np.int64); f2_ = np.where(v < f1_, v, f1_)
+            f3_, d3 = f1_.copy(), np.zeros(len(nodes_l), np.int64)
+            for k, v in ((1, f0[:, 0] + f1[:, 1]), (2, f0[:, 1] + f1[:, 0])):
+                take = v < f3_
+                f3_, d3 = np.where(take, v, f3_), np.where(take, k, d3)
+            F[nodes_l, 0], F[nodes_l, 1], F[nodes_l, 2] = f1_, f2_, f3_
+            K1[nodes_l], D2[nodes_l], D3[nodes_l] = k1, d2, d3
+
+    def rule(v):
+        e, todo = [], [(int(child[v, 1]), 4 - int(K1[v])), (int(child[v, 0]), int(K1[v]))]
+        while todo:
+            x, allowed = todo.pop()
+            k = 0 if (x < 0 or allowed == 1) else int(D2[x]) if allowed == 2 else int(D3[x])
+            if k == 0:
+                e.append(x)
+            else:
+                todo.append((int(child[x, 1]), allowed - k)); todo.append((int(child[x, 0]), k))
+        return e + [EMPTY] * (4 - len(e))
+
+    def within_three(v, r):
+        for _ in range(3):
+            r = int(parent[r])
+            if r == v:
+                return True
+            if r < 0:
+                return False
+        return False
+
     num_leaves = int(count[root])
     seen_leaf = np.zeros(num_leaves, np.int32)
     used = np.zeros(n, bool)
-    stack = [int(root)]
+    stack = [(int(root), 0)]
     while stack:
-        v = stack.pop()
-        assert not used[v] and depth[v] % 2 == 0, "4-wide node %d reached twice or at odd depth" % v
+        v, lvl = stack.pop()
+        assert not used[v], "4-wide node %d reached twice" % v
         used[v] = True
+        if built_shape:
+            assert [int(x) for x in r4[v]] == rule(v), "entries of 4-wide node %d: %s, the surface-area rule gives %s" % (v, list(r4[v]), rule(v))
+        assert int(nodes4[v, 28]) == lvl, "level of node %d" % v
         got = 0
         for e in range(4):
             r = int(r4[v, e])
             if r == EMPTY:
+                assert (u4[v, e:12:4].view(np.float32) == np.inf).all() and (u4[v, 12 + e::4].view(np.float32) == -np.inf).all(), "an unused entry's box is empty"
                 continue
             box = u4[v, e::4]
             if r >= 0:
-                assert r < n and parent[r] >= 0 and (parent[r] == v or parent[parent[r]] == v), "entry %d of node %d is not a (grand)child" % (e, v)
+                assert r < n and within_three(v, r), "entry %d of node %d is not a descendant within three levels" % (e, v)
                 want = nbox[r]
-                stack.append(r); got += int(count[r])
+                stack.append((r, lvl + 1)); got += int(count[r])
             else:
-                lr = ~r
-                slot, cnt = lr & 0x0FFFFFFF, (lr >> 28) + 1
-                assert 1 <= cnt <= 4 and slot + cnt <= num_leaves
-                seen_leaf[slot:slot + cnt] += 1
-                if cnt == 1:
-                    want = leaf_box[slot]
-                else:
-                    assert (slot, cnt) in by_range, "multi-leaf (%d, %d) of node %d is not a subtree of the binary tree" % (slot, cnt, v)
-                    sub = by_range[(slot, cnt)]
-                    assert parent[sub] == v or parent[parent[sub]] == v
-                    want = nbox[sub]
-                got += cnt
+                slot = ~r
+                assert 0 <= slot < num_leaves
+                seen_leaf[slot] += 1
+                want = leaf_box[slot]
+                got += 1
             assert np.array_equal(box, want), "box of entry %d of node %d" % (e, v)
         assert got == count[v], "node %d covers %d of its %d triangles" % (v, got, count[v])
     assert (seen_leaf == 1).all(), "every leaf slot reached exactly once through the 4-wide nodes"

@@ -177,7 +177,7 @@ def test_cpp_strip_plans_equal_the_python_ones(built):
         b = None if bounds is None else np.asarray(bounds, np.uint32)
         n = L.rtggx_host_exchange_plan(H, rank, world, apron, None if b is None else b.ctypes.data, ops.ctypes.data, 64)
         assert n >= 0
-        return [("send" if o[0] else "recv", "history" if o[1] else "backbuffer", int(o[2]), int(o[3]), int(o[4])) for o in ops[:n]]
+        return [("send" if o[0] else "recv", ("backbuffer", "history", "token")[o[1]], int(o[2]), int(o[3]), int(o[4])) for o in ops[:n]]
     for H in (272, 1080, 2160):
         for world in range(2, 9):
             cost = rng.random(H) * 100 + 1

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from raytracedggx_amd.capi import MAX_PEERS
 from raytracedggx_amd.strips import HISTORY_APRON, exchange_plan, make_ops, run_exchange, strip_rows
 
 H, W = 120, 16
@@ -28,9 +29,12 @@ def _worker(rank, world, port, results):
         b, e = strip_rows(H, rank, world)
         # as in StripRenderer: persistent targets, the operation list built once and reissued every frame
         history = torch.empty((H, W), dtype=torch.int64); back = torch.empty((H, W), dtype=torch.int32)
-        ops = make_ops(dist, exchange_plan(H, rank, world), {"history": history, "backbuffer": back})
+        tokens = torch.zeros(2 * MAX_PEERS, dtype=torch.int32)
+        plan = exchange_plan(H, rank, world)
+        ops = make_ops(dist, plan, {"history": history, "backbuffer": back, "token": tokens})
         for frame in range(4):                                   # several frames: the matching must not drift
             history.fill_(-1); back.fill_(-1)                     # rows this rank did not produce are garbage
+            tokens[rank] = 100 * rank + frame + 1
             history[b:e] = _truth((b, e)) + frame
             back[b:e] = (_truth((b, e)) + frame + 7).to(torch.int32)
             run_exchange(dist, None, None, ops=ops)
@@ -39,6 +43,9 @@ def _worker(rank, world, port, results):
             assert (history[:lo] == -1).all() and (history[hi:] == -1).all(), "nothing beyond the apron is touched"
             if rank == 0:
                 assert torch.equal(back, (_truth((0, H)) + frame + 7).to(torch.int32)), "frame assembly on rank 0"
+            for op, name, r0, r1, peer in plan:                   # the ordering tokens between ranks that exchange nothing else
+                if op == "recv" and name == "token":
+                    assert int(tokens[r0]) == 100 * peer + frame + 1, "rank %d frame %d: token of rank %d" % (rank, frame, peer)
         results[rank] = 1
     finally:
         dist.destroy_process_group()
@@ -50,7 +57,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_exchange_over_gloo(world):
     results = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), results), nprocs=world, join=True)
@@ -58,18 +65,26 @@ def test_exchange_over_gloo(world):
 
 
 def test_plan_is_consistent():
-    """Every send has the matching recv on the peer (same buffer, same rows), in the same per-pair order; strips tile the frame."""
+    """Every send has the matching recv on the peer (same buffer, same rows), in the same per-pair order; strips tile the frame; and
+    EVERY ordered pair of ranks has a message (round 4: any rank may read any rank's history image, rtggx_set_history_peers, and the
+    exchange is what orders the two)."""
     for height, world in ((1080, 8), (2160, 8), (1080, 3), (120, 2), (1081, 4)):
         plans = [exchange_plan(height, r, world) for r in range(world)]
         rows = [strip_rows(height, r, world) for r in range(world)]
         assert rows[0][0] == 0 and rows[-1][1] == height and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
         for a in range(world):
             for b in range(world):
-                sends = [(n, r0, r1) for op, n, r0, r1, peer in plans[a] if op == "send" and peer == b]
-                recvs = [(n, r0, r1) for op, n, r0, r1, peer in plans[b] if op == "recv" and peer == a]
+                sends = [(n, r0, r1) if n != "token" else (n, 1) for op, n, r0, r1, peer in plans[a] if op == "send" and peer == b]
+                recvs = [(n, r0, r1) if n != "token" else (n, 1) for op, n, r0, r1, peer in plans[b] if op == "recv" and peer == a]
                 assert sends == recvs, (height, world, a, b)
+                assert a == b or len(sends) >= 1, "no message from rank %d to rank %d" % (a, b)
+                assert sum(1 for x in sends if x[0] == "token") == (1 if abs(a - b) >= 2 and b != 0 else 0)
+                assert [p for p in exchange_plan(height, a, world, tokens=False)] == [p for p in plans[a] if p[1] != "token"]
         for r in range(world):
             for op, name, r0, r1, peer in plans[r]:
+                if name == "token":
+                    assert r1 == r0 + 1 and r0 == (r if op == "send" else MAX_PEERS + peer)
+                    continue
                 assert 0 <= r0 < r1 <= height
                 if op == "send":
                     assert rows[r][0] <= r0 and r1 <= rows[r][1], "a rank only sends rows it produced"
@@ -109,7 +124,10 @@ def test_raw_send_recv_lists_move_the_right_rows(world):
     for r in range(world):
         b, e = strips.strip_rows(H, r, world)
         hist[r][b:e] = truth_h[b:e]; bb[r][b:e] = truth_b[b:e]
-    raw = [strips.plan_to_raw(strips.exchange_plan(H, r, world), hist[r].ctypes.data, bb[r].ctypes.data, W) for r in range(world)]
+    tok = [np.zeros(2 * MAX_PEERS, np.uint32) for _ in range(world)]
+    for r in range(world):
+        tok[r][r] = 1000 + r
+    raw = [strips.plan_to_raw(strips.exchange_plan(H, r, world), hist[r].ctypes.data, bb[r].ctypes.data, W, tok[r].ctypes.data) for r in range(world)]
     for a in range(world):
         for b_ in range(world):
             sends = [op for op in raw[a] if op[0] and op[3] == b_]
@@ -123,6 +141,8 @@ def test_raw_send_recv_lists_move_the_right_rows(world):
         b, e = strips.strip_rows(H, r, world)
         lo, hi = max(b - strips.HISTORY_APRON, 0), min(e + strips.HISTORY_APRON, H)
         np.testing.assert_array_equal(hist[r][lo:hi], truth_h[lo:hi])
+        for p in range(world):      # a token from everybody who sends this rank nothing else
+            assert tok[r][MAX_PEERS + p] == (1000 + p if abs(p - r) >= 2 and r != 0 else 0)
 
 
 def test_balanced_bounds_and_uneven_plans():
@@ -148,7 +168,8 @@ def test_balanced_bounds_and_uneven_plans():
         truth_b = ((np.arange(H * W, dtype=np.uint64).reshape(H, W) + 7) * 2654435761 % (2 ** 32)).astype(np.uint32)
         for r in range(world):
             hist[r][b[r]:b[r + 1]] = truth_h[b[r]:b[r + 1]]; bb[r][b[r]:b[r + 1]] = truth_b[b[r]:b[r + 1]]
-        raw = [strips.plan_to_raw(strips.exchange_plan(H, r, world, bounds=b), hist[r].ctypes.data, bb[r].ctypes.data, W) for r in range(world)]
+        tok = [np.zeros(2 * MAX_PEERS, np.uint32) for _ in range(world)]
+        raw = [strips.plan_to_raw(strips.exchange_plan(H, r, world, bounds=b), hist[r].ctypes.data, bb[r].ctypes.data, W, tok[r].ctypes.data) for r in range(world)]
         for a in range(world):
             for c in range(world):
                 sends = [op for op in raw[a] if op[0] and op[3] == c]
