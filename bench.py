@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--metallic", type=float, nargs=2, default=None, help="metallic of ground and model (default: the sample's 1 1 = no diffuse rays)")
     ap.add_argument("--deform", type=float, default=0.0, help="amplitude of the breathing-model animation (-deform): new vertices and an asynchronous BVH refit every frame")
     ap.add_argument("--trace-waves", type=int, default=0, help="pin the size of the traversal's resident workgroup (10, 12, 14, 16) instead of letting the library steer it (measurement)")
+    ap.add_argument("--tone-map", choices=["auto", "fused", "two"], default="auto", help="temporal pass + tone map as one kernel or two (measurement; auto: the library's choice, fused on small launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (default: the job's CPU share, at most 16)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
@@ -201,6 +202,8 @@ def main():
     # in the result line as config.setup_priming_frames.
     if not args.stub and args.trace_waves:
         ctx.trace_residency(args.trace_waves)
+    if not args.stub and args.tone_map != "auto":
+        ctx.fuse_tone_map(args.tone_map == "fused")
     for _ in range(0 if args.stub else args.prime_frames):
         r.frame()
     if not args.stub:
@@ -209,7 +212,7 @@ def main():
         # right after set-up, inside the clock ramp, and read 4.6 TB/s)
         if rank == 0:
             ctx.sync()
-            peak_measured = ctx.copy_bandwidth(1 << 30, 64)
+            peak_measured = ctx.copy_bandwidth(1 << 30, 32)
         for _ in range(16):       # (the copy evicted everything: a few frames to refill the caches before the warm-up steps)
             r.frame()
     for _ in range(args.warmup):
@@ -313,7 +316,7 @@ def report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, p
                      "trace_kernel_mrays_alone": None if k_alone != k_alone else round(rays_per_launch / (k_alone * 1e-3) / 1e6, 1),
                      "frac_alone": None if k_alone != k_alone else round(alg_bytes / (k_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      "peak_measured": None if peak_measured is None else round(peak_measured, 1),
-                     "peak_measured_how": "float4 copy kernel, 2 x 1 GiB per launch, best of 2 / 4 / 8 / 16 workgroups per CU at 64 launches each (>= 25 ms), read + written bytes (rtggx_copy_bandwidth), on this box after the set-up priming frames",
+                     "peak_measured_how": "float4 copy kernel, 2 x 1 GiB per launch, best of 2 / 4 / 8 / 16 workgroups per CU, plain and with non-temporal loads / stores, 32 launches each (>= 12 ms), read + written bytes (rtggx_copy_bandwidth), on this box after the set-up priming frames",
                      "note": "traversal is a dependent gather from an L2-resident tree, not a stream: the fraction is reported because the contract asks for it. "
                              "kernel_ms is the duration DURING the timed region, beside two other pipeline stages and at low stream priority (the frame is bound by "
                              "wave-slot time, so the launch is tuned for few wave-cycles, not for its own duration); kernel_ms_alone is the same launch with the chip to "

@@ -228,16 +228,18 @@ int  rtggx_ray_trace(rtggx_context* ctx);
 int  rtggx_denoise(rtggx_context* ctx, int use_shared_mem);
 int  rtggx_tone_map(rtggx_context* ctx);
 
-/* Since round 4 rtggx_denoise's temporal pass also tone-maps its result (one kernel instead of two: Denoiser::Denoise and ::ToneMap
- * follow each other in every frame of the sample, RayTracedGGX.cpp:341-350), and the rtggx_tone_map that follows it in the same frame
- * finds its work done.  A tone map without a preceding rtggx_denoise in the frame, or after an rtggx_upload, runs as a kernel of its
- * own.  Diagnostic: 0 = always two kernels (rounds 1-3's path, kept for comparison: the back buffer is bit-identical). */
-int  rtggx_debug_fuse_tone_map(rtggx_context* ctx, int on);
+/* Round 4: rtggx_denoise's temporal pass can tone-map its result as well (one kernel instead of two: Denoiser::Denoise and ::ToneMap
+ * follow each other in every frame of the sample, RayTracedGGX.cpp:341-350); the rtggx_tone_map that follows it in the same frame then
+ * finds its work done.  The library does so where it pays: on small launches (thin strips, small frames), not on full-size frames
+ * (measured: profiles/r04_c_pipeline_ab.txt).  A tone map without a preceding rtggx_denoise in the frame, or after an rtggx_upload,
+ * always runs as a kernel of its own.  Diagnostic: mode 0 = always two kernels, 1 = always fused, -1 = the library's choice again;
+ * the back buffer and TemporalSSOut are bit-identical either way. */
+int  rtggx_debug_fuse_tone_map(rtggx_context* ctx, int mode);
 /* Diagnostic: which streams a frame's kernels go to is decided from five facts (capi.hip placeFrame: small launch, strip, deforming
  * mesh, diffuse rays, caller-owned main stream).  force_small = 0 / 1 pins the first of them whatever the ray count says (-1: by the
  * count again).  key / where (may be null): the most recent rtggx_ray_trace's key (bit 0 small, 1 strip, 2 deforming, 3 diffuse,
- * 4 caller-owned stream) and placement (bits 0-3 / 4-7 / 8-11: stream of ray generation / traversal / hit shading -- 0 main, 1 B, 2 C,
- * 3 R --, bits 12-15 frames in flight).  Results do not depend on any of it. */
+ * 4 caller-owned stream) and placement (bits 0-3 / 4-7 / 8-11 / 16-19: stream of ray generation / traversal / hit shading / the visibility pass --
+ * 0 main, 1 B, 2 C, 3 R --, bits 12-15 frames in flight).  Results do not depend on any of it. */
 int  rtggx_debug_placement(rtggx_context* ctx, int force_small, uint32_t* key, uint32_t* where);
 /* Diagnostic: the two weights of the 4-wide collapse's objective (lbvh.hip "the 4-wide collapse"): a 4-wide node costs
  * area_weight x (its half-area / the root's) + tris_weight x (its triangles / all triangles) -- the chance that a random ray enters it,

@@ -170,9 +170,9 @@ class Context:
         self._check(self.L.rtggx_debug_fence_wait(self.h, C.byref(us), C.byref(n), 1 if reset else 0))
         return us.value, n.value
 
-    def fuse_tone_map(self, on):
-        """The temporal pass also tone-maps its result (default) / temporal pass and tone map as two kernels (diagnostic)."""
-        self._check(self.L.rtggx_debug_fuse_tone_map(self.h, 1 if on else 0))
+    def fuse_tone_map(self, mode):
+        """True / False: the temporal pass always / never tone-maps its result as well; None: the library's choice (small launches) (diagnostic)."""
+        self._check(self.L.rtggx_debug_fuse_tone_map(self.h, -1 if mode is None else 1 if mode else 0))
 
     def placement(self, force_small=-1):
         """Pins the `small launch` fact of the stream placement (0 / 1; -1: by the ray count) and returns the key and placement of the most
@@ -182,7 +182,7 @@ class Context:
         self._check(self.L.rtggx_debug_placement(self.h, int(force_small), C.byref(k), C.byref(w)))
         names = ("main", "B", "C", "R", "?")
         key = {n: bool((k.value >> i) & 1) for i, n in enumerate(("small", "strip", "deforming", "diffuse", "caller_stream"))}
-        where = {"gen": names[w.value & 15], "trace": names[(w.value >> 4) & 15], "shade": names[(w.value >> 8) & 15], "frames_in_flight": (w.value >> 12) & 15}
+        where = {"raster": names[(w.value >> 16) & 15], "gen": names[w.value & 15], "trace": names[(w.value >> 4) & 15], "shade": names[(w.value >> 8) & 15], "frames_in_flight": (w.value >> 12) & 15}
         return key, where
 
     def collapse_weights(self, area=None, tris=None):

@@ -31,6 +31,10 @@ __global__ void uploadParamsKernel(FrameParams src, FrameParams* dst) {
 __global__ void __launch_bounds__(256) copyKernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
 }
+typedef float __attribute__((ext_vector_type(4))) CopyVec4;
+__global__ void __launch_bounds__(256) copyKernelNT(const CopyVec4* __restrict__ src, CopyVec4* __restrict__ dst, size_t n) {      // the data is used once: non-temporal loads and stores
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
 int uploadParams(rtggx_context* c, uint32_t slot, hipStream_t s) {
   hipLaunchKernelGGL(uploadParamsKernel, dim3(1), dim3(64), 0, s, c->slots[slot], c->dParams + slot);
   RT_HIP(hipGetLastError());
@@ -185,7 +189,7 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   RT_HIP(hipStreamCreateWithPriority(&c->ownVis, hipStreamNonBlocking, prioLeast)); c->streamVis = c->ownVis;
   RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
   RT_HIP(hipEventCreateWithFlags(&c->evRefit, hipEventDisableTiming));
-  RT_HIP(hipEventCreateWithFlags(&c->evGen, hipEventDisableTiming));
+  for (auto& e : c->evGenRing) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : c->evTraceRing) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, prioMid));
   c->rebuildRatio = RT_REFIT_REBUILD_RATIO; c->rebuildSteps = RT_REBUILD_STEPS;      // rtggx_set_refit_policy
@@ -291,7 +295,7 @@ void rtggx_destroy(rtggx_context* c) {
   for (auto& e : c->tev) hipEventDestroy(e);
   hipEventDestroy(c->evAS); hipEventDestroy(c->evRT); for (auto e : c->evSetRead) hipEventDestroy(e);
   hipStreamDestroy(c->ownMain); hipStreamDestroy(c->ownAS); if (c->ownVis) hipStreamDestroy(c->ownVis);
-  hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit); hipEventDestroy(c->evGen); for (auto e : c->evTraceRing) hipEventDestroy(e);
+  hipEventDestroy(c->evVis); hipEventDestroy(c->evRefit); for (auto e : c->evGenRing) hipEventDestroy(e); for (auto e : c->evTraceRing) hipEventDestroy(e);
   if (c->streamRefit) hipStreamDestroy(c->streamRefit);
   delete c;
 }
@@ -402,7 +406,7 @@ int rtggx_set_async_compute(rtggx_context* c, int enable) {
   c->asyncCompute = enable != 0;
   c->streamAS = c->asyncCompute ? c->ownAS : c->streamMain;
   c->streamVis = c->asyncCompute ? c->ownVis : nullptr;
-  c->evVisStream = nullptr; c->genStream = nullptr;
+  c->evVisStream = nullptr; c->genStream = nullptr; for (auto& f : c->genFrame) f = 0u;
   return 0;
 }
 
@@ -539,10 +543,10 @@ static int splitBvhPerSet(rtggx_context* c, uint32_t slot) {
 
 // Issued by rtggx_render_visibility once the new input set is selected and fenced: bring the set's vertex buffer up to date and
 // refit -- everything on stream R; *touched: stream R was given work the visibility pass and the traversal must follow (evRefit, recorded
-// HERE, right behind the refit).  A rebuild beside the frames gets its next launches only after that: they read the snapshot and write
-// the job's own topology, nobody waits for them, and they must not sit between a frame's refit and the event its visibility pass and
-// traversal wait for (round 3 issued them in front: while a rebuild was in progress every frame stalled behind 16 build launches, the
-// single-workgroup plocFinal among them).
+// HERE, right behind the refit).  A rebuild beside the frames gets its next launches only after that and after the visibility pass
+// (issueRebuildSteps): they read the snapshot and write the job's own topology, nobody waits for them, and they must not sit between a
+// frame's refit and what waits for it (round 3 issued them in front: while a rebuild was in progress every frame stalled behind 16
+// build launches, the single-workgroup plocFinal among them).
 static int issuePendingRefits(rtggx_context* c, bool* touched) {
   *touched = false;
   const hipStream_t s = c->asyncCompute ? c->streamRefit : c->streamMain;
@@ -572,13 +576,23 @@ static int issuePendingRefits(rtggx_context* c, bool* touched) {
   for (uint32_t slot = 0; slot < RTGGX_NUM_MESH; ++slot) {
     MeshDev& m = c->mesh[slot];
     if (!m.deforming) continue;
-    bool sw = false;
     if (m.wantRebuild && !swapped[slot]) {      // (the cost that asked for it was the old topology's)
       const int r = startRebuild(c, slot, m.latestSet);
       if (r < 0) return r;
       if (r == 1) m.wantRebuild = false;
     } else if (swapped[slot]) m.wantRebuild = false;
-    { const int r = continueRebuild(c, slot, s, c->rebuildSteps, &sw); if (r) return r; }      // the next launches of a build in progress (the first ones of one just started: the copy of the vertices it starts from)
+  }
+  return 0;
+}
+// ... and, once the frame's visibility pass (which follows the refit on the same stream where launches are full-size) is out as well:
+// the next launches of a rebuild in progress (the first ones of one just started: the copy of the vertices it starts from).
+static int issueRebuildSteps(rtggx_context* c) {
+  const hipStream_t s = c->asyncCompute ? c->streamRefit : c->streamMain;
+  for (uint32_t slot = 0; slot < RTGGX_NUM_MESH; ++slot) {
+    if (!c->mesh[slot].deforming) continue;
+    bool sw = false;
+    const int r = continueRebuild(c, slot, s, c->rebuildSteps, &sw);
+    if (r) return r;
   }
   return 0;
 }
@@ -653,8 +667,9 @@ int rtggx_transform_sh(rtggx_context* c) {
 // plus stream R for the vertex upload and tree refit of a deforming mesh.  No stage fills the machine by itself (the traversal
 // is a latency-bound chain of dependent gathers: profiles/r02_*_limiter.txt), so the three overlap; what each stage hands to the next
 // exists four times (the input sets), and the events are
-//     stream order           visibility -> ray generation (same stream)
-//     evGen                  ray generation f    -> traversal f                (C -> B)
+//     evVis                  visibility f        -> ray generation f           (R -> C; stream order where both are on C)
+//     evGenRing[f & 3]       ray generation f    -> traversal f                (C -> B)
+//                            ray generation f    -> visibility f + 2           (C -> R: the target and the list it cleared)
 //     evTraceRing[f & 3]     traversal f         -> shading f                  (B -> main)
 //                            traversal f - 2     -> ray generation f           (B -> C: the bins' cost record and the ray counters
 //                                                                               exist twice, by frame parity)
@@ -664,16 +679,16 @@ int rtggx_transform_sh(rtggx_context* c) {
 //
 // WHERE a frame's kernels go is decided in ONE place, placeFrame, from a key of five facts (round 4: rounds 2-3 had grown nine
 // interacting switches for it).  The table, each line measured in the round that introduced it (DESIGN.md sections 5, 7, 9):
-//     key                              ray generation   traversal            hit shading       frames in flight
-//     full-size launch                 C                B                    main              4
-//       + a mesh deforms / diffuse rays                                                        3   (the front stages otherwise run ahead into one of two states)
-//     small launch (< 200 000 rays)    C                B, odd frames on R   the traversal's   4   (two traversals in flight; the main stream's chain is a strip's longest)
-//       + a mesh deforms               C                B                    main              4   (R is the refit's)
+//     key                              visibility pass   ray generation   traversal            hit shading       frames in flight
+//     full-size launch                 C                 C                B                    main              4
+//       + a mesh deforms / diffuse rays                                                                          3   (the front stages otherwise run ahead into one of two states)
+//     small launch (< 200 000 rays)    C                 C                B, odd frames on R   the traversal's   4   (two traversals in flight; the main stream's chain is a strip's longest)
+//       + a mesh deforms               C                 C                B                    main              4   (R is the refit's)
 //     strip / caller-owned stream      no line of their own: rows and the main stream's identity do not move a kernel
-//     async compute off                main             main                 main              4
+//     async compute off                main              main             main                 main              4
 struct Placement {
   bool small, strip, deforming, diffuse, callerStream;      // the key
-  hipStream_t gen, trace, shade;
+  hipStream_t raster, gen, trace, shade;
   uint32_t framesInFlight;
   bool alternate, shadeWithTrace;
 };
@@ -686,6 +701,10 @@ static Placement placeFrame(const rtggx_context* c, const FrameParams& fp, uint3
   P.callerStream = c->externalStream;
   const bool async = c->asyncCompute && c->streamVis != nullptr;
   P.gen = async ? c->streamVis : c->streamMain;
+  // (the visibility pass on the geometry stream R, beside the previous frame's ray generation instead of behind it -- built and measured in
+  // round 4: 1080p 0.186 -> 0.202-0.216 ms, the traversal stretched from 0.146 to 0.226 ms by the busier mid-priority stream; profiles/r04_c_pipeline_ab.txt.
+  // What it needed stays: ray generation clears the target of frame f + 2, and the pass waits for that ray generation by event.)
+  P.raster = P.gen;
   P.alternate = async && c->streamRefit != nullptr && P.small && !P.deforming && (frame & 1u) != 0u;
   P.trace = !async ? c->streamMain : P.alternate ? c->streamRefit : c->streamAS;
   P.shadeWithTrace = async && c->attachEvents && !c->timing && P.small && !P.deforming;
@@ -720,17 +739,21 @@ int rtggx_render_visibility(rtggx_context* c) {
   if (P.framesInFlight < RT_SETS) { const int r = waitForSet(c, (c->setIndex + RT_SETS - P.framesInFlight) % RT_SETS); if (r) return r; }
   c->refitIssued = false;
   { const int r = issuePendingRefits(c, &c->refitIssued); if (r) return r; }
-  const hipStream_t s = P.gen;
+  const hipStream_t s = P.raster;
   if (c->evVisStream && c->evVisStream != s) RT_HIP(hipStreamWaitEvent(s, c->evVis, 0));      // the previous pass ran on another stream
-  // constants already on their way on stream B (timing mode uploads them in rtggx_update_as): a pass on stream C reads
-  // dParams[slot] and has to be ordered behind that upload (evAS); on stream B it follows it anyway
+  // this frame's target and list of large triangles were cleared by the ray generation two frames back: on another stream, mostly
+  { const uint32_t k = (c->frameCounter + 2u) & 3u;
+    if (c->frameCounter >= 2u && c->genFrame[k] == c->frameCounter - 2u && c->genStreamOf[k] != s) RT_HIP(hipStreamWaitEvent(s, c->evGenRing[k], 0)); }
+  // constants already on their way on stream B (timing mode uploads them in rtggx_update_as): the pass reads dParams[slot] and has to be
+  // ordered behind that upload (evAS); on stream B it follows it anyway
   if (c->slotUploaded && s != c->streamAS) RT_HIP(hipStreamWaitEvent(s, c->evAS, 0));
-  if (c->refitIssued && c->asyncCompute) RT_HIP(hipStreamWaitEvent(s, c->evRefit, 0));       // the rasteriser reads this set's vertices
+  if (c->refitIssued && c->asyncCompute && s != c->streamRefit) RT_HIP(hipStreamWaitEvent(s, c->evRefit, 0));       // the rasteriser reads this set's vertices (on R it follows the refit anyway)
   if (c->timing) hipEventRecord(c->tev[2], s);
-  const int r = launchVisibility(c, c->slots[c->slot], s, c->streamVis ? c->evVis : nullptr);
+  int r = launchVisibility(c, c->slots[c->slot], s, c->streamVis ? c->evVis : nullptr);
   if (c->streamVis) c->evVisStream = s;
   if (c->timing) hipEventRecord(c->tev[13], s);
-  c->genStream = s;
+  c->genStream = P.gen;
+  if (!r) r = issueRebuildSteps(c);
   return r;
 }
 
@@ -745,9 +768,9 @@ int rtggx_ray_trace(rtggx_context* c) {
   const Placement P = placeFrame(c, fp, f);
   c->lastPlacement[0] = P.small | (P.strip << 1) | (P.deforming << 2) | (P.diffuse << 3) | (P.callerStream << 4);
   const auto streamId = [&](hipStream_t st) { return st == c->streamMain ? 0u : st == c->streamAS ? 1u : st == c->streamVis ? 2u : st == c->streamRefit ? 3u : 4u; };
-  c->lastPlacement[1] = streamId(P.gen) | (streamId(P.trace) << 4) | (streamId(P.shade) << 8) | (P.framesInFlight << 12);
-  // a caller that skipped the visibility pass traces on the placement's streams all the same
-  const hipStream_t sGen = c->genStream ? c->genStream : P.gen;
+  c->lastPlacement[1] = streamId(P.gen) | (streamId(P.trace) << 4) | (streamId(P.shade) << 8) | (P.framesInFlight << 12) | (streamId(P.raster) << 16);
+  const hipStream_t sGen = P.gen;
+  if (c->evVisStream && c->evVisStream != sGen) RT_HIP(hipStreamWaitEvent(sGen, c->evVis, 0));      // this frame's visibility pass (on the geometry stream)
   // Small launches last as long as their longest chain of dependent traversal steps and leave most of the chip idle meanwhile: the
   // traversals of odd frames go to a second stream (R, idle unless a mesh deforms), so that two are in flight.  Everything a traversal
   // shares with its neighbours in time is per input set, per frame parity or per frame & 3, and everybody who needs its results waits
@@ -810,10 +833,14 @@ int rtggx_denoise(rtggx_context* c, int useSharedMem) {
   RT_CHECK_CTX(c);
   if (!c->haveConstants) { setError("rtggx_denoise: no frame constants"); return -1; }
   if (c->timing) hipEventRecord(c->tev[9], c->streamMain);   // start of denoise
-  // Denoiser::Denoise and Denoiser::ToneMap follow each other in every frame of the sample (RayTracedGGX.cpp:341-350): the temporal pass
-  // also tone-maps its result (denoise.hip temporalToneKernel), and rtggx_tone_map finds its work done.  Not in the per-pass timing
-  // mode (the tone map keeps a duration of its own) and not after rtggx_debug_fuse_tone_map(ctx, 0).
-  const bool fuse = c->fuseToneMap && !c->timing;
+  // Denoiser::Denoise and Denoiser::ToneMap follow each other in every frame of the sample (RayTracedGGX.cpp:341-350), and the temporal pass can
+  // tone-map its result as well (denoise.hip temporalToneKernel; rtggx_tone_map then finds its work done): one launch, one event-carrying
+  // gap and 8 bytes per pixel less.  WHERE that pays was measured (profiles/r04_c_pipeline_ab.txt): on small launches -- thin strips, small
+  // frames, bound by the host's launches and the main stream's chain of short kernels -- and NOT on full-size frames, where the fused
+  // kernel's workgroups of 1024 threads and 45 KB of LDS find room on a CU shared with the traversal's resident workgroup and ray
+  // generation later than four small ones do (1080p 0.186 -> 0.204 ms; 512 threads: 0.199).  So it follows the placement's `small`; not in
+  // the per-pass timing mode (the tone map keeps a duration of its own); rtggx_debug_fuse_tone_map pins it either way.
+  const bool fuse = !c->timing && (c->fuseToneMap > 0 || (c->fuseToneMap < 0 && c->lastTraceSmall));
   const bool carry = fuse || !c->attachEvents;      // the frame's last kernel on this stream carries the set's event; else the tone map will
   const int r = launchDenoise(c, c->slots[c->slot], useSharedMem, c->streamMain, carry ? c->evSetRead[c->setIndex] : nullptr, fuse);
   if (carry) { c->setReadRecorded[c->setIndex] = true; c->setReadDeferred = -1; } else c->setReadDeferred = (int)c->setIndex;
@@ -870,9 +897,9 @@ int rtggx_debug_fence_wait(rtggx_context* c, double* usTotal, uint32_t* waits, i
   if (reset) { c->fenceWaitUs = 0.0; c->fenceWaits = 0u; }
   return 0;
 }
-int rtggx_debug_fuse_tone_map(rtggx_context* c, int on) {
+int rtggx_debug_fuse_tone_map(rtggx_context* c, int mode) {
   RT_CHECK_CTX(c);
-  c->fuseToneMap = on != 0;      // from the next rtggx_denoise on
+  c->fuseToneMap = mode < 0 ? -1 : mode != 0;      // from the next rtggx_denoise on
   return 0;
 }
 // force_small: -1 by the ray count, 0 / 1 the placement of a full-size / small launch whatever the count (from the next frame on).
@@ -1050,10 +1077,12 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
 }
 
 // Attainable HBM bandwidth of the device, for the roofline's "peak measured beside the vendor figure" (SURVEY 8d): a float4
-// copy kernel over two buffers of `bytes` each (far larger than the 256 MiB Infinity Cache when bytes >= 1 GiB), timed with
-// events on the main stream; gbytes_per_s = (bytes read + bytes written) / time.  The launch shape matters by 20 % on this part
-// (tools/microbench/copy_bw.hip, profiles/r03_h_copy_peak.txt: 2 x 1 GiB grid-stride at 4 workgroups per CU 5.6 TB/s, at 16 per CU
-// 4.6 TB/s, hipMemcpyAsync 4.8): the shapes of kCopyShapes each get `iterations` launches and the best one is reported.
+// copy kernel over two buffers of `bytes` each (far larger than the 256 MiB Infinity Cache when bytes >= 1 GiB: at 2 x 128 MiB the same
+// loop reads 7.2 TB/s), timed with events on the main stream; gbytes_per_s = (bytes read + bytes written) / time.  The launch shape
+// matters by 20 % on this part and non-temporal accesses by another 8 % (tools/microbench/copy_bw.hip, profiles/r03_h_copy_peak.txt,
+// r04_b_copy_peak.txt: a grid-stride loop at 4 workgroups per CU 5.7 TB/s, at 16 per CU 4.6, hipMemcpyAsync 4.8; the same loop at 4 per CU
+// with non-temporal loads and stores 6.17 TB/s -- 98 % of the 6.29 MI355X_MICROARCH.md quotes; rounds 2-3 reported 5.5-5.7 without them):
+// the shapes of kCopyShapes each get `iterations` launches, plain and non-temporal, and the best one is reported.
 static const uint32_t kCopyShapes[] = {2u, 4u, 8u, 16u};   // workgroups per CU
 int rtggx_copy_bandwidth(rtggx_context* c, size_t bytes, int iterations, double* gbytesPerS) {
   RT_CHECK_CTX(c);
@@ -1069,16 +1098,21 @@ int rtggx_copy_bandwidth(rtggx_context* c, size_t bytes, int iterations, double*
   double best = 0.0;
   for (uint32_t shape : kCopyShapes) {
     const uint32_t blocks = c->numCUs * shape;
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
-    hipEventRecord(e0, c->streamMain);
-    for (int i = 0; i < iterations; ++i) hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n);
-    hipEventRecord(e1, c->streamMain);
-    e = hipEventSynchronize(e1);
-    float ms = 0.0f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e != hipSuccess || !(ms > 0.0f)) { if (e == hipSuccess) e = hipErrorUnknown; break; }
-    const double rate = 2.0 * (double)(n * 16) * iterations / ((double)ms * 1e-3) / 1e9;
-    if (rate > best) best = rate;
+    for (int nt = 0; nt < 2 && e == hipSuccess; ++nt) {
+      const auto launch = [&]() { if (nt) hipLaunchKernelGGL(copyKernelNT, dim3(blocks), dim3(256), 0, c->streamMain, (const CopyVec4*)src, (CopyVec4*)dst, n);
+                                  else hipLaunchKernelGGL(copyKernel, dim3(blocks), dim3(256), 0, c->streamMain, (const float4*)src, dst, n); };
+      for (int i = 0; i < 2; ++i) launch();
+      hipEventRecord(e0, c->streamMain);
+      for (int i = 0; i < iterations; ++i) launch();
+      hipEventRecord(e1, c->streamMain);
+      e = hipEventSynchronize(e1);
+      float ms = 0.0f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      if (e != hipSuccess || !(ms > 0.0f)) { if (e == hipSuccess) e = hipErrorUnknown; break; }
+      const double rate = 2.0 * (double)(n * 16) * iterations / ((double)ms * 1e-3) / 1e9;
+      if (rate > best) best = rate;
+    }
+    if (e != hipSuccess) break;
   }
   hipEventDestroy(e0); hipEventDestroy(e1); hipFree(src); hipFree(dst);
   if (e != hipSuccess) { setError("rtggx_copy_bandwidth: %s", hipGetErrorString(e)); return -2; }

@@ -35,17 +35,19 @@ namespace rt {
 // instructions each) become multiplications by a constant or by v_rcp_f32 (1 ulp).  Not in the temporal pass: see tssTM.
 RT_DEV float rcpFast(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// nx, ny, nz: the 10-bit UNORM normal as the INTEGERS 2 k - 1023 (in floats): the reference's value k * 2 / 1023 - 1 is that / 1023, and the
+// filters' dot products are then exact in fp32 (tapWeight)
 struct GTexel { float nx, ny, nz, nw, rough, metal, depth; };
 
 RT_DEV GTexel loadG(const uint32_t* __restrict__ normal, const uint16_t* __restrict__ roughMetal, const uint32_t* __restrict__ depth32,
                     int x, int y, int W, int H) {
   GTexel g;
-  if (x < 0 || y < 0 || x >= W || y >= H) { g.nx = g.ny = g.nz = -1.0f; g.nw = 0.0f; g.rough = 0.0f; g.metal = 0.0f; g.depth = 0.0f; return g; }
+  if (x < 0 || y < 0 || x >= W || y >= H) { g.nx = g.ny = g.nz = -1023.0f; g.nw = 0.0f; g.rough = 0.0f; g.metal = 0.0f; g.depth = 0.0f; return g; }      // (zeros: the normal reads -1)
   const size_t i = (size_t)y * W + x;
   const uint32_t n = normal[i];
-  g.nx = (float)(n & 1023u) * (2.0f / 1023.0f) - 1.0f;
-  g.ny = (float)((n >> 10) & 1023u) * (2.0f / 1023.0f) - 1.0f;
-  g.nz = (float)((n >> 20) & 1023u) * (2.0f / 1023.0f) - 1.0f;
+  g.nx = (float)(2 * (int)(n & 1023u) - 1023);
+  g.ny = (float)(2 * (int)((n >> 10) & 1023u) - 1023);
+  g.nz = (float)(2 * (int)((n >> 20) & 1023u) - 1023);
   g.nw = (float)(n >> 30) * (1.0f / 3.0f);
   const uint32_t rm = roughMetal[i];
   g.rough = (float)(rm & 0xFFu) * (1.0f / 255.0f); g.metal = (rm >> 8) == 255u ? 1.0f : (float)(rm >> 8) * (1.0f / 255.0f);
@@ -80,25 +82,39 @@ struct Targets {
 // 512th power overflows, 0 x inf = NaN, and the pixel (then its column) turns NaN -- in the reference, hence here:
 // reflection texels are staged as they are, with the flag in the sign bit of the roughness word.
 struct Centre { float nx, ny, nz, depth, rough, gaussK /* -0.5 log2(e) / sigma^2 */, depthK /* dc 4 log2(e) */; };
-// pow(x, 512) / pow(x, 32) of the normal weight.  HLSL's pow IS exp2(y log2 x) on the hardware's 1-ulp functions; rounds 1-3 squared x nine
-// (five) times, which carries 2^k - 1 roundings -- up to 423 ulps of the true power over the possible dot products, against 16 for
-// v_exp_f32(512 v_log_f32(x)) where the weight is above 1e-6 and 80 at worst (tools/microbench/pow512.hip, profiles/r04_a_pow512.txt) --
-// and the temporal pass turns a 1e-5 difference of the filtered image into 1e-3.  Two quarter-rate instructions
-// and a multiplication instead of nine (five) multiplications; x = 0 gives 0, x > 2^(1/4) gives +inf like the true power does (the
-// reference's 0 x inf = NaN for taps outside the frame, SpatialFilter.hlsli:60, stays where it was).
-RT_DEV float powByLog(float x, float n) { return __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(x)); }
+// The normal weight pow(max(dot(N, Nc), 0), 512 | 32) (SpatialFilter.hlsli:62,73).  x = dot(N, Nc) sits next to 1 and the power multiplies
+// its relative error by 512: one fp32 rounding of the dot product (6e-8) is 3e-5 in the weight, and the temporal pass turns a 1e-5
+// difference of the filtered image into 1e-3 of its result.  HLSL leaves the order of a dp3 and the last bits of
+// pow (= exp2(y log2 x) on 1-ulp functions) open, so two faithful implementations differ by that much; rounds 1-3 passed the parity
+// check by sharing one arbitrary choice (a fused dot product and nine squarings, 423 ulps from the true power) with the oracle.
+// Round 4 evaluates the TRUE value instead, to a few ulps, and the oracle holds its own evaluations against it (exact in double; plain
+// fp32 libm):
+//   * the normals are 10-bit UNORM codes k: N = (2 k - 1023) / 1023.  With the integers 2 k - 1023 the dot product I is an integer below
+//     2^24: three fp32 operations, no rounding at all.  x - 1 = d = (I - 1023^2) / 1023^2: exact numerator, ONE rounding, relative to d;
+//   * log2(1 + d) = v_log_f32(fl(1 + d)) + (what that rounding dropped) log2(e);
+//   * the power, the Gaussian and the depth term share one v_exp_f32: 2^(n log2 x + e).  A power that overflows (x >= 2^(1/4): only a
+//     tap outside the frame, whose normal reads (-1, -1, -1)) stays +inf whatever e is -- the reference's 0 x inf = NaN for such taps
+//     (SpatialFilter.hlsli:60) appears in the same pixels.
+// tools/microbench/pow512.hip, profiles/r04_a_pow512.txt: within 5 ulps of the true power where the weight is above 0.01.
+#define RT_NORMAL_SCALE_SQ 1046529.0f      // 1023^2
+RT_DEV float log2OfDot(float I) {          // log2(max(I / 1023^2, 0))
+  const float d = fmaxf((I - RT_NORMAL_SCALE_SQ) * (1.0f / RT_NORMAL_SCALE_SQ), -1.0f);
+  const float xr = 1.0f + d;
+  const float dropped = (1.0f - xr) + d;
+  return __builtin_fmaf(dropped, RT_LOG2E, __builtin_amdgcn_logf(xr));      // (x = 0: -inf, the weight 0)
+}
 template <bool DIFFUSE>
 RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, float depth, float rough) {
 #pragma clang fp contract(fast)
-  // N . Nc as one multiplication and two fused multiply-adds (what a dp3 is on the reference's hardware)
-  const float x = fmaxf(__builtin_fmaf(c.nz, nz, __builtin_fmaf(c.ny, ny, c.nx * nx)), 0.0f);
+  const float I = __builtin_fmaf(c.nz, nz, __builtin_fmaf(c.ny, ny, c.nx * nx));      // exact: integers below 2^24
+  const float lg = log2OfDot(I);
   const float dd = fabsf(c.depth - depth) * c.depthK;
-  if (DIFFUSE) return powByLog(x, 32.0f) * __builtin_amdgcn_exp2f(-dd);
-  const float p = powByLog(x, 512.0f);
+  if (DIFFUSE) return __builtin_amdgcn_exp2f(__builtin_fmaf(32.0f, lg, -dd));
+  const float pw = 512.0f * lg;
   const float e = __builtin_fmaf(c.gaussK, (float)(i * i), -dd);
   const float t = saturatef(fabsf(fabsf(rough) - c.rough) * 2.0f);
   const float flag = (__float_as_uint(rough) >> 31) ? 0.0f : 1.0f;          // sign bit set: norm.w <= 0
-  return ((p * __builtin_amdgcn_exp2f(e)) * (1.0f - t * t * (3.0f - 2.0f * t))) * flag;
+  return (__builtin_amdgcn_exp2f(pw >= 128.0f ? pw : pw + e) * (1.0f - t * t * (3.0f - 2.0f * t))) * flag;
 }
 template <bool DIFFUSE>
 RT_DEV Centre makeCentre(float nx, float ny, float nz, float depth, float rough, int W, int H) {
@@ -280,8 +296,8 @@ RT_DEV const uint2* peerHistoryRow(const Targets& T, int iy) {
 }
 // One pixel of the temporal pass: (x, y) of the frame = (lx, ly) of the workgroup's LDS tiles (tone-mapped FilteredOut1 + alpha, the
 // velocity texels and their squared lengths; 66 texels per row, a one-texel apron all round).  Returns TemporalSSOut's packed texel.
-template <int ROWS>
-RT_DEV uint2 temporalPixel(const Targets& T, const float4 (&tile)[ROWS][66], const uint32_t (&velRaw)[ROWS][66], const float (&velSq)[ROWS][66], int x, int y, int lx, int ly) {
+template <int ROWS, int PITCH>
+RT_DEV uint2 temporalPixel(const Targets& T, const float4 (&tile)[ROWS][PITCH], const uint32_t (&velRaw)[ROWS][PITCH], const float (&velSq)[ROWS][PITCH], int x, int y, int lx, int ly) {
   const int W = T.W, H = T.H;
   const float Wf = (float)W, Hf = (float)H;
   const float uvx = ((float)x + 0.5f) * rcpFast(Wf), uvy = ((float)y + 0.5f) * rcpFast(Hf);
@@ -434,21 +450,21 @@ RT_DEV uint2 temporalPixel(const Targets& T, const float4 (&tile)[ROWS][66], con
   }
   return packRGBA16F(result.x, result.y, result.z, hw);   // :335 (TSS[parity])
 }
-// Stages the tiles of a (ROWS - 2) x 64 pixel block whose first pixel is (ox + 1, oy + 1).
-template <int ROWS, int THREADS>
-RT_DEV void stageTemporalTiles(const Targets& T, float4 (&tile)[ROWS][66], uint32_t (&velRaw)[ROWS][66], float (&velSq)[ROWS][66], int ox, int oy) {
+// Stages the tiles of a (ROWS - 2) x (PITCH - 2) pixel block whose first pixel is (ox + 1, oy + 1).
+template <int ROWS, int PITCH, int THREADS>
+RT_DEV void stageTemporalTiles(const Targets& T, float4 (&tile)[ROWS][PITCH], uint32_t (&velRaw)[ROWS][PITCH], float (&velSq)[ROWS][PITCH], int ox, int oy) {
   const int W = T.W, H = T.H;
-  for (int t = threadIdx.x; t < ROWS * 66; t += THREADS) {
-    const int tx = ox + t % 66, ty = oy + t / 66;
+  for (int t = threadIdx.x; t < ROWS * PITCH; t += THREADS) {
+    const int tx = ox + t % PITCH, ty = oy + t / PITCH;
     const bool inside = tx >= 0 && ty >= 0 && tx < W && ty < H;
     const size_t ti = inside ? (size_t)ty * W + tx : 0;
     const f4 raw = inside ? unpackRGBA16F(T.fltDff[ti]) : f4{0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t vr = inside ? T.velocity[ti] : 0u;
     const f3 tm = tssTM(mk3(raw.x, raw.y, raw.z));
-    tile[t / 66][t % 66] = make_float4(tm.x, tm.y, tm.z, raw.w);
+    tile[t / PITCH][t % PITCH] = make_float4(tm.x, tm.y, tm.z, raw.w);
     const float vx = f16ToF32(vr & 0xFFFFu), vy = f16ToF32(vr >> 16);
-    velRaw[t / 66][t % 66] = vr;
-    velSq[t / 66][t % 66] = vx * vx + vy * vy;
+    velRaw[t / PITCH][t % PITCH] = vr;
+    velSq[t / PITCH][t % PITCH] = vx * vx + vy * vy;
   }
 }
 #define RT_TP_ROWS 4
@@ -456,12 +472,12 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
   __shared__ float4 tile[RT_TP_ROWS + 2][66];
   __shared__ uint32_t velRaw[RT_TP_ROWS + 2][66];      // the velocity texels of the same window (zero outside the frame) ...
   __shared__ float velSq[RT_TP_ROWS + 2][66];          // ... and their squared lengths: VelocityMax compares five of them per pixel
-  stageTemporalTiles<RT_TP_ROWS + 2, 256>(T, tile, velRaw, velSq, (int)blockIdx.x * 64 - 1, T.rowBegin + (int)blockIdx.y * RT_TP_ROWS - 1);
+  stageTemporalTiles<RT_TP_ROWS + 2, 66, 256>(T, tile, velRaw, velSq, (int)blockIdx.x * 64 - 1, T.rowBegin + (int)blockIdx.y * RT_TP_ROWS - 1);
   __syncthreads();
   const int lx = (threadIdx.x & 63) + 1, ly = (threadIdx.x >> 6) + 1;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = T.rowBegin + blockIdx.y * RT_TP_ROWS + (threadIdx.x >> 6);
   if (x >= T.W || y >= T.rowEnd) return;
-  T.scratch[(size_t)y * T.W + x] = temporalPixel<RT_TP_ROWS + 2>(T, tile, velRaw, velSq, x, y, lx, ly);
+  T.scratch[(size_t)y * T.W + x] = temporalPixel<RT_TP_ROWS + 2, 66>(T, tile, velRaw, velSq, x, y, lx, ly);
 }
 
 // The temporal pass and the tone map in ONE kernel (round 4; CSTemporalSS.hlsl:254-336 + PSToneMap.hlsl:13-41; Denoiser.cpp:66-103 issues
@@ -472,21 +488,26 @@ __global__ void __launch_bounds__(256) temporalKernel(Targets T) {
 // two-kernel path reads back: the back buffer is bit-identical) in LDS and tone-maps the 62 x 14 pixels inside: 1.18 x the temporal work.
 // TemporalSSOut is written by the workgroup whose interior holds the pixel; of a strip's apron rows (b - 1 and e: what the two-kernel
 // path's temporal pass writes there) by the first and last row of workgroups.
-#define RT_TT_W 62
-#define RT_TT_H 14
-__global__ void __launch_bounds__(1024) temporalToneKernel(Targets T) {
-  __shared__ float4 tile[RT_TT_H + 4][66];
-  __shared__ uint32_t velRaw[RT_TT_H + 4][66];
-  __shared__ float velSq[RT_TT_H + 4][66];
-  __shared__ float4 tm[RT_TT_H + 2][64];      // c / (c + 0.5) and alpha of the temporal result; zero outside the frame (what D3D reads there)
+#ifndef RT_TT_TW
+#define RT_TT_TW 64      // temporal pixels (= threads) of a workgroup: RT_TT_TW x RT_TT_TH; back-buffer pixels: two less each way
+#define RT_TT_TH 16
+#endif
+#define RT_TT_W (RT_TT_TW - 2)
+#define RT_TT_H (RT_TT_TH - 2)
+__global__ void __launch_bounds__(RT_TT_TW * RT_TT_TH) temporalToneKernel(Targets T) {
+  constexpr int TW = RT_TT_TW, TH = RT_TT_TH;
+  __shared__ float4 tile[TH + 2][TW + 2];
+  __shared__ uint32_t velRaw[TH + 2][TW + 2];
+  __shared__ float velSq[TH + 2][TW + 2];
+  __shared__ float4 tm[TH][TW];      // c / (c + 0.5) and alpha of the temporal result; zero outside the frame (what D3D reads there)
   const int x0 = (int)blockIdx.x * RT_TT_W - 1, y0 = T.outBegin + (int)blockIdx.y * RT_TT_H - 1;      // the pixel of thread (0, 0)
-  stageTemporalTiles<RT_TT_H + 4, 1024>(T, tile, velRaw, velSq, x0 - 1, y0 - 1);
+  stageTemporalTiles<TH + 2, TW + 2, TW * TH>(T, tile, velRaw, velSq, x0 - 1, y0 - 1);
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
   const int x = x0 + tx, y = y0 + ty;
   float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (x >= 0 && x < T.W && y >= T.rowBegin && y < T.rowEnd) {      // (T.rowBegin .. T.rowEnd: the strip + one row either side, inside the frame)
-    const uint2 packed = temporalPixel<RT_TT_H + 4>(T, tile, velRaw, velSq, x, y, tx + 1, ty + 1);
+    const uint2 packed = temporalPixel<TH + 2, TW + 2>(T, tile, velRaw, velSq, x, y, tx + 1, ty + 1);
     const bool mine = tx >= 1 && tx <= RT_TT_W && (ty >= 1 && ty <= RT_TT_H ? true : ty == 0 ? blockIdx.y == 0 : blockIdx.y == gridDim.y - 1);
     if (mine) T.scratch[(size_t)y * T.W + x] = packed;
     {
@@ -607,7 +628,7 @@ int launchDenoise(rtggx_context* c, const FrameParams& fp, int useLds, hipStream
     hipLaunchKernelGGL(spatialDirectKernel<3>, grid(TV, 64, 4), block, 0, s, TV); mark(7);
   }
   if (fuseToneMap) {      // the temporal pass and the tone map of its result in one kernel: workgroups of 62 x 14 back-buffer pixels over the strip's own rows
-    const dim3 g((fp.W + RT_TT_W - 1) / RT_TT_W, (uint32_t)(TT.outEnd - TT.outBegin + RT_TT_H - 1) / RT_TT_H), b(1024);
+    const dim3 g((fp.W + RT_TT_W - 1) / RT_TT_W, (uint32_t)(TT.outEnd - TT.outBegin + RT_TT_H - 1) / RT_TT_H), b(RT_TT_TW * RT_TT_TH);
     if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalToneKernel, g, b, 0, s, nullptr, done, 0, TT);
     else { hipLaunchKernelGGL(temporalToneKernel, g, b, 0, s, TT); if (done) hipEventRecord(done, s); }
   } else if (done && c->attachEvents) hipExtLaunchKernelGGL(temporalKernel, grid(TT, 64, RT_TP_ROWS), block, 0, s, nullptr, done, 0, TT);

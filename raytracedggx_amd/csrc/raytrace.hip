@@ -511,10 +511,11 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
     setError("rtggx_ray_trace: a material with metallic below 1 (a diffuse ray per pixel as well) but ray bins of %u slots: rtggx_update_frame sizes them", c->binSlots); return -1;
   }
   GenArgs G;
-  // ray generation starts the next frame's visibility pass (GenArgs)
-  { const uint32_t nextFrame = c->frameCounter + 1u, nextSet = (c->setIndex + 1u) % RT_SETS;
-    G.visNext = c->visDepthBuf[nextFrame % RT_VIS_RING]; G.zeroNext0 = c->largeCountBase + (nextFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
-    c->visClearedFor = G.visNext; c->visClearedRows[0] = rb; c->visClearedRows[1] = re; }
+  // ray generation starts the visibility pass of the frame after next (GenArgs): its target cleared, its list of large triangles emptied
+  // (the list by frame parity: the one this frame's visibility pass has just used up), and the next set's split list
+  { const uint32_t thenFrame = c->frameCounter + 2u, nextSet = (c->setIndex + 1u) % RT_SETS;
+    G.visNext = c->visDepthBuf[thenFrame % RT_VIS_RING]; G.zeroNext0 = c->largeCountBase + (thenFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
+    auto& vc = c->visClearedAt[thenFrame % RT_VIS_RING]; vc.frame = thenFrame; vc.rows[0] = rb; vc.rows[1] = re; }
   G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
   G.diffPrev = c->genCarriesDiff ? c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS] : nullptr;
@@ -534,11 +535,14 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   G.binWork = adaptive ? c->binWork : nullptr; G.splitList = c->splitList; G.splitCount = c->splitCount;
   G.frontWork = RT_SPLIT_FRONT < splitWork ? RT_SPLIT_FRONT : splitWork;
   G.splitWork = splitWork; G.splitMaxShift = splitMaxShift < 3u ? splitMaxShift : 3u; G.splitCap = splitCap < RT_SPLIT_CAP ? splitCap : RT_SPLIT_CAP;
-  if (sGen != s && c->attachEvents) hipExtLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, sGen, nullptr, c->evGen, 0, (const FrameParams*)(c->dParams + c->slot), G);
+  const hipEvent_t evGen = c->evGenRing[c->frameCounter & 3u];
+  if (sGen != s && c->attachEvents) hipExtLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, sGen, nullptr, evGen, 0, (const FrameParams*)(c->dParams + c->slot), G);
   else hipLaunchKernelGGL(rayGenKernel, dim3(G.numTiles), dim3(256), 0, sGen, c->dParams + c->slot, G);
-  if (sGen != s) {      // ray generation on the visibility pass's stream, the traversal on stream B behind it
-    if (!c->attachEvents) RT_HIP(hipEventRecord(c->evGen, sGen));
-    RT_HIP(hipStreamWaitEvent(s, c->evGen, 0));
+  c->genFrame[c->frameCounter & 3u] = 0u; c->genStreamOf[c->frameCounter & 3u] = sGen;
+  if (sGen != s) {      // ray generation on stream C, the traversal on stream B behind it
+    if (!c->attachEvents) RT_HIP(hipEventRecord(evGen, sGen));
+    RT_HIP(hipStreamWaitEvent(s, evGen, 0));
+    c->genFrame[c->frameCounter & 3u] = c->frameCounter;      // (the event exists: a visibility pass on another stream two frames on waits for it)
   }
   if (c->timing) hipEventRecord(c->tev[11], s);
   const bool ring = c->kernelRing && c->kevCount < c->kevBegin.size() && (c->ringTick++ % c->ringStride) == 0u;

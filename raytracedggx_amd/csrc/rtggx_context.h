@@ -33,10 +33,12 @@
 #define RT_SETS 4
 #endif
 #define RT_SLOTS (RT_SETS + 1)
-// The visibility target (visDepth) exists once more than the other members of an input set: ray generation of frame f clears the
-// target of frame f + 1 on its way (raytrace.hip) -- one kernel launch and one pass over 8 bytes per pixel less per frame --, and the
-// target it clears must be one nobody reads any more: frame f + 1 - RT_VIS_RING's, whose last reader the host has waited for (evSetRead).
-#define RT_VIS_RING (RT_SETS + 1)
+// The visibility target (visDepth) exists twice more than the other members of an input set: ray generation of frame f clears the
+// target of frame f + 2 on its way (raytrace.hip) -- one kernel launch and one pass over 8 bytes per pixel less per frame --, and the
+// target it clears must be one nobody reads any more: frame f + 2 - RT_VIS_RING's, whose last reader the host has waited for (evSetRead).
+// (Round 3 cleared the target of frame f + 1, which chained the visibility pass of frame f + 1 behind ray generation f on one stream;
+// round 4 runs the visibility pass on the geometry stream beside it: capi.hip placeFrame.)
+#define RT_VIS_RING (RT_SETS + 2)
 #define RT_VIS_CLEAR 0x00FFFFFF00000000ull      // (D24 = 1.0) << 32 | nothing drawn
 namespace rt {
 
@@ -168,7 +170,8 @@ struct rtggx_context {
   int pipeline = 1;
   bool refitIssued = false; bool traceRecorded[4] = {}; hipStream_t genStream = nullptr;   // per-frame issue state (capi.hip)
   uint32_t frameCounter = 0;                       // frames started (rtggx_render_visibility); parity selects binWork / ray counters
-  hipEvent_t evGen = nullptr;                      // ray generation of the current frame done (C -> B)
+  hipEvent_t evGenRing[4] = {};                    // ray generation of frame f done: [f & 3] (C -> B: traversal f; C -> R: the visibility pass of frame f + 2, whose target and lists it cleared)
+  uint32_t genFrame[4] = {}; hipStream_t genStreamOf[4] = {};      // the frame whose ray generation evGenRing[k] belongs to (0: none), and its stream
   hipEvent_t evTraceRing[4] = {};                  // traversal of frame f done: [f & 3] (B -> main; B -> C two frames later: binWork)
   hipStream_t ownAS = nullptr, ownVis = nullptr;   // the context's own stream B / stream C; streamAS / streamVis alias streamMain / null while
   bool asyncCompute = true;                        // rtggx_set_async_compute(0) is in force (the sample's [A] toggle: one queue, submission order)
@@ -187,8 +190,9 @@ struct rtggx_context {
   int setReadDeferred = -1;      // the set whose event is still to ride on a later kernel of this frame (capi.hip settleSetRead)
   double fenceWaitUs = 0.0; uint32_t fenceWaits = 0;      // host time spent waiting at the frames-in-flight fence (rtggx_render_visibility; rtggx_debug_fence_wait)
   // The temporal pass and the tone map as one kernel (denoise.hip temporalToneKernel): rtggx_denoise then writes the back buffer as well and
-  // the rtggx_tone_map that follows it in the same frame has nothing left to launch.  rtggx_debug_fuse_tone_map(ctx, 0): two kernels, as in rounds 1-3.
-  bool fuseToneMap = true, toneMapDone = false, denoiseIssued = false;
+  // the rtggx_tone_map that follows it in the same frame has nothing left to launch.  -1: where it pays -- small launches (capi.hip
+  // rtggx_denoise); rtggx_debug_fuse_tone_map(ctx, 0 / 1): never / always.
+  int fuseToneMap = -1; bool toneMapDone = false, denoiseIssued = false;
   // Multi-GPU strips: every rank's two history images as mapped into THIS process (rtggx_set_history_peers) -- device table
   // [2][RT_MAX_PEERS] pointers + [RT_MAX_PEERS + 1] row boundaries; a history tap beyond the exchanged apron reads the owner's image.
   uint32_t* exchangeTokens = nullptr;      // RTGGX_BUF_EXCHANGE_TOKENS
@@ -215,7 +219,8 @@ struct rtggx_context {
   uint16_t* roughMetal = nullptr;
   unsigned long long* visDepthBuf[RT_VIS_RING] = {};      // by frameCounter % RT_VIS_RING
   // which target the last ray generation cleared for the next frame's visibility pass, and over which rows (visibility.hip)
-  unsigned long long* visClearedFor = nullptr; uint32_t visClearedRows[2] = {0, 0}; uint32_t visStandaloneClears = 0;
+  struct VisCleared { uint32_t frame = 0, rows[2] = {0, 0}; } visClearedAt[RT_VIS_RING];      // target k has been cleared, over these rows, FOR this frame (0: not)
+  uint32_t visStandaloneClears = 0;
   uint32_t* depth32 = nullptr; uint32_t* depth32Buf[RT_SETS] = {};      // the D24 word of visDepth once more, 4 bytes per pixel, for the spatial filters (written by ray generation)
   uint32_t *normalBuf[RT_SETS] = {}, *velocityBuf[RT_SETS] = {}, *rtReflBuf[RT_SETS] = {}, *rtDiffBuf[RT_SETS] = {};
   uint16_t* roughMetalBuf[RT_SETS] = {};

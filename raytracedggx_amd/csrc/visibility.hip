@@ -68,8 +68,8 @@ RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
 }
 
 // Clears rows of a visibility target and empties the lists the pass appends to.  Since round 3 this is the EXCEPTION: ray generation
-// of frame f clears the target of frame f + 1 on its way (raytrace.hip), and this kernel runs only where that has not happened -- a
-// context's first frame, a strip whose rows changed, a caller that rendered visibility twice without tracing.
+// of frame f clears the target of frame f + 2 on its way (raytrace.hip), and this kernel runs only where that has not happened -- a
+// context's first two frames, a strip whose rows changed, a caller that rendered visibility without tracing two frames earlier.
 __global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begin, uint32_t end, uint32_t* __restrict__ largeCount, uint32_t* __restrict__ splitCount) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { *largeCount = 0; *splitCount = 0; }      // the large-triangle list of rasterSmall and this set's split list (rayGenKernel) start empty
   // four words (32 bytes) per thread: a quarter of the waves, each with 2 KB of stores in flight
@@ -86,17 +86,17 @@ __global__ void clearVisDepth(unsigned long long* __restrict__ vd, uint32_t begi
 // wave's triangles form one list (prefix sum of the box sizes); lane l takes candidates l, l + 64, ...: finds the
 // triangle by binary search in the prefix sums and the pixel inside the box with a multiply-shift division.  The
 // per-thread box loop this replaces ran as long as the largest box in the wave (42 us on the 1080p bunny frame).
-// Round 4: a wave takes RT_RASTER_TPW = 16 triangles, not 64 -- the kernel is a chain of dependent steps (indices -> vertices -> set-up ->
-// ~30 candidate pixels per triangle), 1 092 waves of it were four per CU with nothing to hide a round trip behind, and in the frame,
-// beside the other stages on a low-priority stream, its 21 us became 40-80 (profiles/r03_n_timeline.txt): four times the waves, a
-// quarter of the candidate rounds each.  And a fragment goes to the target with ONE fire-and-forget atomicMin; rounds 1-3 read the
-// pixel first and skipped the atomic where the fragment was hidden, which saved a third of the atomics and put a load's round trip
-// into every round of the loop.
+// Round 4, measured and NOT adopted (profiles/r04_c_pipeline_ab.txt): RT_RASTER_TPW = 16 triangles per wave instead of 64 (four times the
+// waves, a quarter of the candidate rounds each) and a fire-and-forget atomicMin per fragment instead of a read of the pixel first
+// (RT_RASTER_PREREAD 0).  The kernel is a chain of dependent steps -- indices -> vertices -> set-up -> ~30 candidate pixels per triangle --
+// and alone on the chip it falls from 19-21 us to 8.4-8.9; in the frame its four times as many waves take slots from the main stream's
+// kernels in one burst instead of trickling beside them, and the FRAME gets 2 % slower (1080p 0.1844 -> 0.188 ms, and the pipeline
+// settles into its slower state more often).  The defaults stay at 64 / 1; the variant remains a build option.
 #ifndef RT_RASTER_TPW
-#define RT_RASTER_TPW 16
+#define RT_RASTER_TPW 64
 #endif
 #ifndef RT_RASTER_PREREAD
-#define RT_RASTER_PREREAD 0
+#define RT_RASTER_PREREAD 1
 #endif
 #define RT_SMALL_BOX 1024
 struct __attribute__((aligned(16))) TriSetup {
@@ -271,12 +271,13 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   passRows(fp, ROWS_GBUFFER, rb, re);
   const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
-  // the target was cleared by the previous frame's ray generation -- unless it was not (see clearVisDepth)
-  if (!(c->visClearedFor == c->visDepth && c->visClearedRows[0] <= rb && c->visClearedRows[1] >= re)) {
+  // the target was cleared for this frame by the ray generation two frames back -- unless it was not (see clearVisDepth)
+  auto& vc = c->visClearedAt[c->frameCounter % RT_VIS_RING];
+  if (!(vc.frame == c->frameCounter && vc.rows[0] <= rb && vc.rows[1] >= re)) {
     hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 1023) / 1024), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount, c->splitCount);
     ++c->visStandaloneClears;
   }
-  c->visClearedFor = nullptr;
+  vc.frame = 0u;
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
   FrameParams* const dst = c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot;
   c->slotUploaded = true;

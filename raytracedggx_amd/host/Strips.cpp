@@ -25,15 +25,16 @@ std::pair<uint32_t, uint32_t> StripRows(uint32_t height, int rank, int world, co
   return {(uint32_t)(((uint64_t)rank * height) / world), (uint32_t)(((uint64_t)(rank + 1) * height) / world)};
 }
 
-std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int world, uint32_t minRows) {
+std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int world, uint32_t minRows, double firstExtra) {
   const uint32_t height = (uint32_t)rowCost.size();
   if (height < (uint32_t)world * minRows) throw std::runtime_error(std::to_string(height) + " rows cannot hold " + std::to_string(world) + " strips of at least " + std::to_string(minRows) + " rows");
   std::vector<double> csum(height + 1, 0.0);
   for (uint32_t y = 0; y < height; ++y) csum[y + 1] = csum[y] + rowCost[y];
+  const double share = (csum[height] + firstExtra) / world;
   std::vector<uint32_t> bounds{0};
   for (int k = 1; k < world; ++k) {
-    // first index whose running cost reaches k / world of the total (numpy.searchsorted, side = "left")
-    const double want = csum[height] * k / world;
+    // first index whose running cost reaches k shares less what rank 0 carries besides its rows (numpy.searchsorted, side = "left")
+    const double want = share * k - firstExtra;
     uint32_t b = (uint32_t)(std::lower_bound(csum.begin(), csum.end(), want) - csum.begin());
     b = std::max(b, bounds.back() + minRows);                          // room for this strip ...
     b = std::min(b, height - (uint32_t)(world - k) * minRows);         // ... and for the ones that follow
@@ -41,6 +42,9 @@ std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int wor
   }
   bounds.push_back(height);
   return bounds;
+}
+double GatherCost(uint32_t width, uint32_t height, int world, double rowWeight) {
+  return world > 1 ? rowWeight * width * height * (world - 1) / world : 0.0;
 }
 
 std::vector<Op> ExchangePlan(uint32_t height, int rank, int world, uint32_t apron, const std::vector<uint32_t>* bounds, bool tokens) {
@@ -168,7 +172,7 @@ std::vector<uint32_t> ProfileBounds(RayTracedGGX& app, int world, uint32_t apron
     for (uint32_t x = 0; x < W; ++x) covered += vis[(size_t)y * W + x] != 0u;
     cost[y] = covered + SkyRowWeight * W;
   }
-  return BalancedBounds(cost, world, apron);
+  return BalancedBounds(cost, world, apron, GatherCost(W, H, world));
 }
 
 static std::pair<uint32_t, uint32_t> takeStrip(RayTracedGGX& app, int rank, int world, const std::vector<uint32_t>& bounds, uint32_t apron) {

@@ -23,11 +23,14 @@ namespace strips {
 constexpr uint32_t HistoryApron = 18;     // rows: 1 (the temporal pass also computes rows b-1 and e for the tone map) + 16 px/frame of vertical reprojection + 1 (bilinear footprint)
 constexpr uint32_t ProfileFrames = 2;     // whole frames every rank renders first when it balances the strips itself
 constexpr double SkyRowWeight = 0.5;      // cost of a row = covered pixels + this x width (strips.py SKY_ROW_WEIGHT)
+constexpr double GatherRowWeight = 0.05;  // what a row rank 0 RECEIVES in the gather costs it, x width (strips.py GATHER_ROW_WEIGHT)
 
 // Rows [begin, end) of `rank`: equal strips, or `bounds` (world + 1 ascending row numbers from 0 to height).
 std::pair<uint32_t, uint32_t> StripRows(uint32_t height, int rank, int world, const std::vector<uint32_t>* bounds = nullptr);
-// Boundaries that even out sum(rowCost) per strip; every strip at least minRows rows.  Deterministic: every rank computes the same.
-std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int world, uint32_t minRows = HistoryApron);
+// Boundaries that even out sum(rowCost) per strip; every strip at least minRows rows.  firstExtra: a cost rank 0 carries besides its rows
+// (the gather: GatherCost), so its strip ends where its rows cost that much less than the others'.  Deterministic: every rank computes the same.
+std::vector<uint32_t> BalancedBounds(const std::vector<double>& rowCost, int world, uint32_t minRows = HistoryApron, double firstExtra = 0.0);
+double GatherCost(uint32_t width, uint32_t height, int world, double rowWeight = GatherRowWeight);
 
 enum class Buffer { History /* TemporalSSOut[parity], 8 B/px */, BackBuffer /* 4 B/px */, Token /* words of RTGGX_BUF_EXCHANGE_TOKENS */ };
 struct Op { bool send; Buffer buffer; uint32_t rowBegin, rowEnd; int peer; };      // rows of the frame; for a token: words of the token buffer

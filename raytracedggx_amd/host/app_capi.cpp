@@ -103,9 +103,9 @@ extern "C" int rtggx_host_exchange_plan(uint32_t height, int rank, int world, ui
     return (int)plan.size();
   } catch (const std::exception& e) { g_appError = e.what(); return -1; }
 }
-extern "C" int rtggx_host_balanced_bounds(const double* rowCost, uint32_t height, int world, uint32_t minRows, uint32_t* boundsOut) {
+extern "C" int rtggx_host_balanced_bounds(const double* rowCost, uint32_t height, int world, uint32_t minRows, double firstExtra, uint32_t* boundsOut) {
   try {
-    const std::vector<uint32_t> b = strips::BalancedBounds(std::vector<double>(rowCost, rowCost + height), world, minRows);
+    const std::vector<uint32_t> b = strips::BalancedBounds(std::vector<double>(rowCost, rowCost + height), world, minRows, firstExtra);
     for (size_t i = 0; i < b.size(); ++i) boundsOut[i] = b[i];
     return 0;
   } catch (const std::exception& e) { g_appError = e.what(); return -1; }

@@ -39,23 +39,31 @@ def strip_rows(height, rank, world, bounds=None):
     return (rank * height) // world, ((rank + 1) * height) // world
 
 
-def balanced_bounds(row_cost, world, min_rows=HISTORY_APRON):
+def balanced_bounds(row_cost, world, min_rows=HISTORY_APRON, first_extra=0.0):
     """Strip boundaries that even out sum(row_cost) per strip: boundary k at the row where the running cost passes k/world of
-    the total, every strip at least `min_rows` rows (the history apron must fit).  Deterministic in its inputs: every
-    rank computes the same boundaries from the same profile."""
+    the total, every strip at least `min_rows` rows (the history apron must fit).  first_extra: a cost rank 0 carries besides its
+    rows -- it receives everybody's back-buffer strip (gather_cost) -- so its strip ends where its rows cost that much LESS than the
+    others'.  Deterministic in its inputs: every rank computes the same boundaries from the same profile."""
     cost = np.asarray(row_cost, np.float64)
     height = len(cost)
     if height < world * min_rows:
         raise ValueError("%d rows cannot hold %d strips of at least %d rows" % (height, world, min_rows))
     csum = np.concatenate([[0.0], np.cumsum(cost)])
+    share = (csum[-1] + first_extra) / world
     bounds = [0]
     for k in range(1, world):
-        b = int(np.searchsorted(csum, csum[-1] * k / world, side="left"))
+        b = int(np.searchsorted(csum, share * k - first_extra, side="left"))
         b = max(b, bounds[-1] + min_rows)                       # room for this strip ...
         b = min(b, height - (world - k) * min_rows)             # ... and for the ones that follow
         bounds.append(b)
     bounds.append(height)
     return bounds
+
+
+def gather_cost(width, height, world, row_weight):
+    """What rank 0's gather of the frame weighs in the balance, in the row costs' unit (covered pixels): row_weight x width per row it
+    receives, (world - 1) / world of the frame (StripRenderer.GATHER_ROW_WEIGHT; measured: tools/probes/strip_projection.py)."""
+    return row_weight * width * height * (world - 1) / world if world > 1 else 0.0
 
 
 def exchange_plan(height, rank, world, apron=HISTORY_APRON, bounds=None, tokens=True):
@@ -122,6 +130,9 @@ class StripRenderer:
     # cost of a row = covered pixels + this x width (rows without a surface are not free).  0.3 until the traversal got cheaper relative to
     # the per-pixel passes; 0.5 now: slowest of 8 strips at 4K 0.158 -> 0.145 ms, of 4 at 1080p 0.089 -> 0.085 (profiles/r02_n_strip_projection.txt)
     SKY_ROW_WEIGHT = float(os.environ.get("RTGGX_SKY_ROW_WEIGHT", 0.5))
+    # what a row rank 0 RECEIVES (the gather of the tone-mapped strips) costs it, in the same unit (x width): round 3's projection had rank 0
+    # as the slowest of 8 strips because it gathers (compute 0.058 ms, with its exchange 0.100; profiles/r03_h_strip_projection.txt)
+    GATHER_ROW_WEIGHT = float(os.environ.get("RTGGX_GATHER_ROW_WEIGHT", 0.05))
 
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
                  transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON, peers=True):
@@ -225,7 +236,7 @@ class StripRenderer:
             self.render()
         self.context.sync()
         covered = (self.context.readback(capi.BUF_VISIBILITY) != 0).sum(axis=1)
-        return balanced_bounds(covered + self.SKY_ROW_WEIGHT * self.W, world, min_rows=self.apron)
+        return balanced_bounds(covered + self.SKY_ROW_WEIGHT * self.W, world, min_rows=self.apron, first_extra=gather_cost(self.W, self.H, world, self.GATHER_ROW_WEIGHT))
 
     # -- one frame --------------------------------------------------------------------------------------
     def frame(self):

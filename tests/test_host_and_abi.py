@@ -170,7 +170,7 @@ def test_cpp_strip_plans_equal_the_python_ones(built):
     from raytracedggx_amd import app, strips
     L = app.load()
     L.rtggx_host_exchange_plan.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
-    L.rtggx_host_balanced_bounds.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p]
+    L.rtggx_host_balanced_bounds.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_double, C.c_void_p]
     rng = np.random.default_rng(5)
     def cpp_plan(H, rank, world, apron, bounds):
         ops = np.zeros((64, 5), np.int32)
@@ -181,10 +181,14 @@ def test_cpp_strip_plans_equal_the_python_ones(built):
     for H in (272, 1080, 2160):
         for world in range(2, 9):
             cost = rng.random(H) * 100 + 1
-            want = strips.balanced_bounds(cost, world)
             got = np.zeros(world + 1, np.uint32)
-            assert L.rtggx_host_balanced_bounds(cost.ctypes.data, H, world, strips.HISTORY_APRON, got.ctypes.data) == 0
-            assert got.tolist() == want
+            for extra in (0.0, strips.gather_cost(1920, H, world, 0.05), cost.sum()):      # no gather cost, the default's, an absurd one (rank 0 is left its minimum)
+                want = strips.balanced_bounds(cost, world, first_extra=extra)
+                assert L.rtggx_host_balanced_bounds(cost.ctypes.data, H, world, strips.HISTORY_APRON, extra, got.ctypes.data) == 0
+                assert got.tolist() == want
+                if extra:
+                    assert want[1] <= strips.balanced_bounds(cost, world)[1], "what rank 0 carries besides its rows makes its strip thinner"
+            want = strips.balanced_bounds(cost, world)
             for bounds in (None, want):
                 for apron in (strips.HISTORY_APRON, 30):
                     if any(b1 - b0 < apron for b0, b1 in zip(want[:-1], want[1:])) and bounds is not None:
@@ -194,8 +198,8 @@ def test_cpp_strip_plans_equal_the_python_ones(built):
     # all the cost in one row: the minimum strip height decides
     cost = np.zeros(360); cost[200] = 1.0
     got = np.zeros(7, np.uint32)
-    assert L.rtggx_host_balanced_bounds(cost.ctypes.data, 360, 6, 18, got.ctypes.data) == 0 and got.tolist() == strips.balanced_bounds(cost, 6)
-    assert L.rtggx_host_balanced_bounds(cost.ctypes.data, 100, 6, 18, got.ctypes.data) == -1 and b"cannot hold" in L.rtggx_app_last_error()
+    assert L.rtggx_host_balanced_bounds(cost.ctypes.data, 360, 6, 18, 0.0, got.ctypes.data) == 0 and got.tolist() == strips.balanced_bounds(cost, 6)
+    assert L.rtggx_host_balanced_bounds(cost.ctypes.data, 100, 6, 18, 0.0, got.ctypes.data) == -1 and b"cannot hold" in L.rtggx_app_last_error()
     with pytest.raises(ValueError):
         strips.balanced_bounds(cost[:100], 6)
 
