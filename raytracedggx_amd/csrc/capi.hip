@@ -13,6 +13,9 @@
 #ifndef RT_REFIT_REBUILD_RATIO
 #define RT_REFIT_REBUILD_RATIO 1.2f      // a refitted tree whose cost has grown by this factor since its build is rebuilt (rtggx_refit_as)
 #endif
+// The events that order the streams of one context among each other, and the frames-in-flight fence.  (Measured in round 4: with
+// hipEventReleaseToDevice the 1080p frame gets SLOWER, 0.184 -> 0.191-0.197 ms; hipEventDisableSystemFence changes nothing.)
+#define RT_EVENT_FLAGS (hipEventDisableTiming)
 #ifndef RT_REBUILD_STEPS
 #define RT_REBUILD_STEPS 16u             // launches of such a rebuild issued per frame (the bunny's build is ~75: five frames)
 #endif
@@ -187,15 +190,15 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
   c->streamMain = c->ownMain; c->streamAS = c->ownAS;
   c->attachEvents = !(getenv("RTGGX_ATTACH_EVENTS") && atoi(getenv("RTGGX_ATTACH_EVENTS")) == 0);      // 0: marker packets (hipEventRecord) instead of events riding on kernels
   RT_HIP(hipStreamCreateWithPriority(&c->ownVis, hipStreamNonBlocking, prioLeast)); c->streamVis = c->ownVis;
-  RT_HIP(hipEventCreateWithFlags(&c->evVis, hipEventDisableTiming));
-  RT_HIP(hipEventCreateWithFlags(&c->evRefit, hipEventDisableTiming));
-  for (auto& e : c->evGenRing) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto& e : c->evTraceRing) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&c->evVis, RT_EVENT_FLAGS));
+  RT_HIP(hipEventCreateWithFlags(&c->evRefit, RT_EVENT_FLAGS));
+  for (auto& e : c->evGenRing) RT_HIP(hipEventCreateWithFlags(&e, RT_EVENT_FLAGS));
+  for (auto& e : c->evTraceRing) RT_HIP(hipEventCreateWithFlags(&e, RT_EVENT_FLAGS));
   RT_HIP(hipStreamCreateWithPriority(&c->streamRefit, hipStreamNonBlocking, prioMid));
   c->rebuildRatio = RT_REFIT_REBUILD_RATIO; c->rebuildSteps = RT_REBUILD_STEPS;      // rtggx_set_refit_policy
-  RT_HIP(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
-  RT_HIP(hipEventCreateWithFlags(&c->evRT, hipEventDisableTiming));
-  for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&c->evAS, RT_EVENT_FLAGS));
+  RT_HIP(hipEventCreateWithFlags(&c->evRT, RT_EVENT_FLAGS));
+  for (auto& e : c->evSetRead) RT_HIP(hipEventCreateWithFlags(&e, RT_EVENT_FLAGS));
   for (auto& e : c->tev) RT_HIP(hipEventCreate(&e));
   for (int i = 0; i < RT_SETS; ++i) {
     RT_HIP(hipMalloc(&c->normalBuf[i], n * 4)); RT_HIP(hipMemset(c->normalBuf[i], 0, n * 4));

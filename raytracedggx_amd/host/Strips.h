@@ -23,7 +23,7 @@ namespace strips {
 constexpr uint32_t HistoryApron = 18;     // rows: 1 (the temporal pass also computes rows b-1 and e for the tone map) + 16 px/frame of vertical reprojection + 1 (bilinear footprint)
 constexpr uint32_t ProfileFrames = 2;     // whole frames every rank renders first when it balances the strips itself
 constexpr double SkyRowWeight = 0.5;      // cost of a row = covered pixels + this x width (strips.py SKY_ROW_WEIGHT)
-constexpr double GatherRowWeight = 0.05;  // what a row rank 0 RECEIVES in the gather costs it, x width (strips.py GATHER_ROW_WEIGHT)
+constexpr double GatherRowWeight = 0.02;  // what a row rank 0 RECEIVES in the gather costs it, x width (strips.py GATHER_ROW_WEIGHT)
 
 // Rows [begin, end) of `rank`: equal strips, or `bounds` (world + 1 ascending row numbers from 0 to height).
 std::pair<uint32_t, uint32_t> StripRows(uint32_t height, int rank, int world, const std::vector<uint32_t>* bounds = nullptr);

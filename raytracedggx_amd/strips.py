@@ -132,7 +132,7 @@ class StripRenderer:
     SKY_ROW_WEIGHT = float(os.environ.get("RTGGX_SKY_ROW_WEIGHT", 0.5))
     # what a row rank 0 RECEIVES (the gather of the tone-mapped strips) costs it, in the same unit (x width): round 3's projection had rank 0
     # as the slowest of 8 strips because it gathers (compute 0.058 ms, with its exchange 0.100; profiles/r03_h_strip_projection.txt)
-    GATHER_ROW_WEIGHT = float(os.environ.get("RTGGX_GATHER_ROW_WEIGHT", 0.05))
+    GATHER_ROW_WEIGHT = float(os.environ.get("RTGGX_GATHER_ROW_WEIGHT", 0.02))
 
     def __init__(self, width, height, mesh_path, env_path, rank=0, world=1, device=0, dist=None, pos_scale=None, extra_args=(),
                  transport=None, torch_buffers=None, balance=False, apron=HISTORY_APRON, peers=True):

@@ -182,7 +182,7 @@ def test_cpp_strip_plans_equal_the_python_ones(built):
         for world in range(2, 9):
             cost = rng.random(H) * 100 + 1
             got = np.zeros(world + 1, np.uint32)
-            for extra in (0.0, strips.gather_cost(1920, H, world, 0.05), cost.sum()):      # no gather cost, the default's, an absurd one (rank 0 is left its minimum)
+            for extra in (0.0, strips.gather_cost(1920, H, world, 0.02), cost.sum()):      # no gather cost, the default's, an absurd one (rank 0 is left its minimum)
                 want = strips.balanced_bounds(cost, world, first_extra=extra)
                 assert L.rtggx_host_balanced_bounds(cost.ctypes.data, H, world, strips.HISTORY_APRON, extra, got.ctypes.data) == 0
                 assert got.tolist() == want
