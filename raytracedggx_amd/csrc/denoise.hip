@@ -17,6 +17,7 @@
 // are VALU-bound (33 taps per covered pixel); their HBM traffic (22-30 B/pixel/pass) is ~5% of the
 // time.  Out-of-range texels are the zeros D3D returns.
 #include <cstring>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include "rtggx_context.h"
 
@@ -103,7 +104,11 @@ RT_DEV float log2OfDot(float I) {          // log2(max(I / 1023^2, 0))
   const float dropped = (1.0f - xr) + d;
   return __builtin_fmaf(dropped, RT_LOG2E, __builtin_amdgcn_logf(xr));      // (x = 0: -inf, the weight 0)
 }
-template <bool DIFFUSE>
+// UNIFORM (round 4; the tiled kernels decide it per workgroup while they stage their tile): 1 -- every texel of the tile that has a
+// surface has the centre's roughness, so the roughness weight is 1 for every tap that counts (a tap without a surface is multiplied by
+// its zero flag whatever that weight would be) and its seven operations are left out; 2 -- and every texel has a surface: the flag is
+// left out as well.  Same bits (x 1.0 is exact); most tiles inside the model or the ground are such tiles.
+template <bool DIFFUSE, int UNIFORM = 0>
 RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, float depth, float rough) {
 #pragma clang fp contract(fast)
   const float I = __builtin_fmaf(c.nz, nz, __builtin_fmaf(c.ny, ny, c.nx * nx));      // exact: integers below 2^24
@@ -112,9 +117,12 @@ RT_DEV float tapWeight(const Centre& c, int i, float nx, float ny, float nz, flo
   if (DIFFUSE) return __builtin_amdgcn_exp2f(__builtin_fmaf(32.0f, lg, -dd));
   const float pw = 512.0f * lg;
   const float e = __builtin_fmaf(c.gaussK, (float)(i * i), -dd);
-  const float t = saturatef(fabsf(fabsf(rough) - c.rough) * 2.0f);
+  const float w = __builtin_amdgcn_exp2f(pw >= 128.0f ? pw : pw + e);
+  if (UNIFORM == 2) return w;
   const float flag = (__float_as_uint(rough) >> 31) ? 0.0f : 1.0f;          // sign bit set: norm.w <= 0
-  return (__builtin_amdgcn_exp2f(pw >= 128.0f ? pw : pw + e) * (1.0f - t * t * (3.0f - 2.0f * t))) * flag;
+  if (UNIFORM == 1) return w * flag;
+  const float t = saturatef(fabsf(fabsf(rough) - c.rough) * 2.0f);
+  return (w * (1.0f - t * t * (3.0f - 2.0f * t))) * flag;
 }
 template <bool DIFFUSE>
 RT_DEV Centre makeCentre(float nx, float ny, float nz, float depth, float rough, int W, int H) {
@@ -188,6 +196,8 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
   constexpr int PER = vertical ? BW * BH / 256 : 1, ROWSTEP = 256 / BW;           // pixels per thread, their row distance
   constexpr int N = TW * TH;
   __shared__ float sm[8][N];                                          // nx ny nz depth rough r g b
+  __shared__ uint32_t roughLo, roughHi, unflagged;                    // over the tile: least / greatest roughness of the texels with a surface, texels without one
+  if (threadIdx.x == 0) { roughLo = 0xFFFFFFFFu; roughHi = 0u; unflagged = 0u; }
   const int bx0 = blockIdx.x * BW, by0 = T.rowBegin + blockIdx.y * BH;
   const int lx = threadIdx.x % BW, ly = threadIdx.x / BW;
   const int x = bx0 + lx;
@@ -208,6 +218,7 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
 
   // stage the tile
   const int ox = vertical ? bx0 : bx0 - RT_RADIUS, oy = vertical ? by0 - RT_RADIUS : by0;
+  uint32_t myLo = 0xFFFFFFFFu, myHi = 0u, myUnflagged = 0u;
   for (int t = threadIdx.x; t < N; t += 256) {
     const int tx = ox + t % TW, ty = oy + t / TW;
     float v[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -221,36 +232,49 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
       }
     } else {
       v[0] = g.nx; v[1] = g.ny; v[2] = g.nz;
-      if (g.nw <= 0.0f) v[4] = __uint_as_float(__float_as_uint(g.rough) | 0x80000000u);
+      if (g.nw <= 0.0f) { v[4] = __uint_as_float(__float_as_uint(g.rough) | 0x80000000u); myUnflagged = 1u; }
+      else { myLo = min(myLo, __float_as_uint(g.rough)); myHi = max(myHi, __float_as_uint(g.rough)); }
       if (inside) { const f3 src = tapColour<MODE>(T, (size_t)ty * T.W + tx); v[5] = src.x; v[6] = src.y; v[7] = src.z; }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) sm[q][t] = v[q];
   }
-  __syncthreads();
-
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    if (!todo[k]) continue;
-    const int y = by0 + ly + k * ROWSTEP;
-    const int ci = vertical ? (ly + k * ROWSTEP + RT_RADIUS) * TW + lx : ly * TW + lx + RT_RADIUS;
-    const Centre c = makeCentre<diffuse>(sm[0][ci], sm[1][ci], sm[2][ci], sm[3][ci], sm[4][ci], T.W, T.H);
-    float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
-    // one LDS address per channel (the first tap's), held in a register: the 33 taps are then immediate offsets of the
-    // ds_read instructions instead of an address computation each
-    typedef __attribute__((address_space(3))) const float LdsFloat;
-    LdsFloat* ch[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ch[q] = (LdsFloat*)&sm[q][ci - RT_RADIUS * (vertical ? TW : 1)]; asm volatile("" : "+v"(ch[q])); }
-#pragma unroll
-    for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
-      const int ti = (i + RT_RADIUS) * (vertical ? TW : 1);
-      const float w = tapWeight<diffuse>(c, i, ch[0][ti], ch[1][ti], ch[2][ti], ch[3][ti], ch[4][ti]);
-      mx = __builtin_fmaf(ch[5][ti], w, mx); my = __builtin_fmaf(ch[6][ti], w, my); mz = __builtin_fmaf(ch[7][ti], w, mz);
-      wsum += w;
-    }
-    storeFiltered<MODE>(T, (size_t)y * T.W + x, mx, my, mz, wsum);
+  if (!diffuse) {      // one LDS atomic per wave and fact
+    for (int o = 32; o > 0; o >>= 1) { myLo = min(myLo, (uint32_t)__shfl_down((int)myLo, o)); myHi = max(myHi, (uint32_t)__shfl_down((int)myHi, o)); }
+    const unsigned long long anyUnflagged = __ballot(myUnflagged != 0u);
+    if ((threadIdx.x & 63) == 0) { atomicMin(&roughLo, myLo); atomicMax(&roughHi, myHi); if (anyUnflagged) atomicOr(&unflagged, 1u); }
   }
+  __syncthreads();
+  const int uniform = diffuse ? 0 : (roughLo != roughHi ? 0 : unflagged ? 1 : 2);      // (the same for the whole workgroup: see tapWeight)
+
+  auto filter = [&](auto uniformTag) {
+    constexpr int UNIFORM = decltype(uniformTag)::value;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (!todo[k]) continue;
+      const int y = by0 + ly + k * ROWSTEP;
+      const int ci = vertical ? (ly + k * ROWSTEP + RT_RADIUS) * TW + lx : ly * TW + lx + RT_RADIUS;
+      const Centre c = makeCentre<diffuse>(sm[0][ci], sm[1][ci], sm[2][ci], sm[3][ci], sm[4][ci], T.W, T.H);
+      float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
+      // one LDS address per channel (the first tap's), held in a register: the 33 taps are then immediate offsets of the
+      // ds_read instructions instead of an address computation each
+      typedef __attribute__((address_space(3))) const float LdsFloat;
+      LdsFloat* ch[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { ch[q] = (LdsFloat*)&sm[q][ci - RT_RADIUS * (vertical ? TW : 1)]; asm volatile("" : "+v"(ch[q])); }
+#pragma unroll
+      for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
+        const int ti = (i + RT_RADIUS) * (vertical ? TW : 1);
+        const float w = tapWeight<diffuse, UNIFORM>(c, i, ch[0][ti], ch[1][ti], ch[2][ti], ch[3][ti], UNIFORM == 2 ? 0.0f : ch[4][ti]);
+        mx = __builtin_fmaf(ch[5][ti], w, mx); my = __builtin_fmaf(ch[6][ti], w, my); mz = __builtin_fmaf(ch[7][ti], w, mz);
+        wsum += w;
+      }
+      storeFiltered<MODE>(T, (size_t)y * T.W + x, mx, my, mz, wsum);
+    }
+  };
+  if (uniform == 2) filter(std::integral_constant<int, 2>{});
+  else if (uniform == 1) filter(std::integral_constant<int, 1>{});
+  else filter(std::integral_constant<int, 0>{});
 }
 
 // ---- CSTemporalSS.hlsl --------------------------------------------------------------------------------

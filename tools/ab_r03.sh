@@ -5,8 +5,8 @@ mkdir -p gpurun_out/r04
 for i in $(seq $rounds); do
   for t in "$@"; do
     name=$(echo $t | tr '/. ' '___')
-    if [ "$t" = "." ]; then python bench.py --no-cpu-baseline --two-kernel-tone-map 2>/dev/null | grep '^{' >> gpurun_out/r04/${tag}_new_two.jsonl
-    elif [ "$t" = ".fused" ]; then python bench.py --no-cpu-baseline 2>/dev/null | grep '^{' >> gpurun_out/r04/${tag}_new_fused.jsonl
+    if [ "$t" = "." ]; then python bench.py --no-cpu-baseline 2>/dev/null | grep "^{" >> gpurun_out/r04/${tag}_new.jsonl
+    elif [ "$t" = ".fused" ]; then python bench.py --no-cpu-baseline --tone-map fused 2>/dev/null | grep "^{" >> gpurun_out/r04/${tag}_new_fused.jsonl
     else (cd _ab/$t && python bench.py --no-cpu-baseline 2>/dev/null | grep '^{') >> gpurun_out/r04/${tag}_$name.jsonl; fi
   done
 done
