@@ -209,6 +209,11 @@ int  rtggx_build_as(rtggx_context* ctx);
  * rtggx_refit_stats: cost of the current tree relative to the last
  * build, refits and rebuilds so far; synchronises (a rebuild in progress stays in progress). */
 int  rtggx_refit_as(rtggx_context* ctx, uint32_t slot, const float* verts, uint32_t num_verts);
+/* The same for a mesh animated ON the GPU (round 4): `device_verts` is a device pointer, `hip_stream` the stream that produces it (NULL: the
+ * null stream).  Like a hipMemcpyAsync on that stream: the copy out of `device_verts` is ordered behind everything the stream holds at the
+ * time of the call, and what the caller enqueues there afterwards (the next animation step) behind the copy; it runs on the context's
+ * geometry stream into a device-side staging ring -- no host copy, no wait. */
+int  rtggx_refit_as_device(rtggx_context* ctx, uint32_t slot, const float* device_verts, uint32_t num_verts, void* hip_stream);
 int  rtggx_set_refit_policy(rtggx_context* ctx, float rebuild_ratio, uint32_t steps_per_frame);
 int  rtggx_refit_stats(rtggx_context* ctx, uint32_t slot, float* cost_ratio, uint32_t* refits, uint32_t* rebuilds);
 

@@ -31,7 +31,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream", "rtggx_set_history_peers", "rtggx_history_ipc_export", "rtggx_history_ipc_open",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_fuse_tone_map", "rtggx_debug_placement", "rtggx_debug_collapse_weights", "rtggx_debug_fence_wait", "rtggx_debug_shader_clock"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_as_device", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_fuse_tone_map", "rtggx_debug_placement", "rtggx_debug_collapse_weights", "rtggx_debug_fence_wait", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -162,6 +162,11 @@ class Context:
         """New vertex positions / normals for an unchanged topology: staged now, uploaded and refitted on stream B by the next frame."""
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 6)
         self._check(self.L.rtggx_refit_as(self.h, slot, _p(v), v.shape[0]))
+
+    def refit_as_device(self, slot, device_ptr, num_verts, stream=0):
+        """New vertices from DEVICE memory (a mesh animated on the GPU): ordered on `stream` like a hipMemcpyAsync out of the buffer."""
+        self.L.rtggx_refit_as_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        self._check(self.L.rtggx_refit_as_device(self.h, slot, C.c_void_p(int(device_ptr)), int(num_verts), C.c_void_p(int(stream) or None)))
 
     def fence_wait(self, reset=True):
         """(us the host has waited at the frames-in-flight fence, frames that waited) since the last reset (diagnostic)."""

@@ -91,6 +91,8 @@ struct MeshDev {
   bool deforming = false;
   float* stage[RT_SLOTS] = {};   // pinned host staging ring for the vertices handed to rtggx_refit_as
   uint32_t stageNext = 0; int pendingStage = -1;
+  float* deviceStage[RT_SLOTS] = {};   // device-side staging ring of rtggx_refit_as_device; the events that order it against the caller's stream
+  uint32_t deviceStageNext = 0; int pendingDeviceStage = -1; hipEvent_t evProduced = nullptr, evStaged = nullptr;
   // what a build derives from one vertex shape and a refit keeps: `topo` (BvhTopo above); `job`: a build in progress (lbvh.hip BuildJob)
   BvhTopo topo;
   struct BuildJob* job = nullptr;

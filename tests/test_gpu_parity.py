@@ -1492,3 +1492,39 @@ def test_deforming_mesh_free_running_equals_synchronised(built):
         assert (va != vc).mean() < 2e-3, "-deform renders the same animation (%.4f%% of the visibility words differ)" % (100 * (va != vc).mean())
     finally:
         a.OnDestroy(); b.OnDestroy(); c.OnDestroy()
+
+
+def test_deforming_mesh_from_device_memory(built):
+    """rtggx_refit_as_device (round 4): the vertices of a mesh animated ON the GPU, handed over as a device pointer with the stream that
+    produces them.  A torch stream writes each frame's shape into ONE buffer, hands it over, and overwrites the buffer with garbage right
+    behind the call -- as the next animation step would: 24 free-running frames against 24 synchronised frames that got the same shapes
+    from host memory (rtggx_refit_as), every target and the model's tree bit-identical.  (The call orders its copy out of the buffer like
+    a hipMemcpyAsync on the producer's stream: behind what the stream held, in front of what it is given next.)"""
+    import torch
+    from raytracedggx_amd import app, capi
+    args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", 640, "-height", 360, "-sharedmem", "-metallic", 1.0, 0.5]
+    a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+    try:
+        v0, idx, _ = app.obj_import(assets.path("bunny.obj"))
+        shapes = [np.ascontiguousarray(_wave(v0, f), np.float32) for f in range(8)]
+        on_gpu = [torch.from_numpy(s).cuda() for s in shapes]
+        producer = torch.cuda.Stream()
+        buf = torch.empty_like(on_gpu[0])
+        for x in (a, b):
+            x.context.set_refit_policy(4.0, 16)      # (no rebuild: when its topology takes over depends on timing)
+        for f in range(24):
+            a.context.refit_as(1, shapes[f % 8]); a.OnUpdate(); a.OnRender(); a.context.sync()
+            with torch.cuda.stream(producer):
+                buf.copy_(on_gpu[f % 8], non_blocking=True)
+                b.context.refit_as_device(1, buf.data_ptr(), buf.shape[0], producer.cuda_stream)
+                buf.fill_(float("nan"))           # the buffer is the producer's again at once
+            b.OnUpdate(); b.OnRender()
+        b.context.sync(); torch.cuda.synchronize()
+        for bid in (capi.BUF_VISIBILITY, capi.BUF_DEPTH, capi.BUF_NORMAL, capi.BUF_VELOCITY, capi.BUF_RT_REFL, capi.BUF_RT_DIFF,
+                    capi.BUF_FLT_DFF, capi.BUF_TSS0, capi.BUF_TSS1, capi.BUF_BACKBUFFER, capi.BUF_BVH4_NODES1, capi.BUF_BVH_TRIS1):
+            np.testing.assert_array_equal(a.context.readback(bid), b.context.readback(bid), err_msg="buffer %d" % bid)
+        assert b.context.refit_stats(1)["refits"] == 24
+        with pytest.raises(capi.RtggxError):
+            b.context.refit_as_device(1, buf.data_ptr(), buf.shape[0] - 1)
+    finally:
+        a.OnDestroy(); b.OnDestroy()
