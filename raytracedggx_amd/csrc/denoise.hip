@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(256) spatialDirectKernel(Targets T) {
 
 // Shared-memory variant.  Block geometry: H passes 64x4 pixels (one per thread), tile 96x4; V passes RT_VBW x RT_VBH
 // pixels (thread (lx, ly) filters rows ly, ly + 256/RT_VBW, ... of column lx), tile RT_VBW x (RT_VBH + 32).
+typedef float V4 __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
   constexpr bool vertical = (MODE & 1) != 0;
@@ -195,7 +196,10 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
   constexpr int TW = vertical ? RT_VBW : 96, TH = vertical ? RT_VBH + 2 * RT_RADIUS : 4;      // texels of the tile
   constexpr int PER = vertical ? BW * BH / 256 : 1, ROWSTEP = 256 / BW;           // pixels per thread, their row distance
   constexpr int N = TW * TH;
-  __shared__ float sm[8][N];                                          // nx ny nz depth rough r g b
+  // Two 16-byte words per texel, texel after texel: a tap is two ds_read_b128 -- 256 bytes per clock and CU, where the eight ds_read_b32 of a
+  // field-major tile get 128 (MI355X_MICROARCH.md, LDS) and, at 16 LDS cycles per tap and wave against ~13 cycles of vector issue, set the
+  // pace of the tap loop.  Consecutive lanes read consecutive texels in both passes: conflict-free.
+  __shared__ V4 smA[N], smB[N];                                       // nx ny nz depth | rough r g b
   __shared__ uint32_t roughLo, roughHi, unflagged;                    // over the tile: least / greatest roughness of the texels with a surface, texels without one
   if (threadIdx.x == 0) { roughLo = 0xFFFFFFFFu; roughHi = 0u; unflagged = 0u; }
   const int bx0 = blockIdx.x * BW, by0 = T.rowBegin + blockIdx.y * BH;
@@ -236,8 +240,7 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
       else { myLo = min(myLo, __float_as_uint(g.rough)); myHi = max(myHi, __float_as_uint(g.rough)); }
       if (inside) { const f3 src = tapColour<MODE>(T, (size_t)ty * T.W + tx); v[5] = src.x; v[6] = src.y; v[7] = src.z; }
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sm[q][t] = v[q];
+    smA[t] = V4{v[0], v[1], v[2], v[3]}; smB[t] = V4{v[4], v[5], v[6], v[7]};
   }
   if (!diffuse) {      // one LDS atomic per wave and fact
     for (int o = 32; o > 0; o >>= 1) { myLo = min(myLo, (uint32_t)__shfl_down((int)myLo, o)); myHi = max(myHi, (uint32_t)__shfl_down((int)myHi, o)); }
@@ -254,19 +257,20 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
       if (!todo[k]) continue;
       const int y = by0 + ly + k * ROWSTEP;
       const int ci = vertical ? (ly + k * ROWSTEP + RT_RADIUS) * TW + lx : ly * TW + lx + RT_RADIUS;
-      const Centre c = makeCentre<diffuse>(sm[0][ci], sm[1][ci], sm[2][ci], sm[3][ci], sm[4][ci], T.W, T.H);
+      const V4 ca = smA[ci];
+      const Centre c = makeCentre<diffuse>(ca.x, ca.y, ca.z, ca.w, smB[ci].x, T.W, T.H);
       float mx = 0.0f, my = 0.0f, mz = 0.0f, wsum = 0.0f;
-      // one LDS address per channel (the first tap's), held in a register: the 33 taps are then immediate offsets of the
+      // one LDS address per word (the first tap's), held in a register: the 33 taps are then immediate offsets of the
       // ds_read instructions instead of an address computation each
-      typedef __attribute__((address_space(3))) const float LdsFloat;
-      LdsFloat* ch[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { ch[q] = (LdsFloat*)&sm[q][ci - RT_RADIUS * (vertical ? TW : 1)]; asm volatile("" : "+v"(ch[q])); }
+      typedef __attribute__((address_space(3))) const V4 LdsV4;
+      LdsV4* pa = (LdsV4*)&smA[ci - RT_RADIUS * (vertical ? TW : 1)]; LdsV4* pb = (LdsV4*)&smB[ci - RT_RADIUS * (vertical ? TW : 1)];
+      asm volatile("" : "+v"(pa)); asm volatile("" : "+v"(pb));
 #pragma unroll
       for (int i = -RT_RADIUS; i <= RT_RADIUS; ++i) {
         const int ti = (i + RT_RADIUS) * (vertical ? TW : 1);
-        const float w = tapWeight<diffuse, UNIFORM>(c, i, ch[0][ti], ch[1][ti], ch[2][ti], ch[3][ti], UNIFORM == 2 ? 0.0f : ch[4][ti]);
-        mx = __builtin_fmaf(ch[5][ti], w, mx); my = __builtin_fmaf(ch[6][ti], w, my); mz = __builtin_fmaf(ch[7][ti], w, mz);
+        const V4 a = pa[ti], b = pb[ti];
+        const float w = tapWeight<diffuse, UNIFORM>(c, i, a.x, a.y, a.z, a.w, b.x);
+        mx = __builtin_fmaf(b.y, w, mx); my = __builtin_fmaf(b.z, w, my); mz = __builtin_fmaf(b.w, w, mz);
         wsum += w;
       }
       storeFiltered<MODE>(T, (size_t)y * T.W + x, mx, my, mz, wsum);
