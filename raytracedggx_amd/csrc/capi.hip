@@ -212,6 +212,9 @@ int rtggx_create(rtggx_context** out, uint32_t width, uint32_t height, int devic
     RT_HIP(hipMalloc(&c->roughMetalBuf[i], n * 2)); RT_HIP(hipMemset(c->roughMetalBuf[i], 0, n * 2));
   }
   for (auto& b : c->visDepthBuf) { RT_HIP(hipMalloc(&b, n * 8)); RT_HIP(hipMemset(b, 0, n * 8)); }
+  { const size_t tiles = (size_t)((width + 15) / 16) * ((height + 15) / 16 + 1);      // (+ a row: a strip's tiles start at its first row)
+    for (auto& b : c->visDirtyBuf) { RT_HIP(hipMalloc(&b, tiles * 4)); RT_HIP(hipMemset(b, 0xFF, tiles * 4)); }
+    RT_HIP(hipMalloc(&c->visDirtyOnes, tiles * 4)); RT_HIP(hipMemset(c->visDirtyOnes, 0xFF, tiles * 4)); }
   c->selectSet(0);
   RT_HIP(hipMalloc(&c->backbuffer, n * 4));
   RT_HIP(hipMalloc(&c->tss[0], n * 8)); RT_HIP(hipMalloc(&c->tss[1], n * 8)); RT_HIP(hipMalloc(&c->fltRfl, n * 8)); RT_HIP(hipMalloc(&c->fltDff, n * 8));
@@ -289,6 +292,8 @@ void rtggx_destroy(rtggx_context* c) {
   }
   hipFree(c->env.texels); hipFree(c->sh); hipFree(c->cosSinTab); hipFree(c->backbuffer);
   for (auto b : c->visDepthBuf) hipFree(b);
+  for (auto b : c->visDirtyBuf) hipFree(b);
+  hipFree(c->visDirtyOnes);
   for (int i = 0; i < RT_SETS; ++i) { hipFree(c->depth32Buf[i]); hipFree(c->normalBuf[i]); hipFree(c->velocityBuf[i]); hipFree(c->rtReflBuf[i]); hipFree(c->rtDiffBuf[i]); hipFree(c->roughMetalBuf[i]); }
   hipFree(c->tss[0]); hipFree(c->tss[1]);
   hipFree(c->fltRfl); hipFree(c->fltDff); hipFree(c->largeTrisBuf[0]); hipFree(c->largeTrisBuf[1]); hipFree(c->largeCountBase); hipFree(c->rayCounter); hipFree(c->dParams); hipFree(c->dScene);

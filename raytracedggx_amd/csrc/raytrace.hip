@@ -226,6 +226,10 @@ struct GenArgs {
   // front of every wave's first dependent fetch: rayGenKernel 85 -> 169 us per launch, the 1080p frame 0.190 -> 0.243 ms, 4K 0.715 ->
   // 0.980; with the records in LDS no different.  profiles/r03_b_visibility_merge.txt)
   unsigned long long* visNext; uint32_t* zeroNext0; uint32_t* zeroNext1;
+  // one word per tile of this kernel (rtggx_context.h visDirtyBuf): 0 = the tile of the target holds the clear value only.  visDirty: of the
+  // target read here; visDirtyNext: of visNext; where the words are not known both point at words that are all ones (read / clear every
+  // tile).  The words of visNext's tiles end as 0 (visDirtyNextOut: the target's own words)
+  const uint32_t* visDirty; const uint32_t* visDirtyNext; uint32_t* visDirtyNextOut;
   uint32_t* normalOut; uint16_t* roughMetalOut; uint32_t* velocityOut; uint32_t* reflOut; uint32_t* diffOut;
   const uint16_t* roughMetalPrev;   // the previous frame's input set = what this target held before this frame
   const uint32_t* diffPrev;         // likewise RayTracingOut1, or null: the hit shading carries it over (launchShade)
@@ -252,6 +256,11 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
   const uint32_t px = (tile % A.tilesX) * 16 + (wave & 1u) * 8 + (lane & 7u);
   const uint32_t py = A.rowBegin + (tile / A.tilesX) * 16 + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < fp.W && py < A.rowEnd;
+  // (two scalar loads, one wait: as two vector loads in front of the kernel's first fetch they cost ray generation 10 us in the frame)
+  uint32_t wordHere, wordNext;
+  asm volatile("s_load_dword %0, %2, %4\n\ts_load_dword %1, %3, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(wordHere), "=&s"(wordNext) : "s"(A.visDirty), "s"(A.visDirtyNext), "s"(tile * 4u) : "memory");
+  const bool drawn = wordHere != 0u;                                    // uniform over the workgroup
+  const bool clearNext = A.visNext != nullptr && wordNext != 0u;
   const EnvRef env{A.env, A.envSize, A.envMips, A.envMipOffset};
   bool wantRefl = false, wantDiff = false;
   RayRec rr, rd;
@@ -259,8 +268,8 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
     const uint32_t W = fp.W, H = fp.H;
     const size_t pix = (size_t)py * W + px;
     // getPrimarySurface :277-333
-    const unsigned long long visWord = A.visDepth[pix];
-    if (A.visNext != nullptr) A.visNext[pix] = RT_VIS_CLEAR;
+    const unsigned long long visWord = drawn ? A.visDepth[pix] : RT_VIS_CLEAR;
+    if (clearNext) A.visNext[pix] = RT_VIS_CLEAR;
     uint32_t visibility = (uint32_t)visWord;
     A.depthOut[pix] = (uint32_t)(visWord >> 32);      // the filters read depth four bytes at a time instead of every other word of an 8-byte array
     f2 screenPos; screenPos.x = ((float)px + 0.5f) / (float)W * 2.0f - 1.0f; screenPos.y = ((float)py + 0.5f) / (float)H * 2.0f - 1.0f;
@@ -361,6 +370,8 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
       } else if (A.diffPrev != nullptr) A.diffOut[pix] = A.diffPrev[pix];      // RayTracingOut1 keeps what it held: carried over from the previous frame's set, here or by shadeKernel (launchShade)
     }
   }
+  if (clearNext && threadIdx.x == 0) A.visDirtyNextOut[tile] = 0u;      // (read above by this workgroup only)
+
   // wave-level compaction into this wave's own bin (rt_queue.h): reflection rays first, then diffuse rays
   const uint32_t bin = blockIdx.x * 4u + wave;
   const unsigned long long maskR = __ballot(wantRefl), maskD = __ballot(wantDiff), below = (1ull << lane) - 1ull;
@@ -436,7 +447,12 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) shadeKernel(const Fram
   const FrameParams& fp = *fpp;
   const EnvRef env{A.env, A.envSize, A.envMips, A.envMipOffset};
   // workgroup b shades the four bins its rayGen namesake filled: wave w <-> bin 4b + w
-  const uint32_t bin = blockIdx.x * 4u + (threadIdx.x >> 6);
+  // (Round 4, measured and dropped: a LIST of the bins -- or tiles -- with a surface, appended by ray generation, walked here by a grid of
+  // eight workgroups per CU, instead of three quarters of this kernel's waves reading a zero and leaving.  One atomic per wave with a
+  // surface, ~8 000 per frame on one word, runs at the memory side of eight L2s: ray generation 80 -> 155 us in the frame, the frame
+  // 0.185 -> 0.266 ms; one per tile behind a workgroup barrier: ray generation 80 -> 91 us, the frame +1.3 %.  profiles/r04_j_tile_words.txt)
+  const uint32_t tile = blockIdx.x;
+  const uint32_t bin = tile * 4u + (threadIdx.x >> 6);
   // Carry-over of RayTracingOut1.  The reference has ONE such texture and leaves it untouched where no diffuse ray is traced
   // (covered pixels of a fully metallic instance, RayTracing.hlsl:559): it keeps the last value ever written there.  With three
   // input sets that is the word of the previous frame's set -- final only once that frame's shading has run, which is earlier
@@ -444,8 +460,8 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) shadeKernel(const Fram
   // sub-tile, so it walks those pixels: covered by an instance with metallic >= 1 (carryMask bit per instance) -> copy.
   if (A.carryMask != 0u) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t px = (blockIdx.x % A.tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t py = A.rowBegin + (blockIdx.x / A.tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t px = (tile % A.tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = A.rowBegin + (tile / A.tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
     if (px < fp.W && py < A.rowEnd) {
       const size_t pix = (size_t)py * fp.W + px;
       const uint32_t vis = (uint32_t)A.visDepth[pix];
@@ -515,7 +531,15 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
   // (the list by frame parity: the one this frame's visibility pass has just used up), and the next set's split list
   { const uint32_t thenFrame = c->frameCounter + 2u, nextSet = (c->setIndex + 1u) % RT_SETS;
     G.visNext = c->visDepthBuf[thenFrame % RT_VIS_RING]; G.zeroNext0 = c->largeCountBase + (thenFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
-    auto& vc = c->visClearedAt[thenFrame % RT_VIS_RING]; vc.frame = thenFrame; vc.rows[0] = rb; vc.rows[1] = re; }
+    auto& vc = c->visClearedAt[thenFrame % RT_VIS_RING]; vc.frame = thenFrame; vc.rows[0] = rb; vc.rows[1] = re;
+    // the tiles' words (rtggx_context.h visDirtyBuf): usable where they were kept for these very rows
+    const auto& vf = c->visFlags[c->frameCounter % RT_VIS_RING];
+    G.visDirty = vf.rasterFrame == c->frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? c->visDirtyBuf[c->frameCounter % RT_VIS_RING] : c->visDirtyOnes;
+    auto& vn = c->visFlags[thenFrame % RT_VIS_RING];
+    G.visDirtyNextOut = c->visDirtyBuf[thenFrame % RT_VIS_RING];
+    G.visDirtyNext = vn.rows[0] == rb && vn.rows[1] == re ? G.visDirtyNextOut : c->visDirtyOnes;
+    vn.rows[0] = rb; vn.rows[1] = re;
+  }
   G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;
   G.roughMetalPrev = c->roughMetalBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS];   // the previous frame's set
   G.diffPrev = c->genCarriesDiff ? c->rtDiffBuf[(c->setIndex + RT_SETS - 1u) % RT_SETS] : nullptr;

@@ -223,6 +223,12 @@ struct rtggx_context {
   // which target the last ray generation cleared for the next frame's visibility pass, and over which rows (visibility.hip)
   struct VisCleared { uint32_t frame = 0, rows[2] = {0, 0}; } visClearedAt[RT_VIS_RING];      // target k has been cleared, over these rows, FOR this frame (0: not)
   uint32_t visStandaloneClears = 0;
+  // Round 4: one word per 16x16 tile and target, set by the rasterisers where they draw: a tile whose word is 0 holds nothing but the clear
+  // value, and ray generation neither reads nor re-clears it (three quarters of the bunny frame: 16 bytes per pixel and the first of its
+  // dependent fetches).  Tiles are ray generation's, counted from the pass's first row: the words mean something only for the rows they
+  // were kept under (visFlags[k].rows; another strip: everything is read and cleared, which also resets the words).
+  uint32_t* visDirtyBuf[RT_VIS_RING] = {};
+  struct VisFlags { uint32_t rows[2] = {0, 0}; uint32_t rasterFrame = 0; } visFlags[RT_VIS_RING];      // word 0 => tile clear, for tiles counted from rows[0]; rasterFrame: the frame whose visibility pass drew into the target last
   uint32_t* depth32 = nullptr; uint32_t* depth32Buf[RT_SETS] = {};      // the D24 word of visDepth once more, 4 bytes per pixel, for the spatial filters (written by ray generation)
   uint32_t *normalBuf[RT_SETS] = {}, *velocityBuf[RT_SETS] = {}, *rtReflBuf[RT_SETS] = {}, *rtDiffBuf[RT_SETS] = {};
   uint16_t* roughMetalBuf[RT_SETS] = {};
@@ -252,6 +258,7 @@ struct rtggx_context {
   uint32_t* binWorkBuf[2] = {};         // by frame parity: ray generation of frame f reads what the traversal of frame f - 2 recorded
                                         // (frame f - 1's may still be running beside it) and the traversal of frame f records anew
   // per input set (the visibility pass of the next frame, which empties its set's list, may run beside this frame's traversal):
+  uint32_t* visDirtyOnes = nullptr;      // as many words as a visDirtyBuf, all ones: "every tile may hold something" (raytrace.hip GenArgs)
   uint32_t* splitListBuf[RT_SETS] = {}; // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a listed bin
   uint32_t* splitList = nullptr; uint32_t* splitCount = nullptr;     // the current set's (selectSet)
   uint32_t splitDemand = 0;             // entries the most recent frame whose count has arrived wanted (hostRayCounters[256])

@@ -109,7 +109,7 @@ struct __attribute__((aligned(16))) TriSetup {
 __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FrameParams* __restrict__ dst, uint32_t rowBegin, uint32_t rowEnd, const float* __restrict__ v0, const uint32_t* __restrict__ i0, uint32_t nt0,
                                                    const float* __restrict__ v1, const uint32_t* __restrict__ i1, uint32_t nt1,
                                                    unsigned long long* __restrict__ vd, LargeTri* __restrict__ large,
-                                                   uint32_t* __restrict__ largeCount, uint32_t largeCap) {
+                                                   uint32_t* __restrict__ largeCount, uint32_t largeCap, uint32_t* __restrict__ dirty, uint32_t tilesX) {
   constexpr uint32_t TPW = RT_RASTER_TPW;      // triangles per wave: a power of two, 1 .. 64
   __shared__ TriSetup setupMem[4 * TPW];
   __shared__ uint32_t prefixMem[4 * TPW];
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
               const unsigned long long key = fragmentKey((int32_t)px * 256 + 128, (int32_t)py * 256 + 128, X32, Y32, tl0, tl1, tl2, invA, z0, dz1, dz2, word);
               if (key == ~0ull) continue;
               unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
-              if (key < *dst) atomicMin(dst, key);
+              if (key < *dst) { atomicMin(dst, key); dirty[(((uint32_t)py - rowBegin) >> 4) * tilesX + ((uint32_t)px >> 4)] = 1u; }
             }
         }
       } else {
@@ -213,9 +213,10 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
     if (key == ~0ull) continue;
     unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
 #if RT_RASTER_PREREAD
-    if (key < *dst) atomicMin(dst, key);
+    if (key < *dst) { atomicMin(dst, key); dirty[(((uint32_t)py - rowBegin) >> 4) * tilesX + ((uint32_t)px >> 4)] = 1u; }      // (the tile's word: rtggx_context.h visDirtyBuf)
 #else
     atomicMin(dst, key);      // (no result used: the compiler emits the no-return form, nothing waits for it)
+    dirty[(((uint32_t)py - rowBegin) >> 4) * tilesX + ((uint32_t)px >> 4)] = 1u;
 #endif
   }
 }
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
 // 30 M wave quad-cycles per frame for 8 us of work (profiles/r03_k_pmc_report.txt); a quarter of the waves do the same work.
 #define RT_LARGE_ROWS 16
 __global__ void __launch_bounds__(256) rasterLarge(uint32_t W, uint32_t rowBegin, uint32_t rowEnd, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
-                                                   const uint32_t* __restrict__ largeCount, uint32_t largeCap) {
+                                                   const uint32_t* __restrict__ largeCount, uint32_t largeCap, uint32_t* __restrict__ dirty, uint32_t tilesX) {
   const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63);
   const uint32_t y0 = rowBegin + blockIdx.y * RT_LARGE_ROWS, py0 = y0 + (threadIdx.x >> 6);
   const uint32_t n = min(*largeCount, largeCap);
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(256) rasterLarge(uint32_t W, uint32_t rowBegin
     const uint32_t py = py0 + 4u * k;
     if (py < rowEnd && best[k] != ~0ull) {
       unsigned long long* dst = vd + (size_t)py * W + px;
-      if (best[k] < *dst) *dst = best[k];
+      if (best[k] < *dst) { *dst = best[k]; dirty[blockIdx.y * tilesX + (px >> 4)] = 1u; }      // (RT_LARGE_ROWS = 16: the block's rows are one row of tiles)
     }
   }
 }
@@ -272,11 +273,18 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   const uint32_t begin = rb * fp.W, end = re * fp.W;
   if (end <= begin) return 0;
   // the target was cleared for this frame by the ray generation two frames back -- unless it was not (see clearVisDepth)
-  auto& vc = c->visClearedAt[c->frameCounter % RT_VIS_RING];
+  const uint32_t target = c->frameCounter % RT_VIS_RING;
+  auto& vc = c->visClearedAt[target];
+  auto& vf = c->visFlags[target];
+  uint32_t* const dirty = c->visDirtyBuf[target];
+  const uint32_t tilesX = (fp.W + 15) / 16, tilesY = (re - rb + 15) / 16;
   if (!(vc.frame == c->frameCounter && vc.rows[0] <= rb && vc.rows[1] >= re)) {
     hipLaunchKernelGGL(clearVisDepth, dim3((end - begin + 1023) / 1024), dim3(256), 0, s, c->visDepth, begin, end, c->largeCount, c->splitCount);
+    RT_HIP(hipMemsetAsync(dirty, 0, (size_t)tilesX * tilesY * 4, s));
     ++c->visStandaloneClears;
   }
+  // (cleared ahead over a superset of these rows: every word the clear knew of is 0 and every pixel clear, whatever the tiles' origin)
+  vf.rows[0] = rb; vf.rows[1] = re; vf.rasterFrame = c->frameCounter;
   vc.frame = 0u;
   const uint32_t nt = c->mesh[0].numTris + c->mesh[1].numTris;
   FrameParams* const dst = c->slotUploaded ? (FrameParams*)nullptr : c->dParams + c->slot;
@@ -284,13 +292,13 @@ int launchVisibility(rtggx_context* c, const FrameParams& fp, hipStream_t s, hip
   // (with no triangles at all the kernel still runs, for the constants)
   const dim3 grid(nt ? (nt + 4u * RT_RASTER_TPW - 1u) / (4u * RT_RASTER_TPW) : 1u);
   hipLaunchKernelGGL(rasterSmall, grid, dim3(256), 0, s, fp, dst, rb, re, (const float*)c->mesh[0].verts, (const uint32_t*)c->mesh[0].indices, c->mesh[0].numTris,
-                     (const float*)c->mesh[1].verts, (const uint32_t*)c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity);
+                     (const float*)c->mesh[1].verts, (const uint32_t*)c->mesh[1].indices, c->mesh[1].numTris, c->visDepth, (LargeTri*)c->largeTris, c->largeCount, c->largeCapacity, dirty, tilesX);
   if (nt) {
     const dim3 lgrid((fp.W + 63) / 64, (re - rb + RT_LARGE_ROWS - 1) / RT_LARGE_ROWS);
     if (done && c->attachEvents) {      // the event rides on the pass's last kernel (rtggx_context.h)
-      hipExtLaunchKernelGGL(rasterLarge, lgrid, dim3(256), 0, s, nullptr, done, 0, fp.W, rb, re, c->visDepth, (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity);
+      hipExtLaunchKernelGGL(rasterLarge, lgrid, dim3(256), 0, s, nullptr, done, 0, fp.W, rb, re, c->visDepth, (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity, dirty, tilesX);
       done = nullptr;
-    } else hipLaunchKernelGGL(rasterLarge, lgrid, dim3(256), 0, s, fp.W, rb, re, c->visDepth, (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity);
+    } else hipLaunchKernelGGL(rasterLarge, lgrid, dim3(256), 0, s, fp.W, rb, re, c->visDepth, (const LargeTri*)c->largeTris, (const uint32_t*)c->largeCount, c->largeCapacity, dirty, tilesX);
   }
   if (done) hipEventRecord(done, s);
   RT_HIP(hipGetLastError());
@@ -305,6 +313,8 @@ int unpackVisDepth(rtggx_context* c, uint32_t* dVis, uint32_t* dDepth, hipStream
 }
 int packVisDepth(rtggx_context* c, const uint32_t* dVis, const uint32_t* dDepth, hipStream_t s) {
   const uint32_t n = c->W * c->H;
+  // a caller's visibility: every tile may hold something
+  RT_HIP(hipMemsetAsync(c->visDirtyBuf[c->frameCounter % RT_VIS_RING], 0xFF, (size_t)((c->W + 15) / 16) * ((c->H + 15) / 16 + 1) * 4, s));
   hipLaunchKernelGGL(packVisDepthKernel, dim3((n + 255) / 256), dim3(256), 0, s, c->visDepth, dVis, dDepth, n);
   RT_HIP(hipGetLastError());
   return 0;
