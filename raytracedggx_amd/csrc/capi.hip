@@ -1109,6 +1109,7 @@ int rtggx_upload(rtggx_context* c, int id, const void* src, size_t bytes) {
   if (bytes != need) { setError("rtggx_upload: buffer %d is %zu bytes, %zu given", id, need, bytes); return -1; }
   RT_HIP(syncStreams(c));
   c->toneMapDone = false;      // (a tone map after an upload reads what was uploaded)
+  c->visFlags[c->frameCounter % RT_VIS_RING].rasterFrame = 0u;      // ... and the tiles' words of this frame's visibility pass do not describe it (rtggx_context.h visDirtyBuf)
   if (id == RTGGX_BUF_VISIBILITY || id == RTGGX_BUF_DEPTH) {
     // replace one half of the packed buffer
     uint32_t *dVis, *dDepth;

@@ -70,7 +70,17 @@ struct Targets {
   // own buffer whatever it holds there -- rounds 2-3's "reported, not prevented").
   const uint2* const* peerHist; const uint32_t* peerBounds; int peerWorld;
   int outBegin, outEnd;      // rows of the back buffer (the strip itself): the fused temporal + tone-map kernel
+  // one word per 16x16 tile, counted from row tileRow0, tilesX to a row: 0 = the visibility pass drew nothing there, no pixel of it has a surface
+  // (rtggx_context.h visDirtyBuf; all ones where that is not known)
+  const uint32_t* tileWords; int tilesX, tileRow0;
 };
+// Four of those words OR-ed together: scalar loads, one wait (the indices are uniform over the workgroup).
+RT_DEV uint32_t tileWordsOr(const uint32_t* words, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3) {
+  uint32_t a, b, c, d;
+  asm volatile("s_load_dword %0, %4, %5\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %4, %7\n\ts_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(words), "s"(i0 * 4u), "s"(i1 * 4u), "s"(i2 * 4u), "s"(i3 * 4u) : "memory");
+  return a | b | c | d;
+}
 
 #define RT_LOG2E 1.44269504088896341f
 
@@ -206,6 +216,22 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
   const int lx = threadIdx.x % BW, ly = threadIdx.x / BW;
   const int x = bx0 + lx;
 
+  // Nothing drawn in the tiles the block lies in (three quarters of the bunny frame): no pixel has a surface, none is filtered -- known
+  // from four scalar loads instead of a read of the normals (whose latency was most of such a workgroup's life)
+  static_assert(RT_VBW <= 32 && RT_VBH <= 16, "the V block spans at most two tiles each way");
+  bool nothingDrawn;
+  { const uint32_t txLast = (uint32_t)T.tilesX - 1u, tx0 = (uint32_t)bx0 >> 4;
+    const uint32_t ty0 = (uint32_t)(by0 - T.tileRow0) >> 4, ty1 = (uint32_t)(min(by0 + BH, T.rowEnd) - 1 - T.tileRow0) >> 4;
+    const uint32_t r0 = ty0 * (uint32_t)T.tilesX, r1 = ty1 * (uint32_t)T.tilesX;
+    nothingDrawn = vertical ? tileWordsOr(T.tileWords, r0 + tx0, r0 + min(tx0 + 1u, txLast), r1 + tx0, r1 + min(tx0 + 1u, txLast)) == 0u
+                            : tileWordsOr(T.tileWords, r0 + tx0, r0 + min(tx0 + 1u, txLast), r0 + min(tx0 + 2u, txLast), r0 + min(tx0 + 3u, txLast)) == 0u; }
+  if (nothingDrawn) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { const int y = by0 + ly + k * ROWSTEP; if (x < T.W && y < T.rowEnd) storeSkipped<MODE>(T, (size_t)y * T.W + x); }
+    }
+    return;
+  }
   // which of my pixels are filtered at all; the others get their pass-through value now
   bool todo[PER]; bool any = false;
 #pragma unroll
@@ -621,6 +647,8 @@ static Targets makeTargets(rtggx_context* c, const FrameParams& fp, RowPass pass
   T.peerHist = peers ? reinterpret_cast<const uint2* const*>(c->dPeerTable) + (c->frameParity ^ 1u) * RT_MAX_PEERS : nullptr;
   T.peerBounds = peers ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint2* const*>(c->dPeerTable) + 2 * RT_MAX_PEERS) : nullptr;
   T.peerWorld = peers ? (int)c->peerWorld : 0;
+  { uint32_t gb, ge; passRows(fp, ROWS_GBUFFER, gb, ge);      // the tiles are ray generation's
+    T.tileWords = c->tileWords(gb, ge); T.tilesX = (int)((fp.W + 15) / 16); T.tileRow0 = (int)gb; }
   return T;
 }
 

@@ -427,6 +427,7 @@ struct ShadeArgs {
   uint32_t* reflOut; uint32_t* diffOut;
   // carry-over of RayTracingOut1 (see the kernel)
   const uint32_t* diffPrev; const unsigned long long* visDepth; uint32_t tilesX, rowBegin, rowEnd, carryMask;
+  const uint32_t* tileWords;      // one word per tile of this kernel, 0 = nothing was drawn there (rtggx_context.h visDirtyBuf): no rays, nothing to carry
 };
 
 // computeReflection at recursion depth 1 (:424-484)
@@ -452,6 +453,9 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) shadeKernel(const Fram
   // surface, ~8 000 per frame on one word, runs at the memory side of eight L2s: ray generation 80 -> 155 us in the frame, the frame
   // 0.185 -> 0.266 ms; one per tile behind a workgroup barrier: ray generation 80 -> 91 us, the frame +1.3 %.  profiles/r04_j_tile_words.txt)
   const uint32_t tile = blockIdx.x;
+  { uint32_t word;      // three quarters of the bunny frame's workgroups leave here, after one scalar load (before: a vector load of the bin's count each)
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(word) : "s"(A.tileWords), "s"(tile * 4u) : "memory");
+    if (word == 0u) return; }
   const uint32_t bin = tile * 4u + (threadIdx.x >> 6);
   // Carry-over of RayTracingOut1.  The reference has ONE such texture and leaves it untouched where no diffuse ray is traced
   // (covered pixels of a fully metallic instance, RayTracing.hlsl:559): it keeps the last value ever written there.  With three
@@ -533,8 +537,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
     G.visNext = c->visDepthBuf[thenFrame % RT_VIS_RING]; G.zeroNext0 = c->largeCountBase + (thenFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
     auto& vc = c->visClearedAt[thenFrame % RT_VIS_RING]; vc.frame = thenFrame; vc.rows[0] = rb; vc.rows[1] = re;
     // the tiles' words (rtggx_context.h visDirtyBuf): usable where they were kept for these very rows
-    const auto& vf = c->visFlags[c->frameCounter % RT_VIS_RING];
-    G.visDirty = vf.rasterFrame == c->frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? c->visDirtyBuf[c->frameCounter % RT_VIS_RING] : c->visDirtyOnes;
+    G.visDirty = c->tileWords(rb, re);
     auto& vn = c->visFlags[thenFrame % RT_VIS_RING];
     G.visDirtyNextOut = c->visDirtyBuf[thenFrame % RT_VIS_RING];
     G.visDirtyNext = vn.rows[0] == rb && vn.rows[1] == re ? G.visDirtyNextOut : c->visDirtyOnes;
@@ -596,6 +599,7 @@ int launchShade(rtggx_context* c, const FrameParams& fp, hipStream_t s, hipEvent
   // on the same stream.  The steady state of an all-metal scene: 8 bytes per covered pixel less (this loop reads the visibility word
   // again), and no dependency between the shading kernels of consecutive frames (capi.hip rtggx_ray_trace).
   if (c->genCarriesDiff) S.carryMask = 0u;
+  S.tileWords = c->tileWords(rb, re);
   S.rays = (const RayRec*)c->rayQueue; S.hits = (const HitKey*)c->hitQueue; S.binCount = c->binCount; S.binSlots = c->binSlots;
   S.fat0 = c->mesh[0].fat; S.fat1 = c->mesh[1].fat;
   S.env = c->env.texels; S.envMipOffset = c->dEnvMipOffset; S.envSize = c->env.size; S.envMips = c->env.mips; S.sh = c->sh;

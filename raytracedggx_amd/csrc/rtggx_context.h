@@ -258,6 +258,11 @@ struct rtggx_context {
   uint32_t* binWorkBuf[2] = {};         // by frame parity: ray generation of frame f reads what the traversal of frame f - 2 recorded
                                         // (frame f - 1's may still be running beside it) and the traversal of frame f records anew
   // per input set (the visibility pass of the next frame, which empties its set's list, may run beside this frame's traversal):
+  // the words of the current frame's target, for the kernels that follow its visibility pass: the target's own where they describe rows [rb, re), else all ones
+  const uint32_t* tileWords(uint32_t rb, uint32_t re) const {
+    const VisFlags& vf = visFlags[frameCounter % RT_VIS_RING];
+    return vf.rasterFrame == frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? visDirtyBuf[frameCounter % RT_VIS_RING] : visDirtyOnes;
+  }
   uint32_t* visDirtyOnes = nullptr;      // as many words as a visDirtyBuf, all ones: "every tile may hold something" (raytrace.hip GenArgs)
   uint32_t* splitListBuf[RT_SETS] = {}; // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a listed bin
   uint32_t* splitList = nullptr; uint32_t* splitCount = nullptr;     // the current set's (selectSet)
