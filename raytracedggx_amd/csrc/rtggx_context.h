@@ -263,6 +263,7 @@ struct rtggx_context {
     const VisFlags& vf = visFlags[frameCounter % RT_VIS_RING];
     return vf.rasterFrame == frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? visDirtyBuf[frameCounter % RT_VIS_RING] : visDirtyOnes;
   }
+  const uint32_t* traceTileWords = nullptr;      // launchRayTrace -> launchTrace: tileWords() of the frame's G-buffer rows
   uint32_t* visDirtyOnes = nullptr;      // as many words as a visDirtyBuf, all ones: "every tile may hold something" (raytrace.hip GenArgs)
   uint32_t* splitListBuf[RT_SETS] = {}; // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a listed bin
   uint32_t* splitList = nullptr; uint32_t* splitCount = nullptr;     // the current set's (selectSet)

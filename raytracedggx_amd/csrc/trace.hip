@@ -51,6 +51,7 @@ struct TraceArgs {
   size_t spillStride;
   uint32_t sliceShift;       // 0..3: a wave starts with 64, 32, 16, 8 rays of its bin (1, 2, 4, 8 waves per bin; the other lanes start as helpers)
   uint32_t tilesX, tilesY;   // tile grid of the frame (4 bins per 16x16 tile); tilesX == 0: bins are a plain list (rtggx_trace_rays)
+  const uint32_t* tileWords; // one word per tile, 0 = nothing drawn there, no rays (rtggx_context.h visDirtyBuf); null with a plain list
   // adaptive split: the first splitBlocks workgroups take their (bin, slice) from the split list; a bin marked as split
   // (binCount bits 8..) is left to them.  binWork: lane-steps spent per bin, for the next frame's decision; null when off.
   const uint32_t* splitList; const uint32_t* splitCount; uint32_t* binWork; uint32_t splitBlocks;
@@ -144,6 +145,11 @@ template <int TOP> __device__ __forceinline__ void traceItem(const FrameParams& 
       const uint32_t tx = (super % superX) * 8u + (inSuper & 7u), ty = (super / superX) * 8u + (inSuper >> 3);
       if (tx >= A.tilesX || ty >= A.tilesY) return;
       tile = ty * A.tilesX + tx;
+      // three quarters of the bunny frame's items are bins of tiles nothing was drawn in: known from a scalar load, where the bin's count
+      // below is a vector load a wave waited for eight times in a row
+      uint32_t word;
+      asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(word) : "s"(A.tileWords), "s"(tile * 4u) : "memory");
+      if (word == 0u) return;
     }
     bin = tile * 4u + ((sub * 4u + wave) >> shift); slice = (sub * 4u + wave) & (slices - 1u);
     if (bin >= A.numBins) return;
@@ -501,7 +507,7 @@ int launchTrace(rtggx_context* c, const FrameParams& fp, hipStream_t s, uint32_t
 #ifdef RT_TRACE_STATS
   hipLaunchKernelGGL(stampKernel, dim3(1), dim3(1), 0, s, c->rayCounterBuf + 1024);
 #endif
-  T.tilesX = tilesX; T.tilesY = tilesY;
+  T.tilesX = tilesX; T.tilesY = tilesY; T.tileWords = tilesX ? c->traceTileWords : nullptr;
   T.sliceShift = sliceShift;
   const bool adaptive = splitCap >= 0 && sliceShift == 0u && tilesX != 0u;
   T.splitList = c->splitList; T.splitCount = c->splitCount;
