@@ -74,12 +74,21 @@ struct Targets {
   // (rtggx_context.h visDirtyBuf; all ones where that is not known)
   const uint32_t* tileWords; int tilesX, tileRow0;
 };
+#define RT_SGPR(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))      // a workgroup-uniform value the compiler may have computed in vector registers
 // Four of those words OR-ed together: scalar loads, one wait (the indices are uniform over the workgroup).
 RT_DEV uint32_t tileWordsOr(const uint32_t* words, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3) {
   uint32_t a, b, c, d;
   asm volatile("s_load_dword %0, %4, %5\n\ts_load_dword %1, %4, %6\n\ts_load_dword %2, %4, %7\n\ts_load_dword %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
-               : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(words), "s"(i0 * 4u), "s"(i1 * 4u), "s"(i2 * 4u), "s"(i3 * 4u) : "memory");
+               : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(words), "s"(RT_SGPR(i0 * 4u)), "s"(RT_SGPR(i1 * 4u)), "s"(RT_SGPR(i2 * 4u)), "s"(RT_SGPR(i3 * 4u)) : "memory");
   return a | b | c | d;
+}
+
+RT_DEV uint32_t tileWordsOr6(const uint32_t* words, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, uint32_t i4, uint32_t i5) {
+  uint32_t a, b, c, d, e, f;
+  asm volatile("s_load_dword %0, %6, %7\n\ts_load_dword %1, %6, %8\n\ts_load_dword %2, %6, %9\n\ts_load_dword %3, %6, %10\n\ts_load_dword %4, %6, %11\n\ts_load_dword %5, %6, %12\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e), "=&s"(f)
+               : "s"(words), "s"(RT_SGPR(i0 * 4u)), "s"(RT_SGPR(i1 * 4u)), "s"(RT_SGPR(i2 * 4u)), "s"(RT_SGPR(i3 * 4u)), "s"(RT_SGPR(i4 * 4u)), "s"(RT_SGPR(i5 * 4u)) : "memory");
+  return a | b | c | d | e | f;
 }
 
 #define RT_LOG2E 1.44269504088896341f
@@ -218,13 +227,13 @@ __global__ void __launch_bounds__(256) spatialTiledKernel(Targets T) {
 
   // Nothing drawn in the tiles the block lies in (three quarters of the bunny frame): no pixel has a surface, none is filtered -- known
   // from four scalar loads instead of a read of the normals (whose latency was most of such a workgroup's life)
-  static_assert(RT_VBW <= 32 && RT_VBH <= 16, "the V block spans at most two tiles each way");
+  static_assert(RT_VBW <= 32 && RT_VBH <= 32, "the V block spans at most two tiles across and three down");
   bool nothingDrawn;
-  { const uint32_t txLast = (uint32_t)T.tilesX - 1u, tx0 = (uint32_t)bx0 >> 4;
+  { const uint32_t txLast = (uint32_t)T.tilesX - 1u, tx0 = (uint32_t)bx0 >> 4, tx1 = min(tx0 + 1u, txLast);
     const uint32_t ty0 = (uint32_t)(by0 - T.tileRow0) >> 4, ty1 = (uint32_t)(min(by0 + BH, T.rowEnd) - 1 - T.tileRow0) >> 4;
-    const uint32_t r0 = ty0 * (uint32_t)T.tilesX, r1 = ty1 * (uint32_t)T.tilesX;
-    nothingDrawn = vertical ? tileWordsOr(T.tileWords, r0 + tx0, r0 + min(tx0 + 1u, txLast), r1 + tx0, r1 + min(tx0 + 1u, txLast)) == 0u
-                            : tileWordsOr(T.tileWords, r0 + tx0, r0 + min(tx0 + 1u, txLast), r0 + min(tx0 + 2u, txLast), r0 + min(tx0 + 3u, txLast)) == 0u; }
+    const uint32_t r0 = ty0 * (uint32_t)T.tilesX, r1 = ty1 * (uint32_t)T.tilesX, rm = ((ty0 + ty1) >> 1) * (uint32_t)T.tilesX;
+    nothingDrawn = vertical ? tileWordsOr6(T.tileWords, r0 + tx0, r0 + tx1, rm + tx0, rm + tx1, r1 + tx0, r1 + tx1) == 0u
+                            : tileWordsOr(T.tileWords, r0 + tx0, r0 + tx1, r0 + min(tx0 + 2u, txLast), r0 + min(tx0 + 3u, txLast)) == 0u; }
   if (nothingDrawn) {
     if (MODE == 1) {
 #pragma unroll

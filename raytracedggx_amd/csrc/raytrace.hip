@@ -50,6 +50,9 @@ RT_DEV f3 cubeFaceDir(int face, float u, float v) {
     default: return mk3(-u, -v, -1.0f);
   }
 }
+// MIP0: the level is known to be 0 where it is called (the sky behind a pixel, a ray that misses): its texels start at offset 0, and
+// the offset table -- one more dependent fetch in front of every texel -- is not read.
+template <bool MIP0 = false>
 RT_DEV f3 cubeTexel(const EnvRef& e, uint32_t mip, int face, int x, int y) {
   const int s = (int)((e.size >> mip) ? (e.size >> mip) : 1u);
   if (x < 0 || y < 0 || x >= s || y >= s) {
@@ -58,9 +61,10 @@ RT_DEV f3 cubeTexel(const EnvRef& e, uint32_t mip, int face, int x, int y) {
     x = (int)floorf((uu * 0.5f + 0.5f) * (float)s); y = (int)floorf((vv * 0.5f + 0.5f) * (float)s);
     x = min(max(x, 0), s - 1); y = min(max(y, 0), s - 1);
   }
-  const uint2 t = e.texels[e.mipOffset[mip] + (uint32_t)face * (uint32_t)(s * s) + (uint32_t)(y * s + x)];
+  const uint2 t = e.texels[(MIP0 ? 0u : e.mipOffset[mip]) + (uint32_t)face * (uint32_t)(s * s) + (uint32_t)(y * s + x)];
   return mk3(f16ToF32(t.x & 0xFFFFu), f16ToF32(t.x >> 16), f16ToF32(t.y & 0xFFFFu));
 }
+template <bool MIP0 = false>
 RT_DEV f3 cubeBilinear(const EnvRef& e, uint32_t mip, int face, float u, float v) {
   const int s = (int)((e.size >> mip) ? (e.size >> mip) : 1u);
   const float x = (u * 0.5f + 0.5f) * (float)s - 0.5f, y = (v * 0.5f + 0.5f) * (float)s - 0.5f;
@@ -68,9 +72,14 @@ RT_DEV f3 cubeBilinear(const EnvRef& e, uint32_t mip, int face, float u, float v
   const float fx = x - x0, fy = y - y0;
   const int ix = (int)x0, iy = (int)y0;
   const float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
-  const f3 c00 = cubeTexel(e, mip, face, ix, iy), c10 = cubeTexel(e, mip, face, ix + 1, iy);
-  const f3 c01 = cubeTexel(e, mip, face, ix, iy + 1), c11 = cubeTexel(e, mip, face, ix + 1, iy + 1);
+  const f3 c00 = cubeTexel<MIP0>(e, mip, face, ix, iy), c10 = cubeTexel<MIP0>(e, mip, face, ix + 1, iy);
+  const f3 c01 = cubeTexel<MIP0>(e, mip, face, ix, iy + 1), c11 = cubeTexel<MIP0>(e, mip, face, ix + 1, iy + 1);
   return ((c00 * w00 + c10 * w10) + c01 * w01) + c11 * w11;
+}
+// environment(e, dir, 0): RayTracing.hlsl:620-625 (missMain) and the sky behind a pixel -- the same arithmetic with the level's constants folded
+RT_DEV f3 environmentLevel0(const EnvRef& e, f3 dir) {
+  int face; float u, v; cubeFaceUV(dir, face, u, v);
+  return cubeBilinear<true>(e, 0u, face, u, v);
 }
 __device__ __noinline__ f3 environment(EnvRef e, f3 dir, float level) {
   int face; float u, v; cubeFaceUV(dir, face, u, v);
@@ -270,6 +279,15 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
     // getPrimarySurface :277-333
     const unsigned long long visWord = drawn ? A.visDepth[pix] : RT_VIS_CLEAR;
     if (clearNext) A.visNext[pix] = RT_VIS_CLEAR;
+    // getSampleParam :394-406 -- of every pixel of a tile with something in it, before the visibility word is back: the table fetch then
+    // travels beside that word instead of behind the triangle's
+    float xiY = 0.0f, cosPhi = 0.0f, sinPhi = 0.0f;
+    if (drawn) {
+      uint32_t s = py * W + px;
+      s = rng(s); s += fp.g.FrameIndex; s = rng(s); s %= 256u;
+      xiY = (float)(rng(s) & 0xffffu) / 65536.0f;
+      cosPhi = A.cosSin[s]; sinPhi = A.cosSin[256 + s];
+    }
     uint32_t visibility = (uint32_t)visWord;
     A.depthOut[pix] = (uint32_t)(visWord >> 32);      // the filters read depth four bytes at a time instead of every other word of an 8-byte array
     f2 screenPos; screenPos.x = ((float)px + 0.5f) / (float)W * 2.0f - 1.0f; screenPos.y = ((float)py + 0.5f) / (float)H * 2.0f - 1.0f;
@@ -315,15 +333,10 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) rayGenKernel(const Fra
 
     if (!hit) {
       // degenerate ray [0,0] along -V always misses: missMain, environment mip 0; metallic 0 < 1 -> same for the diffuse target
-      const uint32_t c = packR11G11B10F(environment(env, -V, 0.0f));
+      const uint32_t c = packR11G11B10F(environmentLevel0(env, -V));
       A.reflOut[pix] = c;
       A.diffOut[pix] = c;
     } else {
-      // getSampleParam :394-406
-      uint32_t s = py * W + px;
-      s = rng(s); s += fp.g.FrameIndex; s = rng(s); s %= 256u;
-      const float xiY = (float)(rng(s) & 0xffffu) / 65536.0f;
-      const float cosPhi = A.cosSin[s], sinPhi = A.cosSin[256 + s];
       const uint32_t skip = (inst << 24) | prim;
       {  // computeReflection depth 0 :424-484
         const float a = rghMtl.x * rghMtl.x;
@@ -485,7 +498,7 @@ __global__ void __launch_bounds__(256, RT_GEN_MIN_BLOCKS) shadeKernel(const Fram
     const bool diffuseGroup = (rc.z & 1u) != 0u;
     const uint32_t srcInst = rc.y >> 24;
     f3 col;
-    if (hitId == 0xFFFFFFFFu) col = environment(env, dir, 0.0f);   // missMain :620-625
+    if (hitId == 0xFFFFFFFFu) col = environmentLevel0(env, dir);   // missMain :620-625
     else {
       // payload preset = color * metallic of the surface the ray left (:456); closestHitReflection returns it untouched when <= 0 (:573)
       const float m = fp.mat.RoughMetals[srcInst][1];
