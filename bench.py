@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--deform", type=float, default=0.0, help="amplitude of the breathing-model animation (-deform): new vertices and an asynchronous BVH refit every frame")
     ap.add_argument("--trace-waves", type=int, default=0, help="pin the size of the traversal's resident workgroup (10, 12, 14, 16) instead of letting the library steer it (measurement)")
     ap.add_argument("--collapse-weights", type=float, nargs=2, default=None, help="weights (area, triangle count) of the 4-wide collapse's objective (measurement; rtggx_debug_collapse_weights)")
+    ap.add_argument("--tile-words", choices=["on", "off"], default="on", help="off: every tile of the visibility target counts as drawn, as in rounds 1-3 (measurement)")
     ap.add_argument("--tone-map", choices=["auto", "fused", "two"], default="auto", help="temporal pass + tone map as one kernel or two (measurement; auto: the library's choice, fused on small launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (default: the job's CPU share, at most 16)")
@@ -205,6 +206,8 @@ def main():
         ctx.trace_residency(args.trace_waves)
     if not args.stub and args.collapse_weights:
         ctx.collapse_weights(*args.collapse_weights); ctx.build_as()
+    if not args.stub and args.tile_words == "off":
+        ctx.tile_words(False)
     if not args.stub and args.tone_map != "auto":
         ctx.fuse_tone_map(args.tone_map == "fused")
     for _ in range(0 if args.stub else args.prime_frames):

@@ -246,6 +246,11 @@ int  rtggx_debug_fuse_tone_map(rtggx_context* ctx, int mode);
  * 4 caller-owned stream) and placement (bits 0-3 / 4-7 / 8-11 / 16-19: stream of ray generation / traversal / hit shading / the visibility pass --
  * 0 main, 1 B, 2 C, 3 R --, bits 12-15 frames in flight).  Results do not depend on any of it. */
 int  rtggx_debug_placement(rtggx_context* ctx, int force_small, uint32_t* key, uint32_t* where);
+/* Diagnostic (round 4): the visibility pass keeps one word per 16x16 tile of its target -- "something was drawn here" -- and the kernels
+ * behind it (ray generation, traversal, hit shading, the tiled spatial filters) leave a tile whose word is 0 after a scalar load instead of
+ * fetching pixels to find that out; ray generation neither reads nor re-clears such a tile of the target (RayTracer.cpp:751-791 clears and
+ * reads the whole target every frame).  enable = 0: every tile is treated as drawn, as in rounds 1-3.  Same images either way. */
+int  rtggx_debug_tile_words(rtggx_context* ctx, int enable);
 /* Diagnostic: the two weights of the 4-wide collapse's objective (lbvh.hip "the 4-wide collapse"): a 4-wide node costs
  * area_weight x (its half-area / the root's) + tris_weight x (its triangles / all triangles) -- the chance that a random ray enters it,
  * and the chance that a ray STARTING on the mesh's surface (every ray of this path does) starts inside it.  set (may be null): weights for

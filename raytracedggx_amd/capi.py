@@ -31,7 +31,7 @@ EXPORTS = ["rtggx_last_error", "rtggx_create", "rtggx_destroy", "rtggx_set_strip
            "rtggx_transform_sh", "rtggx_render_visibility", "rtggx_ray_trace", "rtggx_denoise", "rtggx_tone_map", "rtggx_sync",
            "rtggx_ray_count", "rtggx_get_timings", "rtggx_enable_timing", "rtggx_buffer_size", "rtggx_readback", "rtggx_buffer_ptr",
            "rtggx_upload", "rtggx_frame_parity", "rtggx_bvh_root", "rtggx_trace_rays", "rtggx_ray_total", "rtggx_kernel_times", "rtggx_debug_counters", "rtggx_debug_trace_split", "rtggx_debug_trace_residency", "rtggx_get_stream", "rtggx_set_history_peers", "rtggx_history_ipc_export", "rtggx_history_ipc_open",
-           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_as_device", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_fuse_tone_map", "rtggx_debug_placement", "rtggx_debug_collapse_weights", "rtggx_debug_fence_wait", "rtggx_debug_shader_clock"]
+           "rtggx_set_async_compute", "rtggx_set_history_apron", "rtggx_history_overreach", "rtggx_copy_bandwidth", "rtggx_refit_as", "rtggx_refit_as_device", "rtggx_refit_stats", "rtggx_set_refit_policy", "rtggx_set_sampler", "rtggx_debug_fuse_tone_map", "rtggx_debug_placement", "rtggx_debug_tile_words", "rtggx_debug_collapse_weights", "rtggx_debug_fence_wait", "rtggx_debug_shader_clock"]
 
 
 class Timings(C.Structure):
@@ -178,6 +178,10 @@ class Context:
     def fuse_tone_map(self, mode):
         """True / False: the temporal pass always / never tone-maps its result as well; None: the library's choice (small launches) (diagnostic)."""
         self._check(self.L.rtggx_debug_fuse_tone_map(self.h, -1 if mode is None else 1 if mode else 0))
+
+    def tile_words(self, enable):
+        """False: every 16x16 tile of the visibility target counts as drawn (rounds 1-3); True: the tiles' words decide (diagnostic)."""
+        self._check(self.L.rtggx_debug_tile_words(self.h, 1 if enable else 0))
 
     def placement(self, force_small=-1):
         """Pins the `small launch` fact of the stream placement (0 / 1; -1: by the ray count) and returns the key and placement of the most

@@ -958,6 +958,11 @@ int rtggx_debug_fuse_tone_map(rtggx_context* c, int mode) {
 // key / where (either may be null): the most recent rtggx_ray_trace's key (bit 0 small, 1 strip, 2 deforming, 3 diffuse, 4 caller-owned
 // stream) and placement (bits 0-3 / 4-7 / 8-11: the streams of ray generation / traversal / hit shading -- 0 main, 1 B, 2 C, 3 R --,
 // bits 12-15 frames in flight).
+int rtggx_debug_tile_words(rtggx_context* c, int enable) {
+  RT_CHECK_CTX(c);
+  c->useTileWords = enable != 0;
+  return 0;
+}
 int rtggx_debug_placement(rtggx_context* c, int forceSmall, uint32_t* key, uint32_t* where) {
   RT_CHECK_CTX(c);
   if (forceSmall < -1 || forceSmall > 1) { setError("rtggx_debug_placement: force_small is -1, 0 or 1"); return -1; }

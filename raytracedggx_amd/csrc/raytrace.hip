@@ -553,7 +553,7 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
     G.visDirty = c->traceTileWords = c->tileWords(rb, re);
     auto& vn = c->visFlags[thenFrame % RT_VIS_RING];
     G.visDirtyNextOut = c->visDirtyBuf[thenFrame % RT_VIS_RING];
-    G.visDirtyNext = vn.rows[0] == rb && vn.rows[1] == re ? G.visDirtyNextOut : c->visDirtyOnes;
+    G.visDirtyNext = c->useTileWords && vn.rows[0] == rb && vn.rows[1] == re ? G.visDirtyNextOut : c->visDirtyOnes;
     vn.rows[0] = rb; vn.rows[1] = re;
   }
   G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;

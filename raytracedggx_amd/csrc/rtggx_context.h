@@ -261,8 +261,9 @@ struct rtggx_context {
   // the words of the current frame's target, for the kernels that follow its visibility pass: the target's own where they describe rows [rb, re), else all ones
   const uint32_t* tileWords(uint32_t rb, uint32_t re) const {
     const VisFlags& vf = visFlags[frameCounter % RT_VIS_RING];
-    return vf.rasterFrame == frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? visDirtyBuf[frameCounter % RT_VIS_RING] : visDirtyOnes;
+    return useTileWords && vf.rasterFrame == frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? visDirtyBuf[frameCounter % RT_VIS_RING] : visDirtyOnes;
   }
+  bool useTileWords = true;      // rtggx_debug_tile_words
   const uint32_t* traceTileWords = nullptr;      // launchRayTrace -> launchTrace: tileWords() of the frame's G-buffer rows
   uint32_t* visDirtyOnes = nullptr;      // as many words as a visDirtyBuf, all ones: "every tile may hold something" (raytrace.hip GenArgs)
   uint32_t* splitListBuf[RT_SETS] = {}; // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a listed bin

@@ -1193,6 +1193,48 @@ def test_every_stream_placement_free_running_equals_synchronised(built):
             a.OnDestroy(); b.OnDestroy()
 
 
+def test_tile_words_follow_strips_uploads_and_skipped_passes(built):
+    """Round 4: the visibility pass keeps a word per 16x16 tile of its target ("something was drawn here") and the kernels behind it leave
+    tiles whose word is 0 after a scalar load (rtggx_debug_tile_words; rtggx_context.h visDirtyBuf).  The words are only as good as their
+    bookkeeping: tiles are counted from the pass's first row, the target is cleared two frames ahead by another frame's ray generation, a
+    caller may upload a visibility buffer or skip a pass.  One context with the words, one without, through the same schedule of strip
+    changes (rows that are no multiple of 16, growing and shrinking), a frame without ray tracing and an uploaded visibility buffer -- every target of every frame identical inside the strip."""
+    from raytracedggx_amd import app, capi
+    W, H = 320, 180
+    args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", W, "-height", H, "-sharedmem", "-metallic", 1.0, 0.5, "-dt", 0.25]
+    a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
+    targets = ((capi.BUF_VISIBILITY, 1), (capi.BUF_DEPTH, 1), (capi.BUF_NORMAL, 1), (capi.BUF_ROUGH_METAL, 1), (capi.BUF_VELOCITY, 1), (capi.BUF_RT_REFL, 1), (capi.BUF_RT_DIFF, 1),
+               (capi.BUF_FLT_DFF, 1), (capi.BUF_TSS0, 1), (capi.BUF_TSS1, 1), (capi.BUF_BACKBUFFER, 1))
+    schedule = [(0, H)] * 3 + [(40, 140)] * 3 + [(37, 150)] * 3 + [(37, 120)] * 2 + [(0, H)] * 3 + [(8, H)] * 2 + [(8, 100)] * 3 + [(0, H)] * 2
+    try:
+        b.context.tile_words(False)
+        rows = None
+        for f, r in enumerate(schedule):
+            for x in (a, b):
+                c = x.context
+                if r != rows:
+                    c.set_strip(*r)
+                x.OnUpdate()
+                if f == 7:                                            # a frame whose passes the caller issues one by one
+                    c.render_visibility(); c.update_as(); c.ray_trace(); c.denoise(True); c.tone_map()
+                elif f == 12:                                         # a visibility pass and nothing behind it
+                    c.render_visibility()
+                elif f == 16:                                         # the caller's own visibility buffer (the one just rendered, handed back)
+                    c.render_visibility(); c.sync()
+                    c.upload(capi.BUF_VISIBILITY, c.readback(capi.BUF_VISIBILITY))
+                    c.update_as(); c.ray_trace(); c.denoise(True); c.tone_map()
+                else:
+                    x.OnRender()
+            rows = r
+            if f % 3 == 2 or f in (7, 12, 16):
+                a.context.sync(); b.context.sync()
+                for bid, _ in targets:
+                    ia, ib = a.context.readback(bid), b.context.readback(bid)
+                    np.testing.assert_array_equal(ia.reshape(H, W)[r[0]:r[1]], ib.reshape(H, W)[r[0]:r[1]], err_msg="frame %d rows %s buffer %d" % (f, r, bid))
+    finally:
+        a.OnDestroy(); b.OnDestroy()
+
+
 def test_update_as_after_render_visibility(built):
     """The C ABI allows rtggx_update_as after rtggx_render_visibility of the same frame (the sample overlaps the two on its two
     queues, RayTracedGGX.cpp:304-339): the visibility pass has then carried the slot to the device with the previous frame's TLAS,
