@@ -550,10 +550,11 @@ int launchRayTrace(rtggx_context* c, const FrameParams& fp, hipStream_t sGen, hi
     G.visNext = c->visDepthBuf[thenFrame % RT_VIS_RING]; G.zeroNext0 = c->largeCountBase + (thenFrame & 1u); G.zeroNext1 = c->largeCountBase + 2u + nextSet;
     auto& vc = c->visClearedAt[thenFrame % RT_VIS_RING]; vc.frame = thenFrame; vc.rows[0] = rb; vc.rows[1] = re;
     // the tiles' words (rtggx_context.h visDirtyBuf): usable where they were kept for these very rows
+    if (c->traceShare > 0.93f) c->traversalBound = true; else if (c->traceShare < 0.89f) c->traversalBound = false;
     G.visDirty = c->traceTileWords = c->tileWords(rb, re);
     auto& vn = c->visFlags[thenFrame % RT_VIS_RING];
     G.visDirtyNextOut = c->visDirtyBuf[thenFrame % RT_VIS_RING];
-    G.visDirtyNext = c->useTileWords && vn.rows[0] == rb && vn.rows[1] == re ? G.visDirtyNextOut : c->visDirtyOnes;
+    G.visDirtyNext = c->useTileWords && !c->traversalBound && vn.rows[0] == rb && vn.rows[1] == re ? G.visDirtyNextOut : c->visDirtyOnes;
     vn.rows[0] = rb; vn.rows[1] = re;
   }
   G.visDepth = c->visDepth; G.depthOut = c->depth32; G.normalOut = c->normal; G.roughMetalOut = c->roughMetal; G.velocityOut = c->velocity; G.reflOut = c->rtRefl; G.diffOut = c->rtDiff;

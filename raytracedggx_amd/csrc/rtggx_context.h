@@ -261,9 +261,15 @@ struct rtggx_context {
   // the words of the current frame's target, for the kernels that follow its visibility pass: the target's own where they describe rows [rb, re), else all ones
   const uint32_t* tileWords(uint32_t rb, uint32_t re) const {
     const VisFlags& vf = visFlags[frameCounter % RT_VIS_RING];
-    return useTileWords && vf.rasterFrame == frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? visDirtyBuf[frameCounter % RT_VIS_RING] : visDirtyOnes;
+    return useTileWords && !traversalBound && vf.rasterFrame == frameCounter && vf.rows[0] == rb && vf.rows[1] == re ? visDirtyBuf[frameCounter % RT_VIS_RING] : visDirtyOnes;
   }
   bool useTileWords = true;      // rtggx_debug_tile_words
+  // Where the TRAVERSAL is the frame's period (two rays per pixel into a large mesh: it runs 96 % of the time) nobody asks the words:
+  // workgroups over empty tiles that leave at once make the other stages' kernels run denser beside the traversal and stretch it -- dragon,
+  // metallic 0.25 / 0.5: 0.354 ms without the words, 0.360 with them everywhere but in the filters, 0.378 with them in the filters as well
+  // (profiles/r04_j_tile_words.txt).  Decided once per frame (launchRayTrace) from the share of the period the traversal's own time stamps
+  // measure (trace.hip steerTraceWaves), with hysteresis; the words themselves are kept either way.
+  bool traversalBound = false;
   const uint32_t* traceTileWords = nullptr;      // launchRayTrace -> launchTrace: tileWords() of the frame's G-buffer rows
   uint32_t* visDirtyOnes = nullptr;      // as many words as a visDirtyBuf, all ones: "every tile may hold something" (raytrace.hip GenArgs)
   uint32_t* splitListBuf[RT_SETS] = {}; // [RT_SPLIT_CAP] (shift << 28) | (slice << 24) | bin, one entry per wave of a listed bin

@@ -213,7 +213,9 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
     if (key == ~0ull) continue;
     unsigned long long* dst = vd + (size_t)py * fp.W + (size_t)px;
 #if RT_RASTER_PREREAD
-    if (key < *dst) { atomicMin(dst, key); dirty[(((uint32_t)py - rowBegin) >> 4) * tilesX + ((uint32_t)px >> 4)] = 1u; }      // (the tile's word: rtggx_context.h visDirtyBuf)
+    // (the tile's word, rtggx_context.h visDirtyBuf: set by whoever finds the pixel still clear -- the first atomic on a pixel comes from such a lane)
+    const unsigned long long before = *dst;
+    if (key < before) { atomicMin(dst, key); if (before == RT_VIS_CLEAR) dirty[(((uint32_t)py - rowBegin) >> 4) * tilesX + ((uint32_t)px >> 4)] = 1u; }
 #else
     atomicMin(dst, key);      // (no result used: the compiler emits the no-return form, nothing waits for it)
     dirty[(((uint32_t)py - rowBegin) >> 4) * tilesX + ((uint32_t)px >> 4)] = 1u;
