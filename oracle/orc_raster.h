@@ -13,8 +13,13 @@
 //   * near plane: a triangle with vertices on both sides of z_clip = 0 is clipped (Sutherland-Hodgman, one plane,
 //     new vertices by fp32 interpolation in clip space from the inside vertex towards the outside one, z set to 0)
 //     into one or two triangles that share the primitive id; the far plane needs no geometry (z <= 1 per pixel);
-//   * a (sub-)triangle with a vertex at w <= 0 or snapped coordinates beyond +-2^30 is dropped (no guard-band
-//     clipping: not reached by any BASELINE config).
+//   * guard band (round 4): a polygon (after the near clip) with a vertex outside |x| <= 256 w or |y| <= 256 w is clipped against those
+//     four planes, in that order (x <= 256 w, x >= -256 w, y <= 256 w, y >= -256 w), Sutherland-Hodgman in clip space, fp32, new
+//     vertices interpolated from the inside vertex towards the outside one with the clipped coordinate set to +-256 w, and the result
+//     is rasterised as a fan around its first vertex: snapped coordinates then stay below 2^30 for every frame size the context accepts
+//     (256 + 1 viewport half-widths of at most 8192 pixels x 256 sub-pixels = 2^29).  D3D's rasteriser clips to a guard band of its own
+//     choosing; which one is not observable from the reference, so this is the contract;
+//   * a (sub-)triangle with a vertex at w <= 0 is dropped.
 // Equal depth keeps the earlier fragment (LESS): lower instance first, then lower primitive.
 #pragma once
 #include "orc_scene.h"
@@ -61,6 +66,33 @@ static inline int clip_near(const float4 in[3], float4 out[4]) {
   return n;
 }
 
+// Guard-band clip of a convex polygon against plane 1..4 (see the header); returns the new vertex count (at most one more).
+static const float kGuard = 256.0f;
+static inline float guard_distance(const float4& v, int plane) {
+  const float gw = kGuard * v.w;
+  return plane == 1 ? gw - v.x : plane == 2 ? gw + v.x : plane == 3 ? gw - v.y : gw + v.y;
+}
+static inline int clip_guard(const float4* in, int n, float4* out, int plane) {
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    const float4& a = in[k]; const float4& b = in[(k + 1) % n];
+    const float da = guard_distance(a, plane), db = guard_distance(b, plane);
+    const bool ia = da >= 0.0f, ib = db >= 0.0f;
+    if (ia) out[m++] = a;
+    if (ia != ib) {
+      const float4& p = ia ? a : b; const float4& q = ia ? b : a;
+      const float dp = ia ? da : db, dq = ia ? db : da;
+      const float t = dp / (dp - dq);
+      float4 c; c.x = p.x + (q.x - p.x) * t; c.y = p.y + (q.y - p.y) * t; c.z = p.z + (q.z - p.z) * t; c.w = p.w + (q.w - p.w) * t;
+      const float gw = kGuard * c.w;
+      if (plane == 1) c.x = gw; else if (plane == 2) c.x = -gw; else if (plane == 3) c.y = gw; else c.y = -gw;
+      out[m++] = c;
+    }
+  }
+  return m;
+}
+static inline bool outside_guard(const float4& v) { const float gw = kGuard * v.w; return std::fabs(v.x) > gw || std::fabs(v.y) > gw; }
+
 static inline bool is_top_left(int64_t ax, int64_t ay, int64_t bx, int64_t by) {
   // front faces are clockwise in y-down screen space (area2 > 0): a top edge runs left->right
   // on a horizontal line, a left edge runs upwards.
@@ -77,11 +109,17 @@ static inline void render_visibility(Ctx& c) {
     const float* bias = c.fc.po[inst].ProjBias;
     const uint32_t ntri = (uint32_t)(m.idx.size() / 3);
     for (uint32_t prim = 0; prim < ntri; ++prim) {
-      float4 cp[3], poly[4];
+      float4 cp[3], poly[8], tmp[8];
       for (int k = 0; k < 3; ++k) cp[k] = clip_vertex(&m.verts[6 * (size_t)m.idx[3 * prim + k]], wvp, bias);
       const bool allIn = cp[0].z >= 0.0f && cp[1].z >= 0.0f && cp[2].z >= 0.0f;
       int nv = 3;
       if (allIn) { poly[0] = cp[0]; poly[1] = cp[1]; poly[2] = cp[2]; } else nv = clip_near(cp, poly);
+      bool guard = false;
+      for (int k = 0; k < nv; ++k) guard = guard || outside_guard(poly[k]);
+      if (guard) {
+        nv = clip_guard(poly, nv, tmp, 1); nv = clip_guard(tmp, nv, poly, 2);
+        nv = clip_guard(poly, nv, tmp, 3); nv = clip_guard(tmp, nv, poly, 4);
+      }
       for (int sub = 0; sub + 2 < nv; ++sub) {          // fan: (0,1,2), (0,2,3)
       RasterVert v[3];
       v[0] = raster_vertex(poly[0], W, H); v[1] = raster_vertex(poly[sub + 1], W, H); v[2] = raster_vertex(poly[sub + 2], W, H);

@@ -62,6 +62,35 @@ RT_DEV int clipNear(const f4 in[3], f4 out[4]) {
   }
   return n;
 }
+// Guard band (round 4; the contract is written down in oracle/orc_raster.h): a polygon with a vertex outside |x| <= 256 w, |y| <= 256 w is
+// clipped against those four planes in clip space before it is snapped -- the D3D rule behind RayTracer.cpp:751-791; rounds 1-3 dropped
+// a triangle whose snapped coordinates left +-2^30.
+#define RT_GUARD 256.0f
+RT_DEV float guardDistance(const f4& v, int plane) {
+  const float gw = RT_GUARD * v.w;
+  return plane == 1 ? gw - v.x : plane == 2 ? gw + v.x : plane == 3 ? gw - v.y : gw + v.y;
+}
+RT_DEV int clipGuard(const f4* in, int n, f4* out, int plane) {
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    const f4 a = in[k], b = in[k + 1 == n ? 0 : k + 1];
+    const float da = guardDistance(a, plane), db = guardDistance(b, plane);
+    const bool ia = da >= 0.0f, ib = db >= 0.0f;
+    if (ia) out[m++] = a;
+    if (ia != ib) {
+      const f4 p = ia ? a : b, q = ia ? b : a;
+      const float dp = ia ? da : db, dq = ia ? db : da;
+      const float t = dp / (dp - dq);
+      f4 c; c.x = p.x + (q.x - p.x) * t; c.y = p.y + (q.y - p.y) * t; c.z = p.z + (q.z - p.z) * t; c.w = p.w + (q.w - p.w) * t;
+      const float gw = RT_GUARD * c.w;
+      if (plane == 1) c.x = gw; else if (plane == 2) c.x = -gw; else if (plane == 3) c.y = gw; else c.y = -gw;
+      out[m++] = c;
+    }
+  }
+  return m;
+}
+RT_DEV bool outsideGuard(const f4& v) { const float gw = RT_GUARD * v.w; return fabsf(v.x) > gw || fabsf(v.y) > gw; }
+
 RT_DEV bool isTopLeft(long long ax, long long ay, long long bx, long long by) {
   const long long dx = bx - ax, dy = by - ay;
   return (dy == 0 && dx > 0) || dy < 0;
@@ -185,12 +214,19 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
     f4 cp[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) cp[k] = clipVertex(verts + 6 * (size_t)idx[3 * (size_t)prim + k], wvp, bx, by);
-    if (cp[0].z >= 0.0f && cp[1].z >= 0.0f && cp[2].z >= 0.0f) emit(cp[0], cp[1], cp[2], false);
-    else {                                            // crosses (or is behind) the near plane: rare
-      f4 poly[4];
-      const int nv = clipNear(cp, poly);
-      if (nv >= 3) emit(poly[0], poly[1], poly[2], true);
-      if (nv == 4) emit(poly[0], poly[2], poly[3], true);
+    const bool allIn = cp[0].z >= 0.0f && cp[1].z >= 0.0f && cp[2].z >= 0.0f;
+    if (allIn && !(outsideGuard(cp[0]) || outsideGuard(cp[1]) || outsideGuard(cp[2]))) emit(cp[0], cp[1], cp[2], false);
+    else {                                            // crosses (or is behind) the near plane, or leaves the guard band: rare
+      f4 poly[8], tmp[8];
+      int nv = 3;
+      if (allIn) { poly[0] = cp[0]; poly[1] = cp[1]; poly[2] = cp[2]; } else nv = clipNear(cp, poly);
+      bool guard = false;
+      for (int k = 0; k < nv; ++k) guard = guard || outsideGuard(poly[k]);
+      if (guard) {
+        nv = clipGuard(poly, nv, tmp, 1); nv = clipGuard(tmp, nv, poly, 2);
+        nv = clipGuard(poly, nv, tmp, 3); nv = clipGuard(tmp, nv, poly, 4);
+      }
+      for (int sub = 0; sub + 2 < nv; ++sub) emit(poly[0], poly[sub + 1], poly[sub + 2], true);      // a fan around the first vertex
     }
   }
   // exclusive prefix sum of the candidate counts over the wave

@@ -259,6 +259,20 @@ def test_model_crossing_the_near_plane(built):
         p.close()
 
 
+def test_triangle_far_beyond_the_guard_band(built):
+    """Round 4: a triangle whose vertices lie 10^7 units to the sides of the view -- 10^5 viewport widths, far beyond the 2^30 sub-pixel
+    units the snapped coordinates may take -- is clipped against the guard band (|x|, |y| <= 256 w in clip space: oracle/orc_raster.h
+    holds the contract) and rasterised as a fan, where rounds 1-3 dropped it: it covers the frame, with the oracle's words and depths,
+    and the rest of the frame's check holds on it."""
+    p = Pair(320, 180, mesh="triangle.obj", pos_scale=(0.0, -1.0e6, 0.0, 1.0e7), shared_mem=True)
+    try:
+        p.frame(); p.check_frame("a triangle 2 x 10^7 units wide")
+        vis = p.ctx.readback(p.capi.BUF_VISIBILITY)
+        assert (vis == 0x01000001).mean() > 0.7, "the triangle covers the frame where the ground does not hide it: %.3f" % (vis == 0x01000001).mean()
+    finally:
+        p.close()
+
+
 def test_lbvh_structure_and_device_traversal(built):
     from raytracedggx_amd import capi
     p = Pair(64, 64)
