@@ -278,6 +278,34 @@ def test_rasteriser_fill_rules(built):
     assert not (o.buffer(O.BUF_VISIBILITY) > 0).any()
 
 
+def test_rasteriser_guard_band(built):
+    """A triangle with vertices 3 x 10^6 viewport half-widths away (snapped coordinates far beyond 2^30 sub-pixel units) is clipped against the
+    guard band |x|, |y| <= 256 w (oracle/orc_raster.h holds the contract) and still covers every pixel, with the depth of its plane; one that
+    lies wholly beyond one guard plane covers nothing."""
+    W, H = 32, 16
+    big = [(-3.0e6, 3.0e6, 0.25), (3.0e6, 3.0e6, 0.5), (0.0, -6.0e6, 0.75)]      # clockwise on the y-down screen = front
+    o = _fullscreen_setup(W, H, [big])
+    o.render_visibility()
+    vis, depth = o.buffer(O.BUF_VISIBILITY).reshape(H, W), o.buffer(O.BUF_DEPTH).reshape(H, W)
+    assert (vis == 0x01000001).all()
+    # the plane z(x, y) through the three vertices, at the pixel centres
+    A = np.array([[x, y, 1.0] for x, y, _ in big], np.float64)
+    a, b, c = np.linalg.solve(A, np.array([z for _, _, z in big], np.float64))
+    xs = (np.arange(W) + 0.5) / (W / 2.0) - 1.0
+    ys = 1.0 - (np.arange(H) + 0.5) / (H / 2.0)
+    want = a * xs[None, :] + b * ys[:, None] + c
+    assert np.abs(depth.astype(np.float64) - want * 16777215.0).max() <= 4.0, np.abs(depth.astype(np.float64) - want * 16777215.0).max()
+    far_right = [(400.0, 1.0, 0.5), (500.0, 1.0, 0.5), (450.0, -1.0, 0.5)]
+    o = _fullscreen_setup(W, H, [far_right])
+    o.render_visibility()
+    assert not (o.buffer(O.BUF_VISIBILITY) > 0).any()
+    # ... and one that straddles the right guard plane but not the viewport changes nothing inside it
+    beside = [(2.0, 1.0, 0.5), (5.0e5, 1.0, 0.5), (3.0, -1.0, 0.5)]
+    o = _fullscreen_setup(W, H, [beside])
+    o.render_visibility()
+    assert not (o.buffer(O.BUF_VISIBILITY) > 0).any()
+
+
 def test_bvh_trace_equals_brute_force(built):
     # closest-hit semantics must not depend on the hierarchy (oracle/orc_bvh.h)
     o = O.Oracle(64, 64)
