@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--tile-words", choices=["on", "off"], default="on", help="off: every tile of the visibility target counts as drawn, as in rounds 1-3 (measurement)")
     ap.add_argument("--tone-map", choices=["auto", "fused", "two"], default="auto", help="temporal pass + tone map as one kernel or two (measurement; auto: the library's choice, fused on small launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained-frames", type=int, default=1024, help="N = 1: frames of a second, longer window after the timed one, reported as `sustained` (0: none)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (default: the job's CPU share, at most 16)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="timed oracle frames on all threads (one more, untimed, first); the single-thread leg times 1")
     ap.add_argument("--prime-frames", type=int, default=256, help="frames rendered during SET-UP, before the warm-up steps: the GPU's compute clock ramps for "
@@ -236,7 +237,6 @@ def main():
     rays_total = r.rays_traced_since_reset()
     own_rays = rays_total
     overreach = 0 if args.stub else r.history_overreach()
-
     if world > 1:
         t = torch.tensor([dt, float(rays_total), float(overreach)], dtype=torch.float64, device=device)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -257,6 +257,16 @@ def main():
             out["data"] = "none (stub)"
         else:
             out.update(report(r, args, W, H, world, ms_per_step, rays_total, own_rays, overreach, peak_measured, np))
+            # One more figure beside the contract's (N = 1 only; after everything above has been read): 1024 more frames.  The pipeline has
+            # two stable states; a short window after a barrier mostly reads the faster one, a long run spends most of its
+            # time in the slower one (profiles/r04_k_states.txt).
+            if world == 1 and args.sustained_frames > 0:
+                barrier(); ts = time.perf_counter()
+                for _ in range(args.sustained_frames):
+                    r.frame()
+                barrier()
+                out["sustained"] = {"frames": args.sustained_frames, "ms_per_step": round((time.perf_counter() - ts) * 1e3 / args.sustained_frames, 4),
+                                    "note": "after the timed region, same loop, bracketed the same way: what a long run reads (the pipeline's slower state included); `value` and `ms_per_step` are the contract's K steps"}
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:
