@@ -262,7 +262,9 @@ __global__ void __launch_bounds__(256) rasterSmall(const FrameParams fp, FramePa
 // The queued large triangles merged into the target: 64 x 16 pixels per workgroup, four per lane (rows y, y + 4, y + 8, y + 12).  One
 // pixel per lane made this a kernel of 32 400 waves at 1080p that each fetched the list, rejected most of it by bounding box and left:
 // 30 M wave quad-cycles per frame for 8 us of work (profiles/r03_k_pmc_report.txt); a quarter of the waves do the same work.
+#ifndef RT_LARGE_ROWS
 #define RT_LARGE_ROWS 16
+#endif
 __global__ void __launch_bounds__(256) rasterLarge(uint32_t W, uint32_t rowBegin, uint32_t rowEnd, unsigned long long* __restrict__ vd, const LargeTri* __restrict__ large,
                                                    const uint32_t* __restrict__ largeCount, uint32_t largeCap, uint32_t* __restrict__ dirty, uint32_t tilesX) {
   const uint32_t px = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(256) rasterLarge(uint32_t W, uint32_t rowBegin
     const uint32_t py = py0 + 4u * k;
     if (py < rowEnd && best[k] != ~0ull) {
       unsigned long long* dst = vd + (size_t)py * W + px;
-      if (best[k] < *dst) { *dst = best[k]; dirty[blockIdx.y * tilesX + (px >> 4)] = 1u; }      // (RT_LARGE_ROWS = 16: the block's rows are one row of tiles)
+      if (best[k] < *dst) { *dst = best[k]; dirty[((py - rowBegin) >> 4) * tilesX + (px >> 4)] = 1u; }
     }
   }
 }
