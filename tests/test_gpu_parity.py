@@ -1212,14 +1212,15 @@ def test_tile_words_follow_strips_uploads_and_skipped_passes(built):
     tiles whose word is 0 after a scalar load (rtggx_debug_tile_words; rtggx_context.h visDirtyBuf).  The words are only as good as their
     bookkeeping: tiles are counted from the pass's first row, the target is cleared two frames ahead by another frame's ray generation, a
     caller may upload a visibility buffer or skip a pass.  One context with the words, one without, through the same schedule of strip
-    changes (rows that are no multiple of 16, growing and shrinking), a frame without ray tracing and an uploaded visibility buffer -- every target of every frame identical inside the strip."""
+    changes (rows that are no multiple of 16, growing and shrinking), a frame without ray tracing and an uploaded visibility buffer, and a model that changes shape -- every target of every frame identical inside the strip."""
     from raytracedggx_amd import app, capi
     W, H = 320, 180
     args = ["-mesh", assets.path("bunny.obj"), "-env", assets.path("rnl_cross.dds"), "-width", W, "-height", H, "-sharedmem", "-metallic", 1.0, 0.5, "-dt", 0.25]
     a, b = app.RayTracedGGX(args), app.RayTracedGGX(args)
     targets = ((capi.BUF_VISIBILITY, 1), (capi.BUF_DEPTH, 1), (capi.BUF_NORMAL, 1), (capi.BUF_ROUGH_METAL, 1), (capi.BUF_VELOCITY, 1), (capi.BUF_RT_REFL, 1), (capi.BUF_RT_DIFF, 1),
                (capi.BUF_FLT_DFF, 1), (capi.BUF_TSS0, 1), (capi.BUF_TSS1, 1), (capi.BUF_BACKBUFFER, 1))
-    schedule = [(0, H)] * 3 + [(40, 140)] * 3 + [(37, 150)] * 3 + [(37, 120)] * 2 + [(0, H)] * 3 + [(8, H)] * 2 + [(8, 100)] * 3 + [(0, H)] * 2
+    schedule = [(0, H)] * 3 + [(40, 140)] * 3 + [(37, 150)] * 3 + [(37, 120)] * 2 + [(0, H)] * 3 + [(8, H)] * 2 + [(8, 100)] * 3 + [(0, H)] * 2 + [(0, H)] * 6 + [(21, 163)] * 3
+    v0, _, _ = O.obj_import(assets.path("bunny.obj"))
     try:
         b.context.tile_words(False)
         rows = None
@@ -1228,6 +1229,8 @@ def test_tile_words_follow_strips_uploads_and_skipped_passes(built):
                 c = x.context
                 if r != rows:
                     c.set_strip(*r)
+                if f >= 21:                                           # ... and the model changes shape from here on (a refit per frame, per input set)
+                    c.refit_as(1, _wave(v0, f))
                 x.OnUpdate()
                 if f == 7:                                            # a frame whose passes the caller issues one by one
                     c.render_visibility(); c.update_as(); c.ray_trace(); c.denoise(True); c.tone_map()
